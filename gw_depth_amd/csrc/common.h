@@ -1,0 +1,56 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes, MFMA 32x32 tiles).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gwdepth.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define GWD_CHECK_LAUNCH()                       \
+    do {                                         \
+        hipError_t e__ = hipGetLastError();      \
+        if (e__ != hipSuccess) return (int)e__;  \
+    } while (0)
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(__bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float v) {
+    // d/dv [ v * Phi(v) ] = Phi(v) + v * phi(v)
+    const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * v * v);
+    return cdf + v * pdf;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case GWD_ACT_RELU: return v > 0.f ? v : 0.f;
+        case GWD_ACT_GELU: return gelu_f(v);
+        case GWD_ACT_ELU: return v > 0.f ? v : expm1f(v);
+        case GWD_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

@@ -1,0 +1,485 @@
+// Implicit-GEMM convolution / linear layers on the CDNA4 matrix cores.
+//
+//   forward / data-gradient :  Y[m][n] = act( scale[n] * sum_k A[m][k] * W[n][k] + shift[n] + R[m][n] )
+//   weight-gradient         :  dW[n][k] += sum_m dY[m][n] * A[m][k]
+//
+// with m = (b, oh, ow) an output pixel, k = (kh, kw, c) and A the im2col view of an NHWC input that
+// is never materialised: every thread gathers 16-byte channel vectors straight from HBM, the gather
+// rule (plain / transposed for strided data gradients / nearest-upsampled input) is a scalar switch.
+// Tiles are staged through LDS (register-staged, double-buffered, one barrier per K step) and
+// consumed by 64-wide waves with v_mfma_f32_32x32x16_bf16 (bf16 storage, fp32 accumulate) or the
+// exact-fp32 v_mfma_f32_32x32x2_f32 (parity mode).  The epilogue fuses FrozenBN affine / bias,
+// residual add and ReLU / GELU / ELU / sigmoid so a Bottleneck conv writes its activation once.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct Cfg;
+template <> struct Cfg<float> { static constexpr int VEC = 4, BK = 16; };
+template <> struct Cfg<__bf16> { static constexpr int VEC = 8, BK = 32; };
+
+__device__ __forceinline__ bool src_pixel(const gwd_conv_desc &d, int oh, int ow, int kh, int kw, int &ih, int &iw) {
+    if (d.gather == GWD_GATHER_CONV) {
+        ih = oh * d.stride - d.pad + kh;
+        iw = ow * d.stride - d.pad + kw;
+        return (unsigned)ih < (unsigned)d.Hi && (unsigned)iw < (unsigned)d.Wi;
+    } else if (d.gather == GWD_GATHER_TRANSPOSED) {
+        const int th = oh + d.pad - kh, tw = ow + d.pad - kw;
+        if (th < 0 || tw < 0) return false;
+        if (d.stride == 1) {
+            ih = th;
+            iw = tw;
+        } else {
+            ih = th / d.stride;
+            iw = tw / d.stride;
+            if (ih * d.stride != th || iw * d.stride != tw) return false;
+        }
+        return ih < d.Hi && iw < d.Wi;
+    } else {  // GWD_GATHER_UPSAMPLED: legacy 'nearest' rule floor(dst * in/out), as aten upsample_nearest2d
+        const int vh = oh - d.pad + kh, vw = ow - d.pad + kw;
+        if ((unsigned)vh >= (unsigned)d.Hv || (unsigned)vw >= (unsigned)d.Wv) return false;
+        ih = min((int)floorf((float)vh * ((float)d.Hi / (float)d.Hv)), d.Hi - 1);
+        iw = min((int)floorf((float)vw * ((float)d.Wi / (float)d.Wv)), d.Wi - 1);
+        return true;
+    }
+}
+
+// One 16-byte vector of the im2col row of output pixel (b,oh,ow) starting at flattened k0.
+template <typename T>
+__device__ __forceinline__ uint4 gather_vec(const gwd_conv_desc &d, bool row_ok, int b, int oh, int ow, int k0, int K,
+                                            bool fast) {
+    constexpr int VEC = Cfg<T>::VEC;
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+    if (!row_ok || k0 >= K) return r;
+    const T *x = (const T *)d.x;
+    if (fast) {
+        const int tap = k0 / d.Cin, c = k0 - tap * d.Cin;
+        const int kh = tap / d.KW, kw = tap - kh * d.KW;
+        int ih, iw;
+        if (src_pixel(d, oh, ow, kh, kw, ih, iw))
+            r = *(const uint4 *)(x + ((size_t)(b * d.Hi + ih) * d.Wi + iw) * d.Cin + c);
+    } else {
+        T tmp[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int k = k0 + e;
+            T v = from_f32<T>(0.f);
+            if (k < K) {
+                const int tap = k / d.Cin, c = k - tap * d.Cin;
+                const int kh = tap / d.KW, kw = tap - kh * d.KW;
+                int ih, iw;
+                if (src_pixel(d, oh, ow, kh, kw, ih, iw)) v = x[((size_t)(b * d.Hi + ih) * d.Wi + iw) * d.Cin + c];
+            }
+            tmp[e] = v;
+        }
+        r = *(uint4 *)tmp;
+    }
+    return r;
+}
+
+// 16 bytes of row `n` of a row-major [rows][K] matrix starting at column k0 (zero outside).
+template <typename T>
+__device__ __forceinline__ uint4 row_vec(const T *base, int n, int N, int k0, int K, bool fast) {
+    constexpr int VEC = Cfg<T>::VEC;
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+    if (n >= N || k0 >= K) return r;
+    const T *p = base + (size_t)n * K + k0;
+    if (fast) return *(const uint4 *)p;
+    T tmp[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) tmp[e] = (k0 + e < K) ? p[e] : from_f32<T>(0.f);
+    return *(uint4 *)tmp;
+}
+
+__device__ __forceinline__ f32x16 mma(const bf16x8 &a, const bf16x8 &b, const f32x16 &c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma(float a, float b, const f32x16 &c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// ----------------------------------------------------------------------------------------------
+// forward / data gradient
+// ----------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_fwd_kernel(const gwd_conv_desc d) {
+    constexpr int VEC = Cfg<T>::VEC, BK = Cfg<T>::BK;
+    constexpr int KV = BK / VEC;        // 16-byte vectors per tile row (4)
+    constexpr int LDK = BK + VEC;       // padded LDS row: 80 bytes, conflict-free ds_read_b128
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int ROWS_PER_PASS = 256 / KV;  // 64
+    constexpr int A_IT = BM / ROWS_PER_PASS;
+    constexpr int B_IT = (BN + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
+    static_assert(WM * WN == 4, "4 waves");
+
+    __shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * LDK];
+    T *As = smem;
+    T *Bs = smem + 2 * BM * LDK;
+
+    const int M = d.B * d.Ho * d.Wo, N = d.Cout, K = d.KH * d.KW * d.Cin;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const bool fastA = (d.Cin % VEC) == 0, fastB = (K % VEC) == 0;
+
+    const int lv = tid % KV, lr = tid / KV;
+    int a_b[A_IT], a_oh[A_IT], a_ow[A_IT];
+    bool a_ok[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + lr + i * ROWS_PER_PASS;
+        a_ok[i] = m < M;
+        const int mm = a_ok[i] ? m : 0;
+        a_b[i] = mm / (d.Ho * d.Wo);
+        const int rem = mm - a_b[i] * (d.Ho * d.Wo);
+        a_oh[i] = rem / d.Wo;
+        a_ow[i] = rem - a_oh[i] * d.Wo;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int KT = (K + BK - 1) / BK;
+    uint4 ra[A_IT], rb[B_IT];
+
+    auto load_tiles = [&](int kt) {
+        const int k0 = kt * BK + lv * VEC;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) ra[i] = gather_vec<T>(d, a_ok[i], a_b[i], a_oh[i], a_ow[i], k0, K, fastA);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int row = lr + i * ROWS_PER_PASS;
+            rb[i] = (row < BN) ? row_vec<T>((const T *)d.w, n0 + row, N, k0, K, fastB) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            *(uint4 *)(As + (size_t)buf * BM * LDK + (lr + i * ROWS_PER_PASS) * LDK + lv * VEC) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int row = lr + i * ROWS_PER_PASS;
+            if (row < BN) *(uint4 *)(Bs + (size_t)buf * BN * LDK + row * LDK + lv * VEC) = rb[i];
+        }
+    };
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) load_tiles(kt + 1);
+        const T *Ab = As + (size_t)cur * BM * LDK + (wm * (BM / WM) + fr) * LDK;
+        const T *Bb = Bs + (size_t)cur * BN * LDK + (wn * (BN / WN) + fr) * LDK;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 af[TM], bfr[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8 *)(Ab + i * 32 * LDK + ks * 16 + fh * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bfr[j] = *(const bf16x8 *)(Bb + j * 32 * LDK + ks * 16 + fh * 8);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mma(af[i], bfr[j], acc[i][j]);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < BK / 2; ++ks) {
+                float af[TM], bfr[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = Ab[i * 32 * LDK + ks * 2 + fh];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bfr[j] = Bb[j * 32 * LDK + ks * 2 + fh];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mma(af[i], bfr[j], acc[i][j]);
+            }
+        }
+        if (kt + 1 < KT) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    T *y = (T *)d.y;
+    T *z = (T *)d.z;
+    const T *res = (const T *)d.residual;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / WN) + j * 32 + fr;
+        if (n >= N) continue;
+        const float sc = d.scale ? d.scale[n] : 1.0f;
+        const float sh = d.shift ? d.shift[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (m >= M) continue;
+                const size_t o = (size_t)m * N + n;
+                float v = acc[i][j][r] * sc + sh;
+                if (res) v += to_f32(res[o]);
+                if (z) z[o] = from_f32<T>(v);
+                v = apply_act(v, d.act) * d.act_scale;
+                y[o] = from_f32<T>(v);
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// weight gradient
+// ----------------------------------------------------------------------------------------------
+template <typename T, int BNW, int BKW>
+__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const gwd_conv_desc d, float *__restrict__ dw, int m_per_block) {
+    constexpr int VEC = Cfg<T>::VEC, RM = Cfg<T>::BK;  // reduction rows per step
+    // row strides chosen so the transposed bf16 reads (ds_read_b64_tr_b16) of one 32-lane half hit
+    // 64 distinct banks: stride(words) mod 64 == 16.  fp32 reads are single words: any stride works.
+    constexpr int LDY = (sizeof(T) == 2) ? (BNW == 64 ? 96 : 160) : BNW + 4;
+    constexpr int LDX = (sizeof(T) == 2) ? (BKW == 64 ? 96 : 160) : BKW + 4;
+    constexpr int TN = BNW / 64, TK = BKW / 64;  // 32x32 tiles per wave (2x2 waves)
+    constexpr int YV = BNW / VEC, XV = BKW / VEC;  // vectors per row
+    constexpr int Y_IT = RM * YV / 256, X_IT = RM * XV / 256;
+    static_assert(Y_IT >= 1 && X_IT >= 1, "tile too small");
+
+    __shared__ __attribute__((aligned(16))) T smem[2 * RM * (LDY + LDX)];
+    T *Ys = smem;
+    T *Xs = smem + 2 * RM * LDY;
+
+    const int M = d.B * d.Ho * d.Wo, N = d.Cout, K = d.KH * d.KW * d.Cin;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int kb0 = blockIdx.x * BKW, n0 = blockIdx.y * BNW;
+    const int m_begin = blockIdx.z * m_per_block;
+    const int m_end = min(M, m_begin + m_per_block);
+    const bool fastA = (d.Cin % VEC) == 0, fastY = (N % VEC) == 0;
+    const T *gy = (const T *)d.y;
+
+    f32x16 acc[TN][TK];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 ry[Y_IT], rx[X_IT];
+    auto load_tiles = [&](int mbase) {
+#pragma unroll
+        for (int i = 0; i < Y_IT; ++i) {
+            const int idx = tid + i * 256, row = idx / YV, v = idx % YV;
+            const int m = mbase + row;
+            ry[i] = (m < m_end) ? row_vec<T>(gy, m, M, n0 + v * VEC, N, fastY) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < X_IT; ++i) {
+            const int idx = tid + i * 256, row = idx / XV, v = idx % XV;
+            const int m = mbase + row;
+            const bool ok = m < m_end;
+            const int mm = ok ? m : 0;
+            const int b = mm / (d.Ho * d.Wo);
+            const int rem = mm - b * (d.Ho * d.Wo);
+            const int oh = rem / d.Wo, ow = rem - oh * d.Wo;
+            rx[i] = gather_vec<T>(d, ok, b, oh, ow, kb0 + v * VEC, K, fastA);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < Y_IT; ++i) {
+            const int idx = tid + i * 256, row = idx / YV, v = idx % YV;
+            *(uint4 *)(Ys + (size_t)buf * RM * LDY + row * LDY + v * VEC) = ry[i];
+        }
+#pragma unroll
+        for (int i = 0; i < X_IT; ++i) {
+            const int idx = tid + i * 256, row = idx / XV, v = idx % XV;
+            *(uint4 *)(Xs + (size_t)buf * RM * LDX + row * LDX + v * VEC) = rx[i];
+        }
+    };
+
+    const int steps = (m_end - m_begin + RM - 1) / RM;
+    if (steps > 0) {
+        load_tiles(m_begin);
+        store_tiles(0);
+    }
+    __syncthreads();
+    const int fr = lane & 31, fh = lane >> 5;
+    // transposed-read geometry: 16-lane group g reads the 4x16 block rows 8*(g>>1)+4*rd.., cols 16*(g&1)..
+    const int g = lane >> 4, t = lane & 15;
+    for (int s = 0; s < steps; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < steps) load_tiles(m_begin + (s + 1) * RM);
+        const T *Yb = Ys + (size_t)cur * RM * LDY + wn * (BNW / 2);
+        const T *Xb = Xs + (size_t)cur * RM * LDX + wk * (BKW / 2);
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int ks = 0; ks < RM / 16; ++ks) {
+                bf16x8 af[TN], bfr[TK];
+                const int row = ks * 16 + 8 * (g >> 1) + (t >> 2);
+                const int col = 16 * (g & 1) + 4 * (t & 3);
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    const T *p = Yb + row * LDY + i * 32 + col;
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p + 4 * LDY));
+                    union { s16x4 h[2]; bf16x8 v; } u;
+                    u.h[0] = lo;
+                    u.h[1] = hi;
+                    af[i] = u.v;
+                }
+#pragma unroll
+                for (int j = 0; j < TK; ++j) {
+                    const T *p = Xb + row * LDX + j * 32 + col;
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p + 4 * LDX));
+                    union { s16x4 h[2]; bf16x8 v; } u;
+                    u.h[0] = lo;
+                    u.h[1] = hi;
+                    bfr[j] = u.v;
+                }
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TK; ++j) acc[i][j] = mma(af[i], bfr[j], acc[i][j]);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < RM / 2; ++ks) {
+                float af[TN], bfr[TK];
+#pragma unroll
+                for (int i = 0; i < TN; ++i) af[i] = Yb[(ks * 2 + fh) * LDY + i * 32 + fr];
+#pragma unroll
+                for (int j = 0; j < TK; ++j) bfr[j] = Xb[(ks * 2 + fh) * LDX + j * 32 + fr];
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TK; ++j) acc[i][j] = mma(af[i], bfr[j], acc[i][j]);
+            }
+        }
+        if (s + 1 < steps) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < TK; ++j) {
+        const int k = kb0 + wk * (BKW / 2) + j * 32 + fr;
+        if (k >= K) continue;
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * (BNW / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (n < N) unsafeAtomicAdd(dw + (size_t)n * K + k, acc[i][j][r]);
+            }
+    }
+}
+
+template <typename T>
+__global__ void weight_prep_kernel(const float *__restrict__ w, const float *__restrict__ rs, T *__restrict__ wf,
+                                   T *__restrict__ wd, int N, int taps, int C) {
+    const size_t total = (size_t)N * taps * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t r = i / C;
+        const int tap = (int)(r % taps), n = (int)(r / taps);
+        const float v = rs ? w[i] * rs[n] : w[i];
+        if (wf) wf[i] = from_f32<T>(v);
+        if (wd) wd[((size_t)c * taps + tap) * N + n] = from_f32<T>(v);
+    }
+}
+
+int check_desc(const gwd_conv_desc *d) {
+    if (!d || !d->x || !d->y) return -1;
+    if (d->dtype != GWD_F32 && d->dtype != GWD_BF16) return -2;
+    if (d->B <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Cin <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0) return -3;
+    if (d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->pad < 0) return -4;
+    if (d->gather < 0 || d->gather > 2) return -5;
+    if (d->gather == GWD_GATHER_UPSAMPLED && (d->stride != 1 || d->Hv <= 0 || d->Wv <= 0)) return -6;
+    if ((int64_t)d->B * d->Ho * d->Wo >= (1LL << 31) || (int64_t)d->KH * d->KW * d->Cin >= (1LL << 31)) return -7;
+    if ((int64_t)d->B * d->Hi * d->Wi * d->Cin >= (1LL << 40)) return -7;
+    return 0;
+}
+
+template <typename T>
+int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
+    const int M = d->B * d->Ho * d->Wo, N = d->Cout;
+    if (N > 64) {
+        dim3 grid((M + 127) / 128, (N + 127) / 128);
+        igemm_fwd_kernel<T, 128, 128, 2, 2><<<grid, 256, 0, s>>>(*d);
+    } else if (N > 32) {
+        dim3 grid((M + 127) / 128, 1);
+        igemm_fwd_kernel<T, 128, 64, 2, 2><<<grid, 256, 0, s>>>(*d);
+    } else {
+        dim3 grid((M + 127) / 128, 1);
+        igemm_fwd_kernel<T, 128, 32, 4, 1><<<grid, 256, 0, s>>>(*d);
+    }
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T>
+int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s) {
+    constexpr int RM = Cfg<T>::BK;
+    const int M = d->B * d->Ho * d->Wo, N = d->Cout, K = d->KH * d->KW * d->Cin;
+    const bool big = (N > 64 && K > 64);
+    const int bn = big ? 128 : 64, bk = big ? 128 : 64;
+    const int tiles = ((N + bn - 1) / bn) * ((K + bk - 1) / bk);
+    // enough M-splits to put ~4 blocks on every CU, at least 8 reduction steps per block
+    int splits = (1024 + tiles - 1) / tiles;
+    const int max_splits = (M + 8 * RM - 1) / (8 * RM);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int m_per_block = (M + splits - 1) / splits;
+    m_per_block = ((m_per_block + RM - 1) / RM) * RM;
+    splits = (M + m_per_block - 1) / m_per_block;
+    dim3 grid((K + bk - 1) / bk, (N + bn - 1) / bn, splits);
+    if (grid.y > 65535 || grid.z > 65535) return -8;
+    if (big)
+        igemm_wgrad_kernel<T, 128, 128><<<grid, 256, 0, s>>>(*d, dw, m_per_block);
+    else
+        igemm_wgrad_kernel<T, 64, 64><<<grid, 256, 0, s>>>(*d, dw, m_per_block);
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int gwd_conv_forward(const gwd_conv_desc *d, void *stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!d->w) return -1;
+    if ((int64_t)d->B * d->Ho * d->Wo * d->Cout >= (1LL << 40)) return -7;
+    return d->dtype == GWD_BF16 ? launch_fwd<__bf16>(d, (hipStream_t)stream) : launch_fwd<float>(d, (hipStream_t)stream);
+}
+
+extern "C" int gwd_conv_wgrad(const gwd_conv_desc *d, float *dw, void *stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!dw) return -1;
+    return d->dtype == GWD_BF16 ? launch_wgrad<__bf16>(d, dw, (hipStream_t)stream)
+                                : launch_wgrad<float>(d, dw, (hipStream_t)stream);
+}
+
+extern "C" int gwd_weight_prep(const float *w, const float *row_scale, void *w_fwd, void *w_dgrad, int32_t N,
+                               int32_t taps, int32_t C, int32_t dtype, void *stream) {
+    if (!w || N <= 0 || taps <= 0 || C <= 0) return -1;
+    const size_t total = (size_t)N * taps * C;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (dtype == GWD_BF16)
+        weight_prep_kernel<__bf16><<<blocks, 256, 0, (hipStream_t)stream>>>(w, row_scale, (__bf16 *)w_fwd, (__bf16 *)w_dgrad, N, taps, C);
+    else if (dtype == GWD_F32)
+        weight_prep_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>(w, row_scale, (float *)w_fwd, (float *)w_dgrad, N, taps, C);
+    else
+        return -2;
+    GWD_CHECK_LAUNCH();
+    return 0;
+}

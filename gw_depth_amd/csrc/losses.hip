@@ -1,0 +1,171 @@
+// Loss reductions: SiLog (masked, per-scale nearest-resized GT gathered on the fly) and 2-class CE.
+// Sums are accumulated in double (block shuffle-reduce, then one f64 atomic per block), which keeps
+// the fp32 loss value run-to-run stable without a second pass.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ double block_sum_d(double v, double *sh) {
+    v = wave_sum_d(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+    __syncthreads();
+    return r;  // valid on thread 0
+}
+
+// nearest source index exactly as aten::upsample_nearest2d: min(floor(dst * in/out), in-1)
+__device__ __forceinline__ int nearest_src(int dst, int in, int out) {
+    return min((int)floorf((float)dst * ((float)in / (float)out)), in - 1);
+}
+
+template <typename T>
+__device__ __forceinline__ bool silog_term(const T *pred, const float *gt, int64_t i, int h, int w, int H, int W,
+                                            int log_err, float &d, float &p) {
+    const int x = (int)(i % w);
+    const int64_t r = i / w;
+    const int y = (int)(r % h);
+    const int64_t b = r / h;
+    const float g = gt[(b * H + nearest_src(y, H, h)) * W + nearest_src(x, W, w)];
+    if (!(g >= 0.2f && g < 10.0f)) return false;
+    p = to_f32(pred[i]);
+    d = log_err ? (logf(p) - logf(g)) : ((p + logf(p)) - (g + logf(g)));
+    return true;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void silog_sums_kernel(const T *__restrict__ pred, const float *__restrict__ gt,
+                                                         double *__restrict__ sums, int64_t total, int h, int w, int H,
+                                                         int W, int log_err) {
+    __shared__ double sh[4];
+    double s1 = 0.0, s2 = 0.0, cnt = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float d, p;
+        if (silog_term(pred, gt, i, h, w, H, W, log_err, d, p)) {
+            s1 += d;
+            s2 += (double)d * d;
+            cnt += 1.0;
+        }
+    }
+    s1 = block_sum_d(s1, sh);
+    s2 = block_sum_d(s2, sh);
+    cnt = block_sum_d(cnt, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd(sums + 0, s1);
+        atomicAdd(sums + 1, s2);
+        atomicAdd(sums + 2, cnt);
+    }
+}
+
+template <typename T>
+__global__ void silog_bwd_kernel(const T *__restrict__ pred, const float *__restrict__ gt, const double *__restrict__ sums,
+                                 const float *__restrict__ gloss, float loss_weight, float lambda, T *__restrict__ gpred,
+                                 int64_t total, int h, int w, int H, int W, int log_err) {
+    const double n = sums[2];
+    const double mean = sums[0] / n, var = sums[1] / n - (double)lambda * mean * mean;
+    // L = 10 sqrt(var);  dL/dd_i = 10/(2 sqrt(var)) * (2 d_i / n - 2 lambda mean / n)
+    const float c = (float)(10.0 / sqrt(var) / n) * loss_weight * gloss[0];
+    const float lm = (float)((double)lambda * mean);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float d, p, g = 0.f;
+        if (silog_term(pred, gt, i, h, w, H, W, log_err, d, p)) g = c * (d - lm) * (log_err ? 1.0f / p : 1.0f + 1.0f / p);
+        gpred[i] = from_f32<T>(g);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void seg_ce_sum_kernel(const T *__restrict__ logits, const int64_t *__restrict__ target,
+                                                         double *__restrict__ sum, int64_t P) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        const float a = to_f32(logits[2 * i]), b = to_f32(logits[2 * i + 1]);
+        const float mx = fmaxf(a, b);
+        const float lse = mx + logf(expf(a - mx) + expf(b - mx));
+        s += (double)(lse - (target[i] ? b : a));
+    }
+    s = block_sum_d(s, sh);
+    if (threadIdx.x == 0) atomicAdd(sum, s);
+}
+
+template <typename T>
+__global__ void seg_ce_bwd_kernel(const T *__restrict__ logits, const int64_t *__restrict__ target,
+                                  const float *__restrict__ gloss, float scale, T *__restrict__ gl, int64_t P) {
+    const float c = gloss[0] * scale / (float)P;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        const float a = to_f32(logits[2 * i]), b = to_f32(logits[2 * i + 1]);
+        const float mx = fmaxf(a, b);
+        const float ea = expf(a - mx), eb = expf(b - mx), inv = 1.0f / (ea + eb);
+        const int t = target[i] != 0;
+        gl[2 * i] = from_f32<T>(c * (ea * inv - (t ? 0.f : 1.f)));
+        gl[2 * i + 1] = from_f32<T>(c * (eb * inv - (t ? 1.f : 0.f)));
+    }
+}
+
+inline int flat_grid(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" int gwd_silog_sums(const void *pred, const float *gt, double *sums, int32_t B, int32_t h, int32_t w, int32_t H,
+                              int32_t W, int32_t log_depth_error, int32_t dtype, void *stream) {
+    if (!pred || !gt || !sums || B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return -1;
+    const int64_t total = (int64_t)B * h * w;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GWD_BF16)
+        silog_sums_kernel<__bf16><<<flat_grid(total), 256, 0, s>>>((const __bf16 *)pred, gt, sums, total, h, w, H, W, log_depth_error);
+    else if (dtype == GWD_F32)
+        silog_sums_kernel<float><<<flat_grid(total), 256, 0, s>>>((const float *)pred, gt, sums, total, h, w, H, W, log_depth_error);
+    else
+        return -2;
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gwd_silog_backward(const void *pred, const float *gt, const double *sums, const float *gloss,
+                                  float loss_weight, float lambda, void *gpred, int32_t B, int32_t h, int32_t w,
+                                  int32_t H, int32_t W, int32_t log_depth_error, int32_t dtype, void *stream) {
+    if (!pred || !gt || !sums || !gloss || !gpred || B <= 0 || h <= 0 || w <= 0) return -1;
+    const int64_t total = (int64_t)B * h * w;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GWD_BF16)
+        silog_bwd_kernel<__bf16><<<flat_grid(total), 256, 0, s>>>((const __bf16 *)pred, gt, sums, gloss, loss_weight, lambda, (__bf16 *)gpred, total, h, w, H, W, log_depth_error);
+    else if (dtype == GWD_F32)
+        silog_bwd_kernel<float><<<flat_grid(total), 256, 0, s>>>((const float *)pred, gt, sums, gloss, loss_weight, lambda, (float *)gpred, total, h, w, H, W, log_depth_error);
+    else
+        return -2;
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gwd_seg_ce_sum(const void *logits, const int64_t *target, double *sum, int64_t P, int32_t dtype, void *stream) {
+    if (!logits || !target || !sum || P <= 0) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GWD_BF16)
+        seg_ce_sum_kernel<__bf16><<<flat_grid(P), 256, 0, s>>>((const __bf16 *)logits, target, sum, P);
+    else if (dtype == GWD_F32)
+        seg_ce_sum_kernel<float><<<flat_grid(P), 256, 0, s>>>((const float *)logits, target, sum, P);
+    else
+        return -2;
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gwd_seg_ce_backward(const void *logits, const int64_t *target, const float *gloss, float scale, void *glogits,
+                                   int64_t P, int32_t dtype, void *stream) {
+    if (!logits || !target || !gloss || !glogits || P <= 0) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GWD_BF16)
+        seg_ce_bwd_kernel<__bf16><<<flat_grid(P), 256, 0, s>>>((const __bf16 *)logits, target, gloss, scale, (__bf16 *)glogits, P);
+    else if (dtype == GWD_F32)
+        seg_ce_bwd_kernel<float><<<flat_grid(P), 256, 0, s>>>((const float *)logits, target, gloss, scale, (float *)glogits, P);
+    else
+        return -2;
+    GWD_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,303 @@
+// HBM-bound row kernels: LayerNorm (+GELU) fwd/bwd, softmax fwd/bwd, activation backward, column sums.
+// One 64-lane wave owns one row at a time (lane-strided, fully coalesced accesses, shuffle
+// reductions, no LDS); grids are capped at ~8 blocks per CU and stride over rows.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_PER_LANE = 8;   // C <= 512
+constexpr int SM_PER_LANE = 16;   // softmax row length <= 1024
+
+inline int row_grid(int64_t rows, int waves_per_block) {
+    int64_t blocks = (rows + waves_per_block - 1) / waves_per_block;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T *__restrict__ x, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, T *__restrict__ y,
+                                                            float *__restrict__ mean, float *__restrict__ rstd,
+                                                            int64_t rows, int C, int gelu) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    const int per = (C + 63) / 64;
+    for (int64_t r = wave; r < rows; r += nw) {
+        const T *xr = x + r * C;
+        float v[MAX_PER_LANE];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAX_PER_LANE; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = (i < per && c < C) ? to_f32(xr[c]) : 0.f;
+            s += v[i];
+        }
+        const float mu = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAX_PER_LANE; ++i) {
+            const int c = lane + 64 * i;
+            const float dlt = (i < per && c < C) ? v[i] - mu : 0.f;
+            q += dlt * dlt;
+        }
+        const float rs = rsqrtf(wave_sum(q) / (float)C + 1e-5f);
+        if (lane == 0) {
+            mean[r] = mu;
+            rstd[r] = rs;
+        }
+        T *yr = y + r * C;
+#pragma unroll
+        for (int i = 0; i < MAX_PER_LANE; ++i) {
+            const int c = lane + 64 * i;
+            if (i < per && c < C) {
+                float o = (v[i] - mu) * rs;
+                if (gamma) o = o * gamma[c] + beta[c];
+                if (gelu) o = gelu_f(o);
+                yr[c] = from_f32<T>(o);
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T *__restrict__ gy, const T *__restrict__ x,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                            const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                            T *__restrict__ gx, float *__restrict__ dgamma,
+                                                            float *__restrict__ dbeta, int64_t rows, int C, int gelu) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    const int per = (C + 63) / 64;
+    float ag[MAX_PER_LANE], ab[MAX_PER_LANE], gm[MAX_PER_LANE], bt[MAX_PER_LANE];
+#pragma unroll
+    for (int i = 0; i < MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        ag[i] = ab[i] = 0.f;
+        gm[i] = (gamma && i < per && c < C) ? gamma[c] : 1.f;
+        bt[i] = (beta && i < per && c < C) ? beta[c] : 0.f;
+    }
+    for (int64_t r = wave; r < rows; r += nw) {
+        const T *xr = x + r * C;
+        const T *gr = gy + r * C;
+        const float mu = mean[r], rs = rstd[r];
+        float xh[MAX_PER_LANE], gw[MAX_PER_LANE];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAX_PER_LANE; ++i) {
+            const int c = lane + 64 * i;
+            const bool ok = i < per && c < C;
+            xh[i] = ok ? (to_f32(xr[c]) - mu) * rs : 0.f;
+            float g = ok ? to_f32(gr[c]) : 0.f;
+            if (gelu) g *= gelu_grad_f(xh[i] * gm[i] + bt[i]);
+            ag[i] += g * xh[i];
+            ab[i] += g;
+            gw[i] = g * gm[i];
+            s1 += gw[i];
+            s2 += gw[i] * xh[i];
+        }
+        s1 = wave_sum(s1) / (float)C;
+        s2 = wave_sum(s2) / (float)C;
+        T *gxr = gx + r * C;
+#pragma unroll
+        for (int i = 0; i < MAX_PER_LANE; ++i) {
+            const int c = lane + 64 * i;
+            if (i < per && c < C) gxr[c] = from_f32<T>(rs * (gw[i] - s1 - xh[i] * s2));
+        }
+    }
+    if (dgamma) {
+#pragma unroll
+        for (int i = 0; i < MAX_PER_LANE; ++i) {
+            const int c = lane + 64 * i;
+            if (i < per && c < C) {
+                unsafeAtomicAdd(dgamma + c, ag[i]);
+                unsafeAtomicAdd(dbeta + c, ab[i]);
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const T *__restrict__ x, T *__restrict__ y, int64_t rows, int L) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    const int per = (L + 63) / 64;
+    for (int64_t r = wave; r < rows; r += nw) {
+        const T *xr = x + r * L;
+        float v[SM_PER_LANE];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < SM_PER_LANE; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = (i < per && c < L) ? to_f32(xr[c]) : -INFINITY;
+            mx = fmaxf(mx, v[i]);
+        }
+        mx = wave_max(mx);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < SM_PER_LANE; ++i) {
+            v[i] = (v[i] == -INFINITY) ? 0.f : expf(v[i] - mx);
+            s += v[i];
+        }
+        const float inv = 1.0f / wave_sum(s);
+        T *yr = y + r * L;
+#pragma unroll
+        for (int i = 0; i < SM_PER_LANE; ++i) {
+            const int c = lane + 64 * i;
+            if (i < per && c < L) yr[c] = from_f32<T>(v[i] * inv);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const T *__restrict__ gy, const T *__restrict__ y,
+                                                          T *__restrict__ gx, int64_t rows, int L) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    const int per = (L + 63) / 64;
+    for (int64_t r = wave; r < rows; r += nw) {
+        float yv[SM_PER_LANE], gv[SM_PER_LANE];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < SM_PER_LANE; ++i) {
+            const int c = lane + 64 * i;
+            const bool ok = i < per && c < L;
+            yv[i] = ok ? to_f32(y[r * L + c]) : 0.f;
+            gv[i] = ok ? to_f32(gy[r * L + c]) : 0.f;
+            dot += yv[i] * gv[i];
+        }
+        dot = wave_sum(dot);
+#pragma unroll
+        for (int i = 0; i < SM_PER_LANE; ++i) {
+            const int c = lane + 64 * i;
+            if (i < per && c < L) gx[r * L + c] = from_f32<T>(yv[i] * (gv[i] - dot));
+        }
+    }
+}
+
+template <typename T>
+__global__ void act_bwd_kernel(const T *__restrict__ gy, const T *__restrict__ ref, T *__restrict__ gx,
+                               const float *__restrict__ scale, int64_t total, int C, int act, float act_scale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float g = to_f32(gy[i]);
+        const float rv = ref ? to_f32(ref[i]) : 0.f;
+        switch (act) {
+            case GWD_ACT_RELU: g = rv > 0.f ? g : 0.f; break;
+            case GWD_ACT_GELU: g *= gelu_grad_f(rv); break;
+            case GWD_ACT_ELU: g *= (rv > 0.f ? 1.0f : rv / act_scale + 1.0f); break;
+            case GWD_ACT_SIGMOID: {
+                const float sg = rv / act_scale;
+                g *= sg * (1.0f - sg);
+                break;
+            }
+            default: break;
+        }
+        g *= act_scale;
+        if (scale) g *= scale[i % C];
+        gx[i] = from_f32<T>(g);
+    }
+}
+
+// out[c] += sum over rows; block = 256 threads = (256/CW rows) x CW columns, coalesced along c.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ g, float *__restrict__ out, int64_t rows, int C) {
+    const int cw = C < 256 ? (C <= 32 ? 32 : (C <= 64 ? 64 : (C <= 128 ? 128 : 256))) : 256;
+    const int rpb = 256 / cw;
+    const int tc = threadIdx.x % cw, tr = threadIdx.x / cw;
+    for (int c0 = 0; c0 < C; c0 += cw) {
+        const int c = c0 + tc;
+        float s = 0.f;
+        if (c < C)
+            for (int64_t r = (int64_t)blockIdx.x * rpb + tr; r < rows; r += (int64_t)gridDim.x * rpb) s += to_f32(g[r * C + c]);
+        if (c < C) unsafeAtomicAdd(out + c, s);
+    }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL_BF16, CALL_F32) \
+    if ((dtype) == GWD_BF16) { CALL_BF16; }    \
+    else if ((dtype) == GWD_F32) { CALL_F32; } \
+    else return -2;
+
+extern "C" int gwd_layernorm_forward(const void *x, const float *gamma, const float *beta, void *y, float *mean,
+                                     float *rstd, int64_t rows, int32_t C, int32_t gelu, int32_t dtype, void *stream) {
+    if (!x || !y || !mean || !rstd || rows < 0 || C <= 0 || C > 64 * MAX_PER_LANE) return -1;
+    if ((gamma == nullptr) != (beta == nullptr)) return -1;
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = row_grid(rows, 4);
+    DISPATCH_T(dtype,
+               (layernorm_fwd_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)x, gamma, beta, (__bf16 *)y, mean, rstd, rows, C, gelu)),
+               (layernorm_fwd_kernel<float><<<grid, 256, 0, s>>>((const float *)x, gamma, beta, (float *)y, mean, rstd, rows, C, gelu)));
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gwd_layernorm_backward(const void *gy, const void *x, const float *gamma, const float *beta,
+                                      const float *mean, const float *rstd, void *gx, float *dgamma, float *dbeta,
+                                      int64_t rows, int32_t C, int32_t gelu, int32_t dtype, void *stream) {
+    if (!gy || !x || !gx || !mean || !rstd || rows < 0 || C <= 0 || C > 64 * MAX_PER_LANE) return -1;
+    if ((dgamma == nullptr) != (dbeta == nullptr)) return -1;
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    int grid = row_grid(rows, 4);
+    if (grid > 1024) grid = 1024;
+    DISPATCH_T(dtype,
+               (layernorm_bwd_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)gy, (const __bf16 *)x, gamma, beta, mean, rstd, (__bf16 *)gx, dgamma, dbeta, rows, C, gelu)),
+               (layernorm_bwd_kernel<float><<<grid, 256, 0, s>>>((const float *)gy, (const float *)x, gamma, beta, mean, rstd, (float *)gx, dgamma, dbeta, rows, C, gelu)));
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gwd_softmax_forward(const void *x, void *y, int64_t rows, int32_t L, int32_t dtype, void *stream) {
+    if (!x || !y || rows < 0 || L <= 0 || L > 64 * SM_PER_LANE) return -1;
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = row_grid(rows, 4);
+    DISPATCH_T(dtype, (softmax_fwd_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)x, (__bf16 *)y, rows, L)),
+               (softmax_fwd_kernel<float><<<grid, 256, 0, s>>>((const float *)x, (float *)y, rows, L)));
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gwd_softmax_backward(const void *gy, const void *y, void *gx, int64_t rows, int32_t L, int32_t dtype,
+                                    void *stream) {
+    if (!gy || !y || !gx || rows < 0 || L <= 0 || L > 64 * SM_PER_LANE) return -1;
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = row_grid(rows, 4);
+    DISPATCH_T(dtype,
+               (softmax_bwd_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)gy, (const __bf16 *)y, (__bf16 *)gx, rows, L)),
+               (softmax_bwd_kernel<float><<<grid, 256, 0, s>>>((const float *)gy, (const float *)y, (float *)gx, rows, L)));
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gwd_act_backward(const void *gy, const void *ref, void *gx, const float *scale, int64_t rows, int32_t C,
+                                int32_t act, float act_scale, int32_t dtype, void *stream) {
+    if (!gy || !gx || rows < 0 || C <= 0) return -1;
+    if (act != GWD_ACT_NONE && !ref) return -1;
+    const int64_t total = rows * C;
+    if (total == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    int64_t b = (total + 255) / 256;
+    const int grid = (int)(b > 4096 ? 4096 : b);
+    DISPATCH_T(dtype,
+               (act_bwd_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)gy, (const __bf16 *)ref, (__bf16 *)gx, scale, total, C, act, act_scale)),
+               (act_bwd_kernel<float><<<grid, 256, 0, s>>>((const float *)gy, (const float *)ref, (float *)gx, scale, total, C, act, act_scale)));
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gwd_colsum(const void *g, float *out, int64_t rows, int32_t C, int32_t dtype, void *stream) {
+    if (!g || !out || rows < 0 || C <= 0) return -1;
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    int64_t b = (rows + 63) / 64;
+    const int grid = (int)(b > 512 ? 512 : (b < 1 ? 1 : b));
+    DISPATCH_T(dtype, (colsum_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)g, out, rows, C)),
+               (colsum_kernel<float><<<grid, 256, 0, s>>>((const float *)g, out, rows, C)));
+    GWD_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,196 @@
+"""ctypes binding of libgwdepth_hip.so (C ABI: include/gwdepth.h).
+
+There is no CPU fallback: importing works anywhere (so host-side logic can be unit-tested), but
+every compute entry point raises HipUnavailable unless the shared library is present AND the
+tensors live on a HIP device.  Tests may install a fake device library with `set_library()` to
+exercise the host logic on CPU; the product never does.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgwdepth_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3, 4
+GATHER_CONV, GATHER_TRANSPOSED, GATHER_UPSAMPLED = 0, 1, 2
+
+ENTRY_POINTS = [
+    "gwd_version", "gwd_arch", "gwd_conv_forward", "gwd_conv_wgrad", "gwd_weight_prep", "gwd_act_backward",
+    "gwd_colsum", "gwd_layernorm_forward", "gwd_layernorm_backward", "gwd_softmax_forward",
+    "gwd_softmax_backward", "gwd_silog_sums", "gwd_silog_backward", "gwd_seg_ce_sum", "gwd_seg_ce_backward",
+    "gwd_sqnorm", "gwd_adamw_step",
+]
+
+
+class HipUnavailable(RuntimeError):
+    pass
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("w", ctypes.c_void_p), ("y", ctypes.c_void_p), ("z", ctypes.c_void_p),
+                ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("residual", ctypes.c_void_p)] + \
+               [(n, ctypes.c_int32) for n in ("B", "Hi", "Wi", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad",
+                                              "gather", "Hv", "Wv", "act")] + \
+               [("act_scale", ctypes.c_float), ("dtype", ctypes.c_int32)]
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError("gw_depth_amd kernels take float32 or bfloat16, got %s" % t.dtype)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise ValueError("kernel operand must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class HipLibrary:
+    """Thin typed wrapper: tensors in, raw pointers + sizes + current stream out."""
+
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise HipUnavailable(
+                "libgwdepth_hip.so not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+        self.lib = ctypes.CDLL(path)
+        for name in ENTRY_POINTS:
+            if not hasattr(self.lib, name):
+                raise HipUnavailable("libgwdepth_hip.so lacks symbol " + name)
+        self.lib.gwd_arch.restype = ctypes.c_char_p
+        for name in ENTRY_POINTS[2:]:
+            getattr(self.lib, name).restype = ctypes.c_int
+        L = self.lib
+        vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+        L.gwd_conv_forward.argtypes = [ctypes.POINTER(ConvDesc), vp]
+        L.gwd_conv_wgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, vp]
+        L.gwd_weight_prep.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+        L.gwd_act_backward.argtypes = [vp, vp, vp, vp, i64, i32, i32, f32, i32, vp]
+        L.gwd_colsum.argtypes = [vp, vp, i64, i32, i32, vp]
+        L.gwd_layernorm_forward.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
+        L.gwd_layernorm_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
+        L.gwd_softmax_forward.argtypes = [vp, vp, i64, i32, i32, vp]
+        L.gwd_softmax_backward.argtypes = [vp, vp, vp, i64, i32, i32, vp]
+        L.gwd_silog_sums.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+        L.gwd_silog_backward.argtypes = [vp, vp, vp, vp, f32, f32, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+        L.gwd_seg_ce_sum.argtypes = [vp, vp, vp, i64, i32, vp]
+        L.gwd_seg_ce_backward.argtypes = [vp, vp, vp, f32, vp, i64, i32, vp]
+        L.gwd_sqnorm.argtypes = [vp, vp, i64, vp]
+        L.gwd_adamw_step.argtypes = [vp, vp, vp, vp, vp, vp, i64] + [f32] * 9 + [vp]
+
+    # ------------------------------------------------------------------ plumbing
+    @staticmethod
+    def _stream(*tensors):
+        for t in tensors:
+            if t is not None and not t.is_cuda:
+                raise HipUnavailable("gw_depth_amd ops run on a HIP device only (got a %s tensor); "
+                                     "there is no CPU path" % t.device)
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _check(rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed with status %d" % (what, rc))
+
+    def version(self):
+        return self.lib.gwd_version()
+
+    # ------------------------------------------------------------------ entry points
+    @staticmethod
+    def _desc(x, w, y, dims, z=None, scale=None, shift=None, residual=None, stride=1, pad=0,
+              gather=GATHER_CONV, virt=(0, 0), act=ACT_NONE, act_scale=1.0):
+        B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW = dims
+        d = ConvDesc()
+        d.x, d.w, d.y, d.z = _ptr(x), _ptr(w), _ptr(y), _ptr(z)
+        d.scale, d.shift, d.residual = _ptr(scale), _ptr(shift), _ptr(residual)
+        d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW = B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW
+        d.stride, d.pad, d.gather, d.Hv, d.Wv = stride, pad, gather, virt[0], virt[1]
+        d.act, d.act_scale, d.dtype = act, act_scale, dtype_code(x)
+        return d
+
+    def conv_forward(self, x, w, y, dims, **kw):
+        """dims = (B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW); kw: z scale shift residual stride pad gather virt act act_scale."""
+        d = self._desc(x, w, y, dims, **kw)
+        self._check(self.lib.gwd_conv_forward(ctypes.byref(d), self._stream(x, w, y)), "gwd_conv_forward")
+
+    def conv_wgrad(self, x, gy, dw, dims, **kw):
+        d = self._desc(x, None, gy, dims, **kw)
+        self._check(self.lib.gwd_conv_wgrad(ctypes.byref(d), _ptr(dw), self._stream(x, gy, dw)), "gwd_conv_wgrad")
+
+    def weight_prep(self, w, row_scale, w_fwd, w_dgrad, N, taps, C, dtype):
+        self._check(self.lib.gwd_weight_prep(_ptr(w), _ptr(row_scale), _ptr(w_fwd), _ptr(w_dgrad), N, taps, C, dtype,
+                                             self._stream(w, w_fwd, w_dgrad)), "gwd_weight_prep")
+
+    def act_backward(self, gy, ref, gx, scale, rows, C, act, act_scale):
+        self._check(self.lib.gwd_act_backward(_ptr(gy), _ptr(ref), _ptr(gx), _ptr(scale), rows, C, act, act_scale,
+                                              dtype_code(gy), self._stream(gy, ref, gx)), "gwd_act_backward")
+
+    def colsum(self, g, out, rows, C):
+        self._check(self.lib.gwd_colsum(_ptr(g), _ptr(out), rows, C, dtype_code(g), self._stream(g, out)), "gwd_colsum")
+
+    def layernorm_forward(self, x, gamma, beta, y, mean, rstd, rows, C, gelu):
+        self._check(self.lib.gwd_layernorm_forward(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd),
+                                                   rows, C, int(gelu), dtype_code(x), self._stream(x, y)),
+                    "gwd_layernorm_forward")
+
+    def layernorm_backward(self, gy, x, gamma, beta, mean, rstd, gx, dgamma, dbeta, rows, C, gelu):
+        self._check(self.lib.gwd_layernorm_backward(_ptr(gy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd),
+                                                    _ptr(gx), _ptr(dgamma), _ptr(dbeta), rows, C, int(gelu),
+                                                    dtype_code(x), self._stream(gy, x, gx)), "gwd_layernorm_backward")
+
+    def softmax_forward(self, x, y, rows, L):
+        self._check(self.lib.gwd_softmax_forward(_ptr(x), _ptr(y), rows, L, dtype_code(x), self._stream(x, y)),
+                    "gwd_softmax_forward")
+
+    def softmax_backward(self, gy, y, gx, rows, L):
+        self._check(self.lib.gwd_softmax_backward(_ptr(gy), _ptr(y), _ptr(gx), rows, L, dtype_code(y),
+                                                  self._stream(gy, y, gx)), "gwd_softmax_backward")
+
+    def silog_sums(self, pred, gt, sums, B, h, w, H, W, log_err):
+        self._check(self.lib.gwd_silog_sums(_ptr(pred), _ptr(gt), _ptr(sums), B, h, w, H, W, int(log_err),
+                                            dtype_code(pred), self._stream(pred, gt, sums)), "gwd_silog_sums")
+
+    def silog_backward(self, pred, gt, sums, gloss, weight, lam, gpred, B, h, w, H, W, log_err):
+        self._check(self.lib.gwd_silog_backward(_ptr(pred), _ptr(gt), _ptr(sums), _ptr(gloss), weight, lam, _ptr(gpred),
+                                                B, h, w, H, W, int(log_err), dtype_code(pred),
+                                                self._stream(pred, gt, gpred)), "gwd_silog_backward")
+
+    def seg_ce_sum(self, logits, target, out, P):
+        self._check(self.lib.gwd_seg_ce_sum(_ptr(logits), _ptr(target), _ptr(out), P, dtype_code(logits),
+                                            self._stream(logits, target, out)), "gwd_seg_ce_sum")
+
+    def seg_ce_backward(self, logits, target, gloss, scale, glogits, P):
+        self._check(self.lib.gwd_seg_ce_backward(_ptr(logits), _ptr(target), _ptr(gloss), scale, _ptr(glogits), P,
+                                                 dtype_code(logits), self._stream(logits, glogits)), "gwd_seg_ce_backward")
+
+    def sqnorm(self, g, sq, n):
+        self._check(self.lib.gwd_sqnorm(_ptr(g), _ptr(sq), n, self._stream(g, sq)), "gwd_sqnorm")
+
+    def adamw_step(self, p, g, m, v, p16, sq, n, lr, b1, b2, eps, wd, bc1, bc2, max_norm, grad_scale):
+        self._check(self.lib.gwd_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(p16), _ptr(sq), n, lr, b1, b2, eps,
+                                            wd, bc1, bc2, max_norm, grad_scale, self._stream(p, g, m, v)),
+                    "gwd_adamw_step")
+
+
+_LIB = None
+
+
+def library():
+    """The process-wide device library; raises HipUnavailable when it cannot be loaded."""
+    global _LIB
+    if _LIB is None:
+        _LIB = HipLibrary()
+    return _LIB
+
+
+def set_library(lib):
+    """TEST HOOK: install a stand-in device library (tests/fake_device.py) or None to reset."""
+    global _LIB
+    _LIB = lib

@@ -1,0 +1,124 @@
+"""Parameter containers with the reference's state-dict names and kernel-native storage.
+
+Convolution weights live in HBM as (Cout, KH, KW, Cin) — the layout the implicit-GEMM kernels
+read — and are converted to / from the reference's (Cout, Cin, KH, KW) only inside
+state_dict() / load_state_dict(), so reference checkpoints load unchanged
+(/root/reference/src/main_glassrgbd.py:104-157).
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+class Conv(nn.Module):
+    """nn.Conv2d stand-in (weight [+ bias]); forward is done by the owner through ops.conv2d."""
+
+    def __init__(self, cin, cout, k, bias=False):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, k, k, cin))
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+        fan_in, fan_out = cin * k * k, cout * k * k
+        bound = math.sqrt(6.0 / (fan_in + fan_out))          # xavier_uniform, as the reference's _init_weights
+        nn.init.uniform_(self.weight, -bound, bound)
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        destination[prefix + "weight"] = destination[prefix + "weight"].permute(0, 3, 1, 2).contiguous()
+
+    def _load_from_state_dict(self, state_dict, prefix, *args):
+        key = prefix + "weight"
+        if key in state_dict and state_dict[key].dim() == 4:
+            state_dict[key] = state_dict[key].permute(0, 2, 3, 1).contiguous()
+        super()._load_from_state_dict(state_dict, prefix, *args)
+
+
+class Linear(nn.Module):
+    def __init__(self, cin, cout, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin))
+        nn.init.trunc_normal_(self.weight, std=0.02)
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+
+    def forward(self, x, act=ops.ACT_NONE):
+        return ops.linear(x, self.weight, self.bias, act)
+
+
+class LayerNorm(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+
+    def forward(self, x, gelu=False):
+        return ops.layer_norm(x, self.weight, self.bias, gelu)
+
+
+class FrozenBN(nn.Module):
+    """FrozenBatchNorm2d (/root/reference/src/models/backbone.py:19-55): four buffers, folded into the
+    preceding convolution as a per-channel weight scale and an epilogue shift."""
+
+    def __init__(self, n):
+        super().__init__()
+        self.register_buffer("weight", torch.ones(n))
+        self.register_buffer("bias", torch.zeros(n))
+        self.register_buffer("running_mean", torch.zeros(n))
+        self.register_buffer("running_var", torch.ones(n))
+        self._cache = None
+
+    def _load_from_state_dict(self, state_dict, prefix, *args):
+        state_dict.pop(prefix + "num_batches_tracked", None)      # backbone.py:35-43
+        self._cache = None
+        super()._load_from_state_dict(state_dict, prefix, *args)
+
+    def _apply(self, fn, *a, **k):
+        self._cache = None
+        return super()._apply(fn, *a, **k)
+
+    def folded(self):
+        key = (self.weight._version, self.bias._version, self.running_mean._version, self.running_var._version,
+               self.weight.device)
+        if self._cache is None or self._cache[0] != key:
+            scale = self.weight * (self.running_var + 1e-5).rsqrt()
+            shift = self.bias - self.running_mean * scale
+            self._cache = (key, scale.float().contiguous(), shift.float().contiguous())
+        return self._cache[1], self._cache[2]
+
+
+class Mlp(nn.Module):
+    """fc1 -> GELU -> fc2 (/root/reference/src/models/multiscale_transformerr.py:55-73, drop=0)."""
+
+    def __init__(self, cin, hidden=None, cout=None):
+        super().__init__()
+        self.fc1 = Linear(cin, hidden or cin)
+        self.fc2 = Linear(hidden or cin, cout or cin)
+
+    def forward(self, x):
+        return self.fc2(self.fc1(x, ops.ACT_GELU))
+
+
+class MlpNorm(nn.Module):
+    """fc1 -> fc2 -> LayerNorm (/root/reference/src/models/multiscale_transformerr.py:75-102, no act)."""
+
+    def __init__(self, c, hidden):
+        super().__init__()
+        self.fc1 = Linear(c, hidden)
+        self.fc2 = Linear(hidden, c)
+        self.norm = LayerNorm(c)
+
+    def forward(self, x):
+        return self.norm(self.fc2(self.fc1(x)))
+
+
+class Seq(nn.Module):
+    """Children registered under explicit string names ('0', '2', ...) to reproduce nn.Sequential keys."""
+
+    def __init__(self, **named):
+        super().__init__()
+        for k, v in named.items():
+            self.add_module(k.lstrip("_"), v)
+
+    def __getitem__(self, i):
+        return self._modules[str(i)]

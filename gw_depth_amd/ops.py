@@ -1,0 +1,266 @@
+"""torch.autograd.Function wrappers over the C ABI (include/gwdepth.h).
+
+Layout conventions: feature maps are (B, H, W, C) contiguous ("pixel-major"), token tensors
+(..., C) contiguous; conv weights are (Cout, KH, KW, Cin); Linear weights (out, in) as in torch.
+Master parameters are fp32; with bf16 activations the kernels read a bf16 copy of the weights
+(the flat shadow maintained by the fused optimizer when present, otherwise made on the fly).
+"""
+import torch
+
+from . import hip
+from .hip import (ACT_ELU, ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, GATHER_CONV, GATHER_TRANSPOSED,
+                  GATHER_UPSAMPLED)
+
+__all__ = ["conv2d", "linear", "layer_norm", "softmax_lastdim", "silog_loss", "seg_cross_entropy",
+           "ACT_NONE", "ACT_RELU", "ACT_GELU", "ACT_ELU", "ACT_SIGMOID"]
+
+
+def _lib():
+    return hip.library()
+
+
+def _weight_for(w, row_scale, dtype, shadow=None):
+    """Kernel-ready forward weights in the activation dtype (fp32 master -> as is)."""
+    if row_scale is None:
+        if dtype == torch.float32:
+            return w.detach()
+        if shadow is not None and shadow.dtype == dtype:
+            return shadow
+    out = torch.empty(w.shape, dtype=dtype, device=w.device)
+    N, C = w.shape[0], w.shape[-1]
+    _lib().weight_prep(w.detach(), row_scale, out, None, N, w.numel() // (N * C), C, hip.F32 if dtype == torch.float32 else hip.BF16)
+    return out
+
+
+def _weight_transposed(w, row_scale, dtype):
+    """[Cin][taps][Cout] copy for the data gradient."""
+    N, C = w.shape[0], w.shape[-1]
+    taps = w.numel() // (N * C)
+    out = torch.empty((C,) + tuple(w.shape[1:-1]) + (N,), dtype=dtype, device=w.device)
+    _lib().weight_prep(w.detach(), row_scale, None, out, N, taps, C, hip.F32 if dtype == torch.float32 else hip.BF16)
+    return out
+
+
+class _ConvFn(torch.autograd.Function):
+    """y = act_scale * act(conv(x, w * row_scale) + shift + residual), all in one kernel launch."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, residual, row_scale, shift_const, stride, pad, act, act_scale, virt, shadow):
+        lib = _lib()
+        B, Hi, Wi, Cin = x.shape
+        Cout, KH, KW, Cw = w.shape
+        if Cw != Cin:
+            raise ValueError("conv2d: weight expects %d input channels, input has %d" % (Cw, Cin))
+        if virt is None:
+            Ho = (Hi + 2 * pad - KH) // stride + 1
+            Wo = (Wi + 2 * pad - KW) // stride + 1
+            gather, vv = GATHER_CONV, (0, 0)
+        else:
+            Ho, Wo = virt[0] + 2 * pad - KH + 1, virt[1] + 2 * pad - KW + 1
+            gather, vv = GATHER_UPSAMPLED, tuple(virt)
+        x = x.contiguous()
+        wk = _weight_for(w, row_scale, x.dtype, shadow)
+        shift = shift_const if bias is None else (bias.detach().float() if shift_const is None else shift_const + bias.detach().float())
+        y = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+        need_grad = any(ctx.needs_input_grad[:4])
+        z = torch.empty_like(y) if (act == ACT_GELU and need_grad) else None
+        if residual is not None:
+            residual = residual.contiguous()
+        dims = (B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW)
+        lib.conv_forward(x, wk, y, dims, z=z, shift=shift, residual=residual, stride=stride, pad=pad, gather=gather,
+                         virt=vv, act=act, act_scale=act_scale)
+        ctx.cfg = (dims, stride, pad, act, act_scale, gather, vv, bias is not None, residual is not None)
+        ctx.save_for_backward(x, w, row_scale, z if act == ACT_GELU else (y if act != ACT_NONE else None))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib()
+        x, w, row_scale, ref = ctx.saved_tensors
+        dims, stride, pad, act, act_scale, gather, vv, has_bias, has_res = ctx.cfg
+        B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW = dims
+        gy = gy.contiguous()
+        rows = B * Ho * Wo
+        if act != ACT_NONE or act_scale != 1.0:
+            dv = torch.empty_like(gy)
+            lib.act_backward(gy, ref, dv, None, rows, Cout, act, act_scale)
+        else:
+            dv = gy
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wt = _weight_transposed(w, row_scale, x.dtype)
+            if gather == GATHER_UPSAMPLED:
+                gxv = torch.empty((B, vv[0], vv[1], Cin), dtype=x.dtype, device=x.device)
+                lib.conv_forward(dv, wt, gxv, (B, Ho, Wo, Cout, vv[0], vv[1], Cin, KH, KW), stride=1, pad=pad,
+                                 gather=GATHER_TRANSPOSED)
+                gx = _nearest_upsample_backward(gxv, Hi, Wi)
+            else:
+                gx = torch.empty_like(x)
+                lib.conv_forward(dv, wt, gx, (B, Ho, Wo, Cout, Hi, Wi, Cin, KH, KW), stride=stride, pad=pad,
+                                 gather=GATHER_TRANSPOSED)
+        if ctx.needs_input_grad[1]:
+            gw = torch.zeros(w.shape, dtype=torch.float32, device=w.device)
+            lib.conv_wgrad(x, dv, gw, dims, stride=stride, pad=pad, gather=gather, virt=vv)
+            if row_scale is not None:
+                gw.mul_(row_scale.view(-1, 1, 1, 1))
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = torch.zeros(Cout, dtype=torch.float32, device=gy.device)
+            lib.colsum(dv, gb, rows, Cout)
+        gres = dv if (has_res and ctx.needs_input_grad[3]) else None
+        return gx, gw, gb, gres, None, None, None, None, None, None, None, None
+
+
+def _nearest_upsample_backward(gv, Hi, Wi):
+    """Sum the gradient of a nearest-upsampled view back onto its source pixels."""
+    B, Hv, Wv, C = gv.shape
+    if Hv == 2 * Hi and Wv == 2 * Wi:
+        return gv.view(B, Hi, 2, Wi, 2, C).sum(dim=(2, 4))
+    ih = torch.clamp((torch.arange(Hv, device=gv.device, dtype=torch.float32) * (Hi / Hv)).floor().long(), max=Hi - 1)
+    iw = torch.clamp((torch.arange(Wv, device=gv.device, dtype=torch.float32) * (Wi / Wv)).floor().long(), max=Wi - 1)
+    flat = (ih[:, None] * Wi + iw[None, :]).reshape(-1)
+    out = torch.zeros((B, Hi * Wi, C), dtype=torch.float32, device=gv.device)
+    out.index_add_(1, flat, gv.reshape(B, Hv * Wv, C).float())
+    return out.view(B, Hi, Wi, C).to(gv.dtype)
+
+
+def conv2d(x, w, bias=None, *, stride=1, pad=0, act=ACT_NONE, act_scale=1.0, residual=None, row_scale=None,
+           shift=None, upsample_to=None):
+    """x (B,H,W,Cin); w (Cout,KH,KW,Cin) fp32 master; bias fp32 parameter or None.
+    row_scale / shift: constant per-Cout tensors of a folded FrozenBatchNorm.
+    upsample_to=(Hv,Wv): convolve a nearest-upsampled view of x without materialising it."""
+    return _ConvFn.apply(x, w, bias, residual, row_scale, shift, stride, pad, act, float(act_scale), upsample_to,
+                          getattr(w, "_gwd_bf16", None))
+
+
+def linear(x, w, bias=None, act=ACT_NONE):
+    """x (..., K) @ w(N, K)^T + bias, optional fused activation; same kernel as conv2d (1x1, one pixel per row)."""
+    K = x.shape[-1]
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, 1, 1, K)
+    shadow = getattr(w, "_gwd_bf16", None)
+    y = _ConvFn.apply(x2, w.view(w.shape[0], 1, 1, K), bias, None, None, None, 1, 0, act, 1.0, None,
+                      None if shadow is None else shadow.view(w.shape[0], 1, 1, K))
+    return y.view(*lead, w.shape[0])
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, gelu):
+        lib = _lib()
+        x = x.contiguous()
+        C = x.shape[-1]
+        rows = x.numel() // C
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        g = gamma.detach() if gamma is not None else None
+        b = beta.detach() if beta is not None else None
+        lib.layernorm_forward(x, g, b, y, mean, rstd, rows, C, gelu)
+        ctx.save_for_backward(x, g, b, mean, rstd)
+        ctx.gelu = gelu
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib()
+        x, g, b, mean, rstd = ctx.saved_tensors
+        C = x.shape[-1]
+        rows = x.numel() // C
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        dg = db = None
+        if g is not None:
+            dg = torch.zeros(C, dtype=torch.float32, device=x.device)
+            db = torch.zeros(C, dtype=torch.float32, device=x.device)
+        lib.layernorm_backward(gy, x, g, b, mean, rstd, gx, dg, db, rows, C, ctx.gelu)
+        return gx, dg, db, None
+
+
+def layer_norm(x, gamma, beta, gelu=False):
+    """LayerNorm over the last dim (eps 1e-5) with optional fused exact GELU."""
+    return _LayerNormFn.apply(x, gamma, beta, bool(gelu))
+
+
+class _SoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        L = x.shape[-1]
+        y = torch.empty_like(x)
+        _lib().softmax_forward(x, y, x.numel() // L, L)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        L = y.shape[-1]
+        gx = torch.empty_like(y)
+        _lib().softmax_backward(gy.contiguous(), y, gx, y.numel() // L, L)
+        return gx
+
+
+def softmax_lastdim(x):
+    return _SoftmaxFn.apply(x)
+
+
+class _SilogFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, gt, weight, lam, log_err):
+        lib = _lib()
+        pred = pred.contiguous()
+        B = pred.shape[0]
+        # accepted layouts: (B,h,w,1) pixel-major or (B,1,h,w); both are the same bytes
+        if pred.dim() == 4 and pred.shape[-1] == 1:
+            h, w = pred.shape[1], pred.shape[2]
+        elif pred.dim() == 4 and pred.shape[1] == 1:
+            h, w = pred.shape[2], pred.shape[3]
+        else:
+            h, w = pred.shape[-2], pred.shape[-1]
+        H, W = gt.shape[-2], gt.shape[-1]
+        sums = torch.zeros(3, dtype=torch.float64, device=pred.device)
+        lib.silog_sums(pred, gt, sums, B, h, w, H, W, log_err)
+        n = sums[2]
+        mean = sums[0] / n
+        loss = (torch.sqrt(sums[1] / n - lam * mean * mean) * (10.0 * weight)).float()
+        ctx.save_for_backward(pred, gt, sums)
+        ctx.cfg = (B, h, w, H, W, weight, lam, log_err)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        pred, gt, sums = ctx.saved_tensors
+        B, h, w, H, W, weight, lam, log_err = ctx.cfg
+        gp = torch.empty_like(pred)
+        _lib().silog_backward(pred, gt, sums, gloss.contiguous().float(), weight, lam, gp, B, h, w, H, W, log_err)
+        return gp, None, None, None, None
+
+
+def silog_loss(pred, gt_full, weight=1.0, variance_focus=0.85, log_depth_error=True):
+    """weight * SiLog(pred, nearest_resize(gt), nearest_resize(0.2 <= gt < 10)); gt_full (B,1,H,W)/(B,H,W) fp32."""
+    return _SilogFn.apply(pred, gt_full.contiguous(), float(weight), float(variance_focus), bool(log_depth_error))
+
+
+class _SegCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, scale):
+        logits = logits.contiguous()
+        P = logits.numel() // 2
+        s = torch.zeros(1, dtype=torch.float64, device=logits.device)
+        _lib().seg_ce_sum(logits, target, s, P)
+        ctx.save_for_backward(logits, target)
+        ctx.cfg = (P, scale)
+        return (s[0] * (scale / P)).float()
+
+    @staticmethod
+    def backward(ctx, gloss):
+        logits, target = ctx.saved_tensors
+        P, scale = ctx.cfg
+        gl = torch.empty_like(logits)
+        _lib().seg_ce_backward(logits, target, gloss.contiguous().float(), scale, gl, P)
+        return gl, None, None
+
+
+def seg_cross_entropy(logits_pixel_major, target, scale=1.0):
+    """scale * mean CE of (B,H,W,2) logits against (B,H,W) int64 targets."""
+    return _SegCEFn.apply(logits_pixel_major, target.contiguous(), float(scale))

@@ -1,0 +1,132 @@
+/* gwdepth.h — C ABI of libgwdepth_hip.so: hand-written gfx950 (MI355X) kernels for the GW-Depth
+ * train step.
+ *
+ * The reference (ViktorLiang/GW-Depth) has no FFI/plugin boundary: it is 100 % PyTorch and every
+ * device operation is an ATen call.  Each entry point below therefore replaces an
+ * ATen operator sequence at the cited reference call sites; the host side (the gw_depth_amd Python package) binds
+ * them with ctypes and wraps them in torch.autograd.Function objects.
+ *
+ * Conventions:
+ *   - plain C, no torch types; raw device pointers, explicit sizes, dtype enum, caller's hipStream_t
+ *     passed as void*;
+ *   - return 0 on success, negative = invalid argument / unsupported shape, positive = hipError_t;
+ *   - never allocate or free caller memory, never synchronise the device, no mutable global state;
+ *   - activation tensors are NHWC ("pixel-major": [B][H][W][C], a Linear input is [rows][C]);
+ *   - convolution / linear weights are [Cout][KH][KW][Cin] (a Linear weight is [out][in] as in torch).
+ */
+#ifndef GWDEPTH_H
+#define GWDEPTH_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GWD_VERSION 1
+
+enum { GWD_F32 = 0, GWD_BF16 = 1 };
+enum { GWD_ACT_NONE = 0, GWD_ACT_RELU = 1, GWD_ACT_GELU = 2, GWD_ACT_ELU = 3, GWD_ACT_SIGMOID = 4 };
+/* how output pixel (oh,ow) and tap (kh,kw) map to an input pixel */
+enum {
+    GWD_GATHER_CONV = 0,      /* ih = oh*stride - pad + kh                                     */
+    GWD_GATHER_TRANSPOSED = 1,/* ih = (oh + pad - kh)/stride when divisible (data gradient)    */
+    GWD_GATHER_UPSAMPLED = 2  /* stride 1 over a nearest-upsampled (Hv,Wv) view of the input   */
+};
+
+typedef struct {
+    const void *x;        /* [B][Hi][Wi][Cin]                                                   */
+    const void *w;        /* [Cout][KH][KW][Cin]                                                */
+    void *y;              /* [B][Ho][Wo][Cout]                                                  */
+    void *z;              /* optional copy of the value BEFORE the activation (for GELU bwd)    */
+    const float *scale;   /* optional per-Cout multiplier (FrozenBN scale)                      */
+    const float *shift;   /* optional per-Cout addend (bias / FrozenBN shift)                   */
+    const void *residual; /* optional [B][Ho][Wo][Cout] added before the activation             */
+    int32_t B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
+    int32_t gather;       /* GWD_GATHER_*                                                       */
+    int32_t Hv, Wv;       /* virtual input size for GWD_GATHER_UPSAMPLED                        */
+    int32_t act;          /* GWD_ACT_*                                                          */
+    float act_scale;      /* y = act_scale * act(v)  (max_depth * sigmoid)                      */
+    int32_t dtype;        /* GWD_F32 / GWD_BF16 for x, w, y, z, residual                        */
+} gwd_conv_desc;
+
+int gwd_version(void);
+const char *gwd_arch(void);
+
+/* Implicit-GEMM convolution on MFMA with fused epilogue y = act(scale*conv(x,w) + shift + residual).
+ * Also the Linear layer (KH=KW=1, Hi=Wi=1, B=rows) and, with GWD_GATHER_TRANSPOSED and
+ * the transposed weights of gwd_weight_prep, the data gradient.
+ * Replaces: torchvision Bottleneck conv+FrozenBN+ReLU (src/models/backbone.py:45-55,90-92), ConvLn /
+ * ConvA / upconv convolutions (src/models/points/points_sample.py:15-22,
+ * src/models/multiscale_transformerr.py:110-116, src/models/dense_upsample.py:82-90,126-146),
+ * every nn.Linear on the path (src/models/transformer.py:133-136,
+ * src/models/multiscale_transformerr.py:62-64,249-251,425-429,445-449).                          */
+int gwd_conv_forward(const gwd_conv_desc *d, void *stream);
+
+/* Weight gradient dw[Cout][KH][KW][Cin] (fp32, ACCUMULATED into dw with atomics; caller zeroes it):
+ * d->x = layer input, d->y = gradient w.r.t. the layer output (already multiplied by act'), gather
+ * as in the forward.  Replaces aten::convolution_backward (weight) / addmm weight grads.          */
+int gwd_conv_wgrad(const gwd_conv_desc *d, float *dw, void *stream);
+
+/* w (fp32 [N][taps][C]), optionally multiplied by row_scale[N] (a frozen BatchNorm folded into the
+ * convolution) -> w_fwd (dtype, same layout; may be NULL) and w_dgrad (dtype, [C][taps][N]; may be
+ * NULL).                                                                                          */
+int gwd_weight_prep(const float *w, const float *row_scale, void *w_fwd, void *w_dgrad, int32_t N,
+                    int32_t taps, int32_t C, int32_t dtype, void *stream);
+
+/* gx = gy * act'(.) ; `ref` is the activation OUTPUT for RELU/ELU/SIGMOID (divided by act_scale
+ * internally) and the PRE-activation for GELU.  Optional per-channel multiplier `scale` ([C]).   */
+int gwd_act_backward(const void *gy, const void *ref, void *gx, const float *scale, int64_t rows,
+                     int32_t C, int32_t act, float act_scale, int32_t dtype, void *stream);
+
+/* out[c] += sum_rows g[row][c]  (bias / shift gradients; fp32 atomics, caller zeroes).           */
+int gwd_colsum(const void *g, float *out, int64_t rows, int32_t C, int32_t dtype, void *stream);
+
+/* LayerNorm over the last dim (C <= 512), eps 1e-5, optional fused exact GELU on the output.
+ * Replaces nn.LayerNorm (+ nn.GELU) call sites: src/models/points/points_sample.py:19-25,
+ * src/models/multiscale_transformerr.py:612-632,659-665,755-777, src/models/transformer.py:138-162,
+ * src/models/dense_upsample.py:125,138,166,177.                                                  */
+int gwd_layernorm_forward(const void *x, const float *gamma, const float *beta, void *y, float *mean,
+                          float *rstd, int64_t rows, int32_t C, int32_t gelu, int32_t dtype, void *stream);
+int gwd_layernorm_backward(const void *gy, const void *x, const float *gamma, const float *beta,
+                           const float *mean, const float *rstd, void *gx, float *dgamma, float *dbeta,
+                           int64_t rows, int32_t C, int32_t gelu, int32_t dtype, void *stream);
+
+/* Softmax over the last dim (row length L <= 1024), forward and backward.
+ * Replaces F.softmax in src/models/multi_head_attention.py:366, multiscale_transformerr.py:307,
+ * 322-324,550-552,570,576, points_sample.py:277.                                                 */
+int gwd_softmax_forward(const void *x, void *y, int64_t rows, int32_t L, int32_t dtype, void *stream);
+int gwd_softmax_backward(const void *gy, const void *y, void *gx, int64_t rows, int32_t L, int32_t dtype,
+                         void *stream);
+
+/* SiLog masked reduction (src/models/glassrgbd.py:366-374 with the per-scale nearest-resized GT and
+ * validity mask of src/engine_glassrgbd.py:65,76-78 gathered on the fly).
+ * pred [B][h][w] (dtype), gt [B][H][W] fp32 at full resolution.  sums[3] (double; caller zeroes)
+ * receive sum d, sum d^2, count.  log_depth_error selects d = log p - log g, else (p+log p)-(g+log g). */
+int gwd_silog_sums(const void *pred, const float *gt, double *sums, int32_t B, int32_t h, int32_t w,
+                   int32_t H, int32_t W, int32_t log_depth_error, int32_t dtype, void *stream);
+/* gpred = gloss * d loss / d pred, loss = 10*sqrt(E[d^2] - lambda*E[d]^2); reads the sums.        */
+int gwd_silog_backward(const void *pred, const float *gt, const double *sums, const float *gloss,
+                       float loss_weight, float lambda, void *gpred, int32_t B, int32_t h, int32_t w,
+                       int32_t H, int32_t W, int32_t log_depth_error, int32_t dtype, void *stream);
+
+/* Mean 2-class cross entropy over pixels (SegLoss, src/models/glassrgbd.py:376-383):
+ * logits [P][2] (dtype), target [P] int64.  sum[1] double (caller zeroes).                        */
+int gwd_seg_ce_sum(const void *logits, const int64_t *target, double *sum, int64_t P, int32_t dtype,
+                   void *stream);
+int gwd_seg_ce_backward(const void *logits, const int64_t *target, const float *gloss, float scale,
+                        void *glogits, int64_t P, int32_t dtype, void *stream);
+
+/* sq[0] += sum g^2 over a flat fp32 buffer (double; caller zeroes).  clip_grad_norm_ numerator.    */
+int gwd_sqnorm(const float *g, double *sq, int64_t n, void *stream);
+/* Fused clip_grad_norm_(max_norm) + torch.optim.AdamW step on a flat fp32 range
+ * (src/engine_glassrgbd.py:157-159, src/main_glassrgbd.py:59-66).  coef = min(1, max_norm/(sqrt(sq)+1e-6))
+ * is computed on device from sq[0]; grad_scale pre-multiplies g (1/world_size for DDP mean).
+ * Optionally refreshes the bf16 shadow copy of the parameters.                                    */
+int gwd_adamw_step(float *p, const float *g, float *m, float *v, void *p_bf16, const double *sq,
+                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                   float bias_corr1, float bias_corr2, float max_norm, float grad_scale, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,176 @@
+"""A stand-in for libgwdepth_hip.so used ONLY by the CPU test-suite (tests/, never the product).
+
+It implements the tensor-level methods of gw_depth_amd.hip.HipLibrary with plain torch-CPU math so
+that the host logic of the product (module wiring, layouts, autograd plumbing, state-dict mapping,
+flat optimizer buffers, DDP bucket plan) can be checked against the oracle without a GPU.  The
+numerical behaviour of the real kernels is checked on the GPU box by the `-m gpu` tests.
+"""
+import torch
+import torch.nn.functional as F
+
+from gw_depth_amd import hip
+
+
+def _act(v, act):
+    if act == hip.ACT_RELU:
+        return F.relu(v)
+    if act == hip.ACT_GELU:
+        return F.gelu(v)
+    if act == hip.ACT_ELU:
+        return F.elu(v)
+    if act == hip.ACT_SIGMOID:
+        return torch.sigmoid(v)
+    return v
+
+
+class FakeDevice:
+    is_fake = True
+
+    def version(self):
+        return 1
+
+    @staticmethod
+    def _conv_core(x, w, dims, stride, pad, gather, virt):
+        B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW = dims
+        xn = x.reshape(B, Hi, Wi, Cin).permute(0, 3, 1, 2).float()
+        wn = w.reshape(Cout, KH, KW, Cin).permute(0, 3, 1, 2).float()
+        if gather == hip.GATHER_CONV:
+            out = F.conv2d(xn, wn, stride=stride, padding=pad)
+        elif gather == hip.GATHER_UPSAMPLED:
+            out = F.conv2d(F.interpolate(xn, size=tuple(virt), mode="nearest"), wn, stride=1, padding=pad)
+        else:
+            opad = (Ho - ((Hi - 1) * stride - 2 * pad + KH), Wo - ((Wi - 1) * stride - 2 * pad + KW))
+            out = F.conv_transpose2d(xn, wn.permute(1, 0, 2, 3), stride=stride, padding=pad, output_padding=opad)
+        assert out.shape == (B, Cout, Ho, Wo), (out.shape, dims)
+        return out.permute(0, 2, 3, 1)
+
+    def conv_forward(self, x, w, y, dims, z=None, scale=None, shift=None, residual=None, stride=1, pad=0,
+                     gather=hip.GATHER_CONV, virt=(0, 0), act=hip.ACT_NONE, act_scale=1.0):
+        v = self._conv_core(x, w, dims, stride, pad, gather, virt)
+        if scale is not None:
+            v = v * scale
+        if shift is not None:
+            v = v + shift
+        if residual is not None:
+            v = v + residual.reshape(v.shape).float()
+        if z is not None:
+            z.copy_(v.reshape(z.shape))
+        y.copy_((_act(v, act) * act_scale).reshape(y.shape))
+
+    def conv_wgrad(self, x, gy, dw, dims, stride=1, pad=0, gather=hip.GATHER_CONV, virt=(0, 0), **_):
+        B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW = dims
+        w0 = torch.zeros(Cout, KH, KW, Cin, requires_grad=True)
+        with torch.enable_grad():
+            out = self._conv_core(x, w0, dims, stride, pad, gather, virt)
+            (g,) = torch.autograd.grad(out, w0, gy.reshape(out.shape).float())
+        dw.add_(g.reshape(dw.shape))
+
+    def weight_prep(self, w, row_scale, w_fwd, w_dgrad, N, taps, C, dtype):
+        v = w.reshape(N, taps, C).float()
+        if row_scale is not None:
+            v = v * row_scale.view(-1, 1, 1)
+        if w_fwd is not None:
+            w_fwd.copy_(v.reshape(w_fwd.shape))
+        if w_dgrad is not None:
+            w_dgrad.copy_(v.permute(2, 1, 0).reshape(w_dgrad.shape))
+
+    def act_backward(self, gy, ref, gx, scale, rows, C, act, act_scale):
+        g = gy.float()
+        if act == hip.ACT_RELU:
+            g = g * (ref.float() > 0)
+        elif act == hip.ACT_GELU:
+            r = ref.float()
+            g = g * (0.5 * (1 + torch.erf(r * 0.7071067811865476)) + r * torch.exp(-0.5 * r * r) * 0.3989422804014327)
+        elif act == hip.ACT_ELU:
+            r = ref.float()
+            g = g * torch.where(r > 0, torch.ones_like(r), r / act_scale + 1)
+        elif act == hip.ACT_SIGMOID:
+            sg = ref.float() / act_scale
+            g = g * sg * (1 - sg)
+        g = g * act_scale
+        if scale is not None:
+            g = g * scale
+        gx.copy_(g.reshape(gx.shape))
+
+    def colsum(self, g, out, rows, C):
+        out.add_(g.reshape(rows, C).float().sum(0))
+
+    def layernorm_forward(self, x, gamma, beta, y, mean, rstd, rows, C, gelu):
+        xf = x.reshape(rows, C).float()
+        mu = xf.mean(1)
+        rs = (xf.var(1, unbiased=False) + 1e-5).rsqrt()
+        o = (xf - mu[:, None]) * rs[:, None]
+        if gamma is not None:
+            o = o * gamma + beta
+        if gelu:
+            o = F.gelu(o)
+        y.copy_(o.reshape(y.shape))
+        mean.copy_(mu)
+        rstd.copy_(rs)
+
+    def layernorm_backward(self, gy, x, gamma, beta, mean, rstd, gx, dgamma, dbeta, rows, C, gelu):
+        xf = x.reshape(rows, C).float().requires_grad_(True)
+        ga = gamma.clone().requires_grad_(True) if gamma is not None else None
+        be = beta.clone().requires_grad_(True) if beta is not None else None
+        with torch.enable_grad():
+            o = F.layer_norm(xf, (C,), ga, be, 1e-5)
+            if gelu:
+                o = F.gelu(o)
+            ins = [xf] + ([ga, be] if ga is not None else [])
+            gs = torch.autograd.grad(o, ins, gy.reshape(rows, C).float())
+        gx.copy_(gs[0].reshape(gx.shape))
+        if ga is not None:
+            dgamma.add_(gs[1])
+            dbeta.add_(gs[2])
+
+    def softmax_forward(self, x, y, rows, L):
+        y.copy_(F.softmax(x.float(), dim=-1))
+
+    def softmax_backward(self, gy, y, gx, rows, L):
+        yf, g = y.float(), gy.float()
+        gx.copy_(yf * (g - (yf * g).sum(-1, keepdim=True)))
+
+    @staticmethod
+    def _silog_terms(pred, gt, B, h, w, H, W, log_err):
+        p = pred.reshape(B, 1, h, w).float()
+        g = F.interpolate(gt.reshape(B, 1, H, W), size=(h, w), mode="nearest")
+        m = (g >= 0.2) & (g < 10.0)
+        d = (torch.log(p) - torch.log(g)) if log_err else ((p + torch.log(p)) - (g + torch.log(g)))
+        return p, m, torch.where(m, d, torch.zeros_like(d))
+
+    def silog_sums(self, pred, gt, sums, B, h, w, H, W, log_err):
+        _, m, d = self._silog_terms(pred, gt, B, h, w, H, W, log_err)
+        sums.add_(torch.stack([d.double().sum(), (d.double() ** 2).sum(), m.double().sum()]))
+
+    def silog_backward(self, pred, gt, sums, gloss, weight, lam, gpred, B, h, w, H, W, log_err):
+        p, m, d = self._silog_terms(pred, gt, B, h, w, H, W, log_err)
+        n = sums[2]
+        mean = sums[0] / n
+        var = sums[1] / n - lam * mean * mean
+        c = (10.0 / torch.sqrt(var) / n).float() * weight * gloss
+        dd = (1.0 / p) if log_err else (1.0 + 1.0 / p)
+        gpred.copy_(torch.where(m, c * (d - (lam * mean).float()) * dd, torch.zeros_like(d)).reshape(gpred.shape))
+
+    def seg_ce_sum(self, logits, target, out, P):
+        out.add_(F.cross_entropy(logits.reshape(P, 2).float(), target.reshape(P), reduction="sum").double())
+
+    def seg_ce_backward(self, logits, target, gloss, scale, glogits, P):
+        sm = F.softmax(logits.reshape(P, 2).float(), dim=-1)
+        sm = sm - F.one_hot(target.reshape(P), 2).float()
+        glogits.copy_((sm * (gloss * scale / P)).reshape(glogits.shape))
+
+    def sqnorm(self, g, sq, n):
+        sq.add_((g[:n].double() ** 2).sum())
+
+    def adamw_step(self, p, g, m, v, p16, sq, n, lr, b1, b2, eps, wd, bc1, bc2, max_norm, grad_scale):
+        coef = grad_scale
+        if sq is not None and max_norm > 0:
+            total = float(sq[0]) ** 0.5 * grad_scale
+            coef *= min(max_norm / (total + 1e-6), 1.0)
+        gi = g[:n] * coef
+        p[:n].mul_(1 - lr * wd)
+        m[:n].lerp_(gi, 1 - b1)
+        v[:n].mul_(b2).addcmul_(gi, gi, value=1 - b2)
+        p[:n].addcdiv_(m[:n], (v[:n].sqrt() / (bc2 ** 0.5)).add_(eps), value=-lr / bc1)
+        if p16 is not None:
+            p16[:n].copy_(p[:n])

@@ -1,0 +1,230 @@
+"""GPU parity of every C-ABI entry point against plain fp32 PyTorch math (tests/fake_device.py runs
+the same tensor-level calls on the CPU).  fp32 kernels use the exact-fp32 MFMA: tolerance 2e-5
+relative L2; bf16 kernels: 1.5e-2 (bf16 has 8 significant bits; accumulation is fp32)."""
+import pytest
+import torch
+
+from gw_depth_amd import hip
+from tests.fake_device import FakeDevice
+
+pytestmark = pytest.mark.gpu
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1.5e-2}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    hip.set_library(None)
+    return hip.library()
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-20))
+
+
+def rnd(*shape, dtype=torch.float32, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+CONV_CASES = [
+    # name, B, Hi, Wi, Cin, Cout, K, stride, pad, virt, extras
+    ("3x3_64_64", 2, 20, 24, 64, 64, 3, 1, 1, None, dict(shift=True, act=hip.ACT_RELU)),
+    ("1x1_256_64_res", 2, 12, 10, 256, 64, 1, 1, 0, None, dict(shift=True, residual=True, act=hip.ACT_RELU)),
+    ("3x3_s2_128_160", 2, 17, 21, 128, 160, 3, 2, 1, None, dict(act=hip.ACT_GELU, z=True, shift=True)),
+    ("1x1_s2_64_256", 1, 16, 16, 64, 256, 1, 2, 0, None, dict()),
+    ("7x7_s2_rgb", 2, 32, 40, 3, 64, 7, 2, 3, None, dict(shift=True, act=hip.ACT_RELU)),
+    ("3x3_30_60_odd", 2, 12, 16, 30, 60, 3, 1, 1, None, dict()),
+    ("3x3_300_120_odd", 1, 12, 16, 300, 120, 3, 1, 1, None, dict()),
+    ("up2_64_64_elu", 2, 10, 12, 64, 64, 3, 1, 1, (20, 24), dict(act=hip.ACT_ELU)),
+    ("up_size_64_32", 1, 9, 11, 64, 32, 3, 1, 1, (24, 32), dict(act=hip.ACT_ELU)),
+    ("3x3_32_1_sig10", 2, 24, 32, 32, 1, 3, 1, 1, None, dict(act=hip.ACT_SIGMOID, act_scale=10.0)),
+    ("3x3_32_2", 2, 24, 32, 32, 2, 3, 1, 1, None, dict()),
+    ("3x3_800_320", 1, 12, 16, 800, 320, 3, 1, 1, None, dict()),
+    ("lin_300x256_768", 300, 1, 1, 256, 768, 1, 1, 0, None, dict(shift=True)),
+    ("lin_800x2048_256", 800, 1, 1, 2048, 256, 1, 1, 0, None, dict(shift=True)),
+    ("lin_1176x64_128_gelu", 1176, 1, 1, 64, 128, 1, 1, 0, None, dict(shift=True, act=hip.ACT_GELU, z=True)),
+    ("lin_5x384_384", 5, 1, 1, 384, 384, 1, 1, 0, None, dict()),
+]
+
+
+def conv_out(Hi, K, s, p):
+    return (Hi + 2 * p - K) // s + 1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_forward_dgrad_wgrad(dev, case, dtype):
+    name, B, Hi, Wi, Cin, Cout, K, s, p, virt, ex = case
+    fake = FakeDevice()
+    if virt is None:
+        Ho, Wo = conv_out(Hi, K, s, p), conv_out(Wi, K, s, p)
+        gather, vv = hip.GATHER_CONV, (0, 0)
+    else:
+        Ho, Wo = virt
+        gather, vv = hip.GATHER_UPSAMPLED, virt
+    dims = (B, Hi, Wi, Cin, Ho, Wo, Cout, K, K)
+    x = rnd(B, Hi, Wi, Cin, dtype=dtype, seed=1)
+    w = rnd(Cout, K, K, Cin, dtype=dtype, seed=2, scale=(K * K * Cin) ** -0.5)
+    shift = rnd(Cout, seed=3) if ex.get("shift") else None
+    res = rnd(B, Ho, Wo, Cout, dtype=dtype, seed=4) if ex.get("residual") else None
+    act, act_scale = ex.get("act", hip.ACT_NONE), ex.get("act_scale", 1.0)
+    kw = dict(shift=shift, residual=res, stride=s, pad=p, gather=gather, virt=vv, act=act, act_scale=act_scale)
+
+    y_ref = torch.empty(B, Ho, Wo, Cout, dtype=dtype)
+    z_ref = torch.empty_like(y_ref) if ex.get("z") else None
+    fake.conv_forward(x, w, y_ref, dims, z=z_ref, **kw)
+
+    cu = lambda t: None if t is None else t.cuda()
+    y = torch.full((B, Ho, Wo, Cout), float("nan"), dtype=dtype, device="cuda")
+    z = torch.empty_like(y) if ex.get("z") else None
+    kwc = dict(kw, shift=cu(shift), residual=cu(res))
+    dev.conv_forward(x.cuda(), w.cuda(), y, dims, z=z, **kwc)
+    torch.cuda.synchronize()
+    assert rel(y, y_ref) < TOL[dtype], "forward"
+    if z is not None:
+        assert rel(z, z_ref) < TOL[dtype], "pre-activation copy"
+
+    # data gradient through the transposed gather (plain and strided); upsampled handled at virtual size
+    gy = rnd(B, Ho, Wo, Cout, dtype=dtype, seed=5)
+    wt_ref = torch.empty(Cin, K, K, Cout, dtype=dtype)
+    fake.weight_prep(w.float(), None, None, wt_ref, Cout, K * K, Cin, 0)
+    wt = torch.empty(Cin, K, K, Cout, dtype=dtype, device="cuda")
+    dev.weight_prep(w.float().cuda(), None, None, wt, Cout, K * K, Cin, hip.dtype_code(wt))
+    assert rel(wt, wt_ref) < 1e-6
+    Hd, Wd = (Hi, Wi) if virt is None else virt
+    ddims = (B, Ho, Wo, Cout, Hd, Wd, Cin, K, K)
+    gx_ref = torch.empty(B, Hd, Wd, Cin, dtype=dtype)
+    fake.conv_forward(gy, wt_ref, gx_ref, ddims, stride=s, pad=p, gather=hip.GATHER_TRANSPOSED)
+    gx = torch.full((B, Hd, Wd, Cin), float("nan"), dtype=dtype, device="cuda")
+    dev.conv_forward(gy.cuda(), wt, gx, ddims, stride=s, pad=p, gather=hip.GATHER_TRANSPOSED)
+    torch.cuda.synchronize()
+    assert rel(gx, gx_ref) < TOL[dtype], "dgrad"
+
+    # weight gradient (fp32 accumulate, atomics)
+    dw_ref = torch.zeros(Cout, K, K, Cin)
+    fake.conv_wgrad(x, gy, dw_ref, dims, stride=s, pad=p, gather=gather, virt=vv)
+    dw = torch.zeros(Cout, K, K, Cin, device="cuda")
+    dev.conv_wgrad(x.cuda(), gy.cuda(), dw, dims, stride=s, pad=p, gather=gather, virt=vv)
+    torch.cuda.synchronize()
+    assert rel(dw, dw_ref) < TOL[dtype], "wgrad"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,C,gelu,affine", [(300, 256, False, True), (1000, 64, False, True), (77, 160, True, True),
+                                                (513, 30, True, True), (64, 512, False, True), (40, 320, False, False)])
+def test_layernorm(dev, rows, C, gelu, affine, dtype):
+    fake = FakeDevice()
+    x = rnd(rows, C, dtype=dtype, seed=1, scale=2.0)
+    ga = (1 + 0.1 * rnd(C, seed=2)) if affine else None
+    be = 0.1 * rnd(C, seed=3) if affine else None
+    gy = rnd(rows, C, dtype=dtype, seed=4)
+    y_r, m_r, r_r = torch.empty_like(x), torch.empty(rows), torch.empty(rows)
+    fake.layernorm_forward(x, ga, be, y_r, m_r, r_r, rows, C, gelu)
+    gx_r, dg_r, db_r = torch.empty_like(x), torch.zeros(C), torch.zeros(C)
+    fake.layernorm_backward(gy, x, ga, be, m_r, r_r, gx_r, dg_r if affine else None, db_r if affine else None, rows, C, gelu)
+    cu = lambda t: None if t is None else t.cuda()
+    y, m, r = torch.empty_like(x).cuda(), torch.empty(rows).cuda(), torch.empty(rows).cuda()
+    dev.layernorm_forward(x.cuda(), cu(ga), cu(be), y, m, r, rows, C, gelu)
+    gx, dg, db = torch.empty_like(x).cuda(), torch.zeros(C).cuda(), torch.zeros(C).cuda()
+    dev.layernorm_backward(gy.cuda(), x.cuda(), cu(ga), cu(be), m, r, gx, dg if affine else None, db if affine else None,
+                           rows, C, gelu)
+    torch.cuda.synchronize()
+    assert rel(y, y_r) < TOL[dtype] and rel(m, m_r) < 1e-5 and rel(r, r_r) < 1e-5
+    assert rel(gx, gx_r) < TOL[dtype]
+    if affine:
+        assert rel(dg, dg_r) < TOL[dtype] and rel(db, db_r) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,L", [(64 * 16 * 49, 49), (1000, 40), (999, 24), (512, 300), (100, 100), (7, 1000)])
+def test_softmax(dev, rows, L, dtype):
+    fake = FakeDevice()
+    x = rnd(rows, L, dtype=dtype, seed=1, scale=3.0)
+    x[0, : L // 2] = float("-inf")        # key-padding style -inf entries
+    gy = rnd(rows, L, dtype=dtype, seed=2)
+    y_r, gx_r = torch.empty_like(x), torch.empty_like(x)
+    fake.softmax_forward(x, y_r, rows, L)
+    fake.softmax_backward(gy, y_r, gx_r, rows, L)
+    y, gx = torch.empty_like(x).cuda(), torch.empty_like(x).cuda()
+    dev.softmax_forward(x.cuda(), y, rows, L)
+    dev.softmax_backward(gy.cuda(), y_r.cuda(), gx, rows, L)
+    torch.cuda.synchronize()
+    assert rel(y, y_r) < TOL[dtype] and rel(gx, gx_r) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act,scale", [(hip.ACT_RELU, 1.0), (hip.ACT_GELU, 1.0), (hip.ACT_ELU, 1.0),
+                                       (hip.ACT_SIGMOID, 10.0), (hip.ACT_NONE, 1.0)])
+def test_act_backward_and_colsum(dev, act, scale, dtype):
+    fake = FakeDevice()
+    rows, C = 1234, 96
+    gy = rnd(rows, C, dtype=dtype, seed=1)
+    pre = rnd(rows, C, seed=2)
+    ref = pre if act == hip.ACT_GELU else (scale * {hip.ACT_RELU: torch.relu, hip.ACT_ELU: torch.nn.functional.elu,
+                                                    hip.ACT_SIGMOID: torch.sigmoid, hip.ACT_NONE: lambda t: t}.get(act, lambda t: t)(pre))
+    ref = ref.to(dtype)
+    ch = rnd(C, seed=3)
+    gx_r, gx = torch.empty_like(gy), torch.empty_like(gy).cuda()
+    fake.act_backward(gy, ref, gx_r, ch, rows, C, act, scale)
+    dev.act_backward(gy.cuda(), ref.cuda(), gx, ch.cuda(), rows, C, act, scale)
+    s_r, s = torch.zeros(C), torch.zeros(C).cuda()
+    fake.colsum(gy, s_r, rows, C)
+    dev.colsum(gy.cuda(), s, rows, C)
+    torch.cuda.synchronize()
+    assert rel(gx, gx_r) < TOL[dtype] and rel(s, s_r) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("log_err", [True, False])
+@pytest.mark.parametrize("hw", [(30, 40), (15, 20), (120, 160), (96, 128)])
+def test_silog_and_segce(dev, hw, log_err, dtype):
+    fake = FakeDevice()
+    B, H, W = 2, 96, 128
+    h, w = hw if hw[0] <= H else (H, W)
+    g = torch.Generator().manual_seed(5)
+    gt = torch.rand(B, H, W, generator=g) * 9 + 0.5
+    gt[torch.rand(B, H, W, generator=g) < 0.1] = 0.0
+    pred = (torch.rand(B, h, w, generator=g) * 0.9 + 0.05).to(dtype)
+    gl = torch.tensor([0.7])
+    s_r, s = torch.zeros(3, dtype=torch.float64), torch.zeros(3, dtype=torch.float64).cuda()
+    fake.silog_sums(pred, gt, s_r, B, h, w, H, W, log_err)
+    dev.silog_sums(pred.cuda(), gt.cuda(), s, B, h, w, H, W, log_err)
+    gp_r, gp = torch.empty_like(pred), torch.empty_like(pred).cuda()
+    fake.silog_backward(pred, gt, s_r, gl, 0.25, 0.85, gp_r, B, h, w, H, W, log_err)
+    dev.silog_backward(pred.cuda(), gt.cuda(), s, gl.cuda(), 0.25, 0.85, gp, B, h, w, H, W, log_err)
+    torch.cuda.synchronize()
+    assert s.cpu()[2] == s_r[2]                       # valid-pixel count: exact
+    assert rel(s, s_r) < 1e-5 and rel(gp, gp_r) < TOL[dtype]
+
+    P = B * h * w
+    logits = rnd(P, 2, dtype=dtype, seed=9, scale=2.0)
+    tgt = (torch.rand(P, generator=g) < 0.5).long()
+    c_r, c = torch.zeros(1, dtype=torch.float64), torch.zeros(1, dtype=torch.float64).cuda()
+    fake.seg_ce_sum(logits, tgt, c_r, P)
+    dev.seg_ce_sum(logits.cuda(), tgt.cuda(), c, P)
+    q_r, q = torch.empty_like(logits), torch.empty_like(logits).cuda()
+    fake.seg_ce_backward(logits, tgt, gl, 2.0, q_r, P)
+    dev.seg_ce_backward(logits.cuda(), tgt.cuda(), gl.cuda(), 2.0, q, P)
+    torch.cuda.synchronize()
+    assert rel(c, c_r) < 1e-5 and rel(q, q_r) < TOL[dtype]
+
+
+def test_sqnorm_adamw(dev):
+    fake = FakeDevice()
+    n = 1_000_003
+    p, g = rnd(n, seed=1), rnd(n, seed=2, scale=3.0)
+    m, v = rnd(n, seed=3, scale=0.1), rnd(n, seed=4).abs() * 0.01
+    outs = []
+    for lib, to in ((fake, lambda t: t.clone()), (dev, lambda t: t.cuda())):
+        P, G, M, V = to(p), to(g), to(m), to(v)
+        P16 = torch.empty(n, dtype=torch.bfloat16, device=P.device)
+        sq = torch.zeros(1, dtype=torch.float64, device=P.device)
+        lib.sqnorm(G, sq, n)
+        lib.adamw_step(P, G, M, V, P16, sq, n, 1e-4, 0.9, 0.999, 1e-8, 1e-4, 1 - 0.9 ** 3, 1 - 0.999 ** 3, 0.1, 0.5)
+        outs.append((sq.cpu(), P.cpu(), M.cpu(), V.cpu(), P16.float().cpu()))
+    torch.cuda.synchronize()
+    for a, b in zip(outs[1], outs[0]):
+        assert rel(a, b) < 1e-5
