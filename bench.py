@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""bench.py — images/s of the full GW-Depth train step (fwd + 17 losses + bwd + clip + AdamW
+[+ RCCL gradient all-reduce when N > 1]) on synthetic 480x640 batches, B=8 per GPU, bf16 storage /
+fp32 accumulate (BASELINE.json configs[1]).  One process per GPU; prints ONE JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 8] [--dtype bf16|fp32] [--no-cpu-baseline]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_MFMA_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBPS = 8000.0
+STEP_GFLOP_PER_IMAGE = 1049.5      # fwd + losses + bwd, conv/mm/addmm/bmm only
+BACKBONE_GFLOP_PER_IMAGE = 128.4   # 50.05 fwd + 78.33 bwd
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-budget-s", type=float, default=25.0)
+    ap.add_argument("--kernel-timing", action="store_true", default=True)
+    return ap.parse_args()
+
+
+def cpu_baseline(sd_cpu, cfg, budget_s):
+    """The oracle (CPU restatement of the reference, checked against the reference's golden vectors) timed on
+    the host cores: a bounded sample — ONE fp32 train step at batch 1, 480x640, same synthetic recipe."""
+    from gw_depth_amd.synth import synth_batch
+    from oracle import gwdepth_ref as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ocfg = R.Cfg(dropout=cfg.dropout, log_depth_error=cfg.log_depth_error)
+    b = synth_batch(1, 480, 640, seed=1)
+    sd = {k: v.clone() for k, v in sd_cpu.items()}
+    opt = {}
+    t0 = time.time()
+    n = 0
+    while True:
+        R.train_step(sd, b, ocfg, opt_state=opt, step=n + 1, training=True)
+        n += 1
+        el = time.time() - t0
+        if el + el / n > budget_s or n >= 3:
+            break
+    return {"value": round(n / el, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d fp32 train step(s), batch 1, 480x640, oracle/gwdepth_ref.py on %d host threads (%.1f s)" % (n, cores, el)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from gw_depth_amd import Config, build_model, hip
+    from gw_depth_amd.engine import TrainStep
+    from gw_depth_amd.synth import det_fill_, synth_batch
+    lib = hip.library()
+    assert not getattr(lib, "is_fake", False)
+
+    cfg = Config(device="cuda", dropout=0.1, log_depth_error=True)
+    model, crits, _ = build_model(cfg)
+    sd_cpu = det_fill_({k: v.detach().clone() for k, v in model.state_dict().items()}, seed=0)   # weight seed 0
+    model.load_state_dict(sd_cpu)
+    model.cuda()
+    crits[0].cuda()
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    step = TrainStep(model, crits, cfg, compute_dtype=dtype)
+    b = synth_batch(a.batch, a.height, a.width, seed=1 + rank)                                   # data seed 1 + rank
+    batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    batch["targets"] = [{k: v.cuda() for k, v in t.items()} for t in b["targets"]]
+    torch.manual_seed(100 + rank)
+
+    for _ in range(a.warmup):
+        step(batch)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        _, total, _ = step(batch)
+    barrier()
+    el = time.perf_counter() - t0
+    t = torch.tensor([el], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    ips = a.batch * world * a.steps / el
+
+    roofline = None
+    if rank == 0:
+        roofline = dominant_kernel_roofline(lib, dtype)
+    out = {
+        "metric": "images/sec (train fwd+bwd) 480x640 bs=8/GPU",
+        "value": round(ips, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(1000 * el / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": "GW-Depth full model (res50 + DETR 6+6 + 4-scale ReferTransformer + decoder) "
+                               "fwd+17 losses+bwd+clip+AdamW, %dx%d, bs=%d/GPU, dropout 0.1" % (a.height, a.width, a.batch),
+                   "global_batch": a.batch * world, "parallelism": "dp%d" % world,
+                   "step_gflop_per_image": STEP_GFLOP_PER_IMAGE,
+                   "whole_step_mfma_frac": round(ips / world * STEP_GFLOP_PER_IMAGE / 1000.0 / PEAK_MFMA_BF16_TFLOPS, 5),
+                   "final_loss": round(float(total), 4)},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(sd_cpu, cfg, a.cpu_baseline_budget_s)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def dominant_kernel_roofline(lib, dtype):
+    """Times the dominant kernel of the step — the 3x3 160->160 ConvLn convolution of
+    point_based_pred2.pyramid at 1/4 resolution (B=8: M = 8*120*160 = 153600 output pixels; 10 forward
+    instances + the K=7200 lastconv make this pyramid 52 % of all forward FLOPs, SURVEY.md header) — live,
+    with HIP events on the launch stream.  Algorithmic FLOPs per launch = 2*M*K*N."""
+    B, H, W, C = 8, 120, 160, 160
+    x = torch.randn(B, H, W, C, device="cuda").to(dtype)
+    w = (torch.randn(C, 3, 3, C, device="cuda") * (9 * C) ** -0.5).to(dtype)
+    y = torch.empty(B, H, W, C, device="cuda", dtype=dtype)
+    dims = (B, H, W, C, H, W, C, 3, 3)
+    for _ in range(3):
+        lib.conv_forward(x, w, y, dims, stride=1, pad=1)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 20
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(n):
+        lib.conv_forward(x, w, y, dims, stride=1, pad=1)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / n
+    flops = 2.0 * B * H * W * 9 * C * C
+    ach = flops / (ms * 1e-3) / 1e12
+    peak = PEAK_MFMA_BF16_TFLOPS if dtype == torch.bfloat16 else 157.3
+    return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "traffic": None, "kernel": "igemm_fwd_kernel<%s,128,128> conv3x3 160->160 @ 8x120x160" % ("bf16" if dtype == torch.bfloat16 else "f32"),
+            "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(flops / 1e9, 2)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,120 @@
+"""Criteria with the reference's call signatures (/root/reference/src/models/glassrgbd.py:133-383,
+/root/reference/src/models/matcher.py).  The dense losses run on the fused HIP reductions; the line
+losses are a few hundred elements (latency class) and use torch tensor plumbing plus scipy's LSAP on
+the host exactly as the reference does."""
+import torch
+import torch.nn.functional as F
+from scipy.optimize import linear_sum_assignment
+from torch import nn
+
+from . import ops
+
+
+def _dist_ready():
+    return torch.distributed.is_available() and torch.distributed.is_initialized()
+
+
+class HungarianMatcherLine(nn.Module):
+    """cost = cost_line * L1 cdist - cost_class * prob[target class]; scipy LSAP per image (matcher.py:28-82)."""
+
+    def __init__(self, cost_class=1.0, cost_line=5.0):
+        super().__init__()
+        self.cost_class, self.cost_line = cost_class, cost_line
+
+    @torch.no_grad()
+    def cost_matrix(self, outputs, targets):
+        B, Q = outputs["pred_logits"].shape[:2]
+        prob = outputs["pred_logits"].flatten(0, 1).float().softmax(-1)
+        lines = outputs["pred_lines"].flatten(0, 1).float()
+        tgt_ids = torch.cat([t["labels"] for t in targets])
+        tgt_lines = torch.cat([t["lines"] for t in targets])
+        C = self.cost_line * torch.cdist(lines, tgt_lines, p=1) + self.cost_class * (-prob[:, tgt_ids])
+        return C.view(B, Q, -1)
+
+    @torch.no_grad()
+    def forward(self, outputs, targets):
+        C = self.cost_matrix(outputs, targets).cpu()
+        sizes = [len(t["lines"]) for t in targets]
+        res = [linear_sum_assignment(c[i]) for i, c in enumerate(C.split(sizes, -1))]
+        return [(torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)) for i, j in res]
+
+
+class SetCriterion(nn.Module):
+    """SetCriterion with losses ['lines_labels', 'lines'] (+ aux), glassrgbd.py:133-358."""
+
+    def __init__(self, num_classes, weight_dict, eos_coef, losses, matcher):
+        super().__init__()
+        self.num_classes, self.weight_dict, self.eos_coef, self.losses, self.matcher = \
+            num_classes, weight_dict, eos_coef, losses, matcher
+        w = torch.ones(num_classes + 1)
+        w[-1] = eos_coef
+        self.register_buffer("empty_weight", w)
+        self.last_indices = []
+
+    @staticmethod
+    def _src_idx(indices):
+        b = torch.cat([torch.full_like(s, i) for i, (s, _) in enumerate(indices)])
+        return b, torch.cat([s for s, _ in indices])
+
+    def _one(self, out, targets, num_items, suffix):
+        idx = self.matcher(out, targets)
+        self.last_indices.append(idx)
+        dev = out["pred_logits"].device
+        bi, si = self._src_idx(idx)
+        bi, si = bi.to(dev), si.to(dev)
+        tc = torch.full(out["pred_logits"].shape[:2], self.num_classes, dtype=torch.int64, device=dev)
+        tc[bi, si] = torch.cat([t["labels"][j.to(dev)] for t, (_, j) in zip(targets, idx)])
+        ce = F.cross_entropy(out["pred_logits"].float().transpose(1, 2), tc, self.empty_weight)          # :168
+        tl = torch.cat([t["lines"][j.to(dev)] for t, (_, j) in zip(targets, idx)], dim=0)
+        l1 = F.l1_loss(out["pred_lines"].float()[bi, si], tl, reduction="none").sum() / num_items         # :239-242
+        return {"loss_ce" + suffix: ce, "loss_line" + suffix: l1}
+
+    def forward(self, outputs, targets, origin_indices=None, depth_gt=None):
+        self.last_indices = []
+        n = torch.as_tensor([float(sum(len(t["labels"]) for t in targets))], device=outputs["pred_logits"].device)
+        world = 1
+        if _dist_ready():                                                                               # :323-326
+            torch.distributed.all_reduce(n)
+            world = torch.distributed.get_world_size()
+        num_items = torch.clamp(n / world, min=1).item()
+        losses = self._one({k: v for k, v in outputs.items() if k != "aux_outputs"}, targets, num_items, "")
+        for i, aux in enumerate(outputs.get("aux_outputs", [])):
+            losses.update(self._one(aux, targets, num_items, f"_{i}"))
+        return losses
+
+
+class SilogLoss(nn.Module):
+    """criterion_depth(pred, gt, mask_bool): glassrgbd.py:360-374 on the fused masked reduction."""
+
+    def __init__(self, variance_focus=0.85, log_depth_error=True):
+        super().__init__()
+        self.variance_focus, self.log_depth_error = variance_focus, log_depth_error
+
+    def forward(self, depth_est, depth_gt, mask):
+        # the kernel derives validity from the GT range [0.2, 10): express an arbitrary mask through it
+        gt = torch.where(mask, depth_gt.float().clamp(0.2, 9.999999), torch.zeros_like(depth_gt, dtype=torch.float32))
+        return ops.silog_loss(depth_est, gt, 1.0, self.variance_focus, self.log_depth_error)
+
+    def fused(self, depth_est, depth_gt_full, weight):
+        """weight * SiLog against the nearest-resized GT / validity mask of engine_glassrgbd.py:65,76-78."""
+        return ops.silog_loss(depth_est, depth_gt_full, weight, self.variance_focus, self.log_depth_error)
+
+
+class SegLoss(nn.Module):
+    """criterion_seg(logits (B,2,H,W), target (B,H,W) int64): glassrgbd.py:376-383."""
+
+    def forward(self, seg_pred, seg_gt, scale=1.0):
+        return ops.seg_cross_entropy(seg_pred.permute(0, 2, 3, 1), seg_gt, scale)
+
+
+class PostProcessLine(nn.Module):
+    """PostProcess_Line 'prediction' branch, glassrgbd.py:452-479."""
+
+    @torch.no_grad()
+    def forward(self, outputs, target_sizes, output_type="prediction"):
+        prob = F.softmax(outputs["pred_logits"].float(), -1)
+        scores, labels = prob[..., :-1].max(-1)
+        img_h, img_w = target_sizes.unbind(1)
+        scale = torch.stack([img_w, img_h, img_w, img_h], dim=1)
+        lines = outputs["pred_lines"][..., :4] * scale[:, None, :]
+        return [{"scores": s, "labels": l, "lines": b} for s, l, b in zip(scores, labels, lines)]

@@ -1,0 +1,196 @@
+"""The train step: forward, 17 loss terms, backward, gradient all-reduce, clip, AdamW.
+
+Mirror of the body of train_one_epoch (/root/reference/src/engine_glassrgbd.py:45-166) and of the
+optimizer / DDP setup of /root/reference/src/main_glassrgbd.py:46-67, re-laid for MI355X:
+
+* all trainable parameters, their gradients and both Adam moments live in four flat fp32 HBM
+  buffers (plus a bf16 shadow of the parameters when activations are bf16), so zero_grad is one
+  memset, the global-norm is one reduction and clip+AdamW is one streaming kernel per LR group;
+* data parallelism is one process per GPU: the flat gradient buffer is cut into contiguous buckets
+  in (approximate) backward order and each bucket is all-reduced over RCCL as soon as the last of its
+  live parameters has accumulated its gradient, overlapping with the rest of backward; the 54
+  parameters that never receive a gradient are learned on the first step and simply
+  stay zero — no find_unused_parameters graph walk, no buffer broadcasts.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import hip
+from .model import NestedTensor
+
+FORWARD_ORDER = ["backbone", "input_proj", "query_embed", "transformer", "class_embed", "lines_embed",
+                 "dense_input_proj", "dense_encoder", "depth_decoder"]
+ALIGN = 8   # elements: keeps every bf16 shadow slice 16-byte aligned
+
+
+def _align(n):
+    return (n + ALIGN - 1) // ALIGN * ALIGN
+
+
+class TrainStep:
+    def __init__(self, model, criterions, cfg, compute_dtype=torch.float32, bucket_mb=32.0, process_group=None,
+                 check_finite=True):
+        self.model, self.cfg = model, cfg
+        self.criterion, self.criterion_depth, self.criterion_seg, _ = criterions
+        self.compute_dtype = compute_dtype
+        model.compute_dtype = compute_dtype
+        self.check_finite = check_finite
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.step_count = 0
+
+        named = dict(model.named_parameters())
+        order = []
+        for top in FORWARD_ORDER:
+            order += [n for n in named if n.split(".")[0] == top and named[n].requires_grad]
+        assert len(order) == sum(p.requires_grad for p in named.values()), "FORWARD_ORDER misses a top-level module"
+        order.reverse()                                   # ~ the order in which backward produces gradients
+        head = [n for n in order if "backbone" not in n]  # LR group 0 (main_glassrgbd.py:59-64)
+        tail = [n for n in order if "backbone" in n]      # LR group 1: lr_backbone
+        self.names = head + tail
+        offs, off = {}, 0
+        for n in self.names:
+            offs[n] = off
+            off += _align(named[n].numel())
+        self.offsets, self.total = offs, off
+        self.split = offs[tail[0]] if tail else off
+        dev = next(model.parameters()).device
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        self.flat_p16 = torch.zeros(off, dtype=torch.bfloat16, device=dev) if compute_dtype == torch.bfloat16 else None
+        self.sq = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.params = {}
+        for n in self.names:
+            p, o, k = named[n], offs[n], named[n].numel()
+            self.flat_p[o:o + k].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[o:o + k].view(p.shape)
+            p.grad = self.flat_g[o:o + k].view(p.shape)
+            if self.flat_p16 is not None:
+                p._gwd_bf16 = self.flat_p16[o:o + k].view(p.shape)
+            self.params[n] = p
+        if self.flat_p16 is not None:
+            self.flat_p16.copy_(self.flat_p)
+
+        # ---- bucket plan: contiguous flat ranges of ~bucket_mb
+        per = max(int(bucket_mb * (1 << 20) / 4), 1)
+        self.buckets, start, members = [], 0, []
+        for n in self.names:
+            members.append(n)
+            end = offs[n] + _align(named[n].numel())
+            if end - start >= per:
+                self.buckets.append((start, end, members))
+                start, members = end, []
+        if members:
+            self.buckets.append((start, off, members))
+        self.live = None            # learned on the first step
+        self._pending, self._works = None, []
+        if self.world > 1:
+            for bi, (_, _, mem) in enumerate(self.buckets):
+                for n in mem:
+                    self.params[n].register_post_accumulate_grad_hook(self._make_hook(bi, n))
+
+    # ------------------------------------------------------------------ DDP
+    def _make_hook(self, bi, name):
+        def hook(_p):
+            if self._pending is None:
+                return
+            if self.live is None:
+                self._seen.add(name)
+            elif name not in self.live:            # a parameter that was dead on step 1 woke up
+                self.live.add(name)
+                self._late.append(name)
+            else:
+                self._pending[bi] -= 1
+                if self._pending[bi] == 0:
+                    self._launch(self.buckets[bi][0], self.buckets[bi][1])
+                    self._launched.add(bi)
+        return hook
+
+    def _launch(self, s, e):
+        self._works.append(dist.all_reduce(self.flat_g[s:e], group=self.pg, async_op=True))
+
+    def _begin_backward(self):
+        if self.world == 1:
+            return
+        self._works, self._late, self._launched = [], [], set()
+        if self.live is None:
+            self._seen, self._pending = set(), [0] * len(self.buckets)
+        else:
+            self._pending = [sum(n in self.live for n in mem) for _, _, mem in self.buckets]
+
+    def _finish_backward(self):
+        if self.world == 1:
+            return
+        if self.live is None:                      # first step: no overlap, learn the live set
+            self.live = set(self._seen)
+            for s, e, _ in self.buckets:
+                self._launch(s, e)
+        else:
+            for bi, left in enumerate(self._pending):
+                if left > 0 and bi not in self._launched:     # a live parameter got no gradient this step
+                    self._launch(self.buckets[bi][0], self.buckets[bi][1])
+            for n in self._late:
+                bi = next(i for i, b in enumerate(self.buckets) if n in b[2])
+                if bi in self._launched:           # its bucket already went out without it: reduce the slice alone
+                    o = self.offsets[n]
+                    self._launch(o, o + self.params[n].numel())
+        for w in self._works:
+            w.wait()
+        self._pending = None
+
+    # ------------------------------------------------------------------ losses (engine_glassrgbd.py:62-115)
+    def losses(self, out, depth_gt, seg_gt, targets):
+        cfg = self.cfg
+        terms = self.criterion(out, targets)
+        wd = self.criterion.weight_dict
+        total = sum(terms[k] * wd[k] for k in terms if k in wd)
+        names = ["1/16", "1/8", "1/4", "1"]
+        for i, pd in enumerate(out["pred_depth"]):
+            ld = self.criterion_depth.fused(pd, depth_gt, cfg.depth_loss_weights[i])
+            terms["loss_depth_" + names[i]] = ld
+            total = total + ld
+        ls = self.criterion_seg(out["pred_seg"], seg_gt.reshape(seg_gt.shape[0], *seg_gt.shape[-2:]), cfg.seg_loss_weight)
+        terms["loss_seg"] = ls
+        return total + ls, terms
+
+    # ------------------------------------------------------------------ the step
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+    def optimizer_step(self):
+        cfg, lib = self.cfg, hip.library()
+        self.step_count += 1
+        t = self.step_count
+        bc1, bc2 = 1 - 0.9 ** t, 1 - 0.999 ** t
+        self.sq.zero_()
+        lib.sqnorm(self.flat_g, self.sq, self.total)
+        gs = 1.0 / self.world
+        for lo, hi, lr in ((0, self.split, cfg.lr), (self.split, self.total, cfg.lr_backbone)):
+            if hi > lo:
+                lib.adamw_step(self.flat_p[lo:hi], self.flat_g[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi],
+                               None if self.flat_p16 is None else self.flat_p16[lo:hi], self.sq, hi - lo, lr, 0.9, 0.999,
+                               1e-8, cfg.weight_decay, bc1, bc2, cfg.clip_max_norm, gs)
+
+    def grad_norm(self):
+        """Un-clipped global gradient norm of the last step (host sync)."""
+        return math.sqrt(float(self.sq.item())) / self.world
+
+    def __call__(self, batch, taps=None):
+        """batch: dict(images (B,3,H,W), pad_mask (B,H,W) bool, depth (B,1,H,W), seg (B,1,H,W) i64, targets)."""
+        self.model.train()
+        out = self.model(NestedTensor(batch["images"], batch["pad_mask"]), taps=taps)
+        total, terms = self.losses(out, batch["depth"], batch["seg"], batch["targets"])
+        self.zero_grad()
+        self._begin_backward()
+        total.backward()
+        self._finish_backward()
+        self.optimizer_step()
+        if self.check_finite:                       # engine_glassrgbd.py:143-153 (one host sync, after all launches)
+            v = float(total.detach())
+            if not math.isfinite(v):
+                raise FloatingPointError("Loss is %r, stopping training" % v)
+        return out, total.detach(), terms

@@ -1,0 +1,813 @@
+"""GW-Depth model on the MI355X kernels: host-side mirror of the reference's model interface.
+
+Same module tree / state-dict key names as the reference (970 entries), same forward contract
+(GlassRGBD.forward, /root/reference/src/models/glassrgbd.py:74-123) — but every feature map is kept
+pixel-major (B, H, W, C), so that map <-> token reshapes are free, channel LayerNorms and softmaxes
+run over the contiguous dim, and the convolutions are implicit GEMMs over NHWC.  Dense compute goes
+through gw_depth_amd.ops (hand-written gfx950 kernels behind the C ABI); torch is used for device
+memory, autograd bookkeeping and small index plumbing (pad / roll / gather).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from .layers import Conv, FrozenBN, LayerNorm, Linear, Mlp, MlpNorm, Seq
+from .ops import ACT_ELU, ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID
+
+WS = 7
+HEADS = 16
+
+
+class NestedTensor:
+    """(tensors, mask) pair, /root/reference/src/util/misc.py:347-367."""
+
+    def __init__(self, tensors, mask):
+        self.tensors, self.mask = tensors, mask
+
+    def to(self, device):
+        return NestedTensor(self.tensors.to(device), None if self.mask is None else self.mask.to(device))
+
+    def decompose(self):
+        return self.tensors, self.mask
+
+
+def nested_tensor_from_tensor_list(tensor_list):
+    """Zero-pad to the largest (H, W); mask True = padding (/root/reference/src/util/misc.py:291-313)."""
+    if isinstance(tensor_list, torch.Tensor) and tensor_list.dim() == 4:
+        tensor_list = list(tensor_list)
+    if tensor_list[0].dim() != 3:
+        raise ValueError("not supported")
+    c = tensor_list[0].shape[0]
+    h = max(t.shape[1] for t in tensor_list)
+    w = max(t.shape[2] for t in tensor_list)
+    out = torch.zeros((len(tensor_list), c, h, w), dtype=tensor_list[0].dtype, device=tensor_list[0].device)
+    mask = torch.ones((len(tensor_list), h, w), dtype=torch.bool, device=out.device)
+    for img, pad, m in zip(tensor_list, out, mask):
+        pad[:, : img.shape[1], : img.shape[2]].copy_(img)
+        m[: img.shape[1], : img.shape[2]] = False
+    return NestedTensor(out, mask)
+
+
+def to_nchw(x):
+    """(B,H,W,C) contiguous -> (B,C,H,W) channels-last view (no copy)."""
+    return x.permute(0, 3, 1, 2)
+
+
+def to_pixel_major(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def pos_sine(mask, num_pos_feats, normalize):
+    """PositionEmbeddingSine (/root/reference/src/models/position_encoding.py:28-48) -> (B,h,w,2F) fp32."""
+    not_mask = ~mask
+    y = not_mask.cumsum(1, dtype=torch.float32)
+    x = not_mask.cumsum(2, dtype=torch.float32)
+    if normalize:
+        y = y / (y[:, -1:, :] + 1e-6) * (2 * math.pi)
+        x = x / (x[:, :, -1:] + 1e-6) * (2 * math.pi)
+    dim_t = torch.arange(num_pos_feats, dtype=torch.float32, device=mask.device)
+    dim_t = 10000 ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / num_pos_feats)
+    px = x[:, :, :, None] / dim_t
+    py = y[:, :, :, None] / dim_t
+    px = torch.stack((px[..., 0::2].sin(), px[..., 1::2].cos()), dim=4).flatten(3)
+    py = torch.stack((py[..., 0::2].sin(), py[..., 1::2].cos()), dim=4).flatten(3)
+    return torch.cat((py, px), dim=3)
+
+
+# ------------------------------------------------------------------------------------ backbone
+class Bottleneck(nn.Module):
+    """torchvision ResNet v1.5 Bottleneck with FrozenBN folded into each conv and the residual +
+    ReLU fused into the third conv's epilogue."""
+
+    def __init__(self, inplanes, planes, stride, down):
+        super().__init__()
+        self.conv1, self.bn1 = Conv(inplanes, planes, 1), FrozenBN(planes)
+        self.conv2, self.bn2 = Conv(planes, planes, 3), FrozenBN(planes)
+        self.conv3, self.bn3 = Conv(planes, planes * 4, 1), FrozenBN(planes * 4)
+        self.stride = stride
+        self.downsample = Seq(_0=Conv(inplanes, planes * 4, 1), _1=FrozenBN(planes * 4)) if down else None
+
+    def forward(self, x):
+        s, b = self.bn1.folded()
+        out = ops.conv2d(x, self.conv1.weight, row_scale=s, shift=b, act=ACT_RELU)
+        s, b = self.bn2.folded()
+        out = ops.conv2d(out, self.conv2.weight, stride=self.stride, pad=1, row_scale=s, shift=b, act=ACT_RELU)
+        idt = x
+        if self.downsample is not None:
+            s, b = self.downsample[1].folded()
+            idt = ops.conv2d(x, self.downsample[0].weight, stride=self.stride, row_scale=s, shift=b)
+        s, b = self.bn3.folded()
+        return ops.conv2d(out, self.conv3.weight, row_scale=s, shift=b, residual=idt, act=ACT_RELU)
+
+
+class ResNetBody(nn.Module):
+    """conv1 .. layer4 (keys as torchvision's IntermediateLayerGetter keeps them, backbone.py:65-69)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1, self.bn1 = Conv(3, 64, 7), FrozenBN(64)
+        inpl = 64
+        for li, (planes, blocks, stride) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)), start=1):
+            layer = [Bottleneck(inpl, planes, stride, True)]
+            inpl = planes * 4
+            layer += [Bottleneck(inpl, planes, 1, False) for _ in range(1, blocks)]
+            setattr(self, f"layer{li}", nn.Sequential(*layer))
+        for m in self.modules():
+            if isinstance(m, Conv):
+                nn.init.normal_(m.weight, std=math.sqrt(2.0 / (m.weight.shape[0] * m.weight.shape[1] * m.weight.shape[2])))
+
+    def forward(self, x):
+        s, b = self.bn1.folded()
+        x = ops.conv2d(x, self.conv1.weight, stride=2, pad=3, row_scale=s, shift=b, act=ACT_RELU)
+        x = to_pixel_major(F.max_pool2d(to_nchw(x), 3, 2, 1))
+        feats = []
+        for li in range(1, 5):
+            x = getattr(self, f"layer{li}")(x)
+            feats.append(x)
+        return feats
+
+
+class BackboneBase(nn.Module):
+    def __init__(self, train_backbone=True):
+        super().__init__()
+        self.body = ResNetBody()
+        for name, p in self.body.named_parameters():            # backbone.py:62-64
+            if not train_backbone or ("layer2" not in name and "layer3" not in name and "layer4" not in name):
+                p.requires_grad_(False)
+        self.num_channels = 2048
+
+
+class PosHolder(nn.Module):
+    """Parameter-free slot '1' of the reference's Joiner (keeps module indices aligned)."""
+
+    def __init__(self, num_pos_feats):
+        super().__init__()
+        self.num_pos_feats = num_pos_feats
+
+
+class Joiner(nn.Module):
+    """backbone.0 = body holder, backbone.1 = sine position embedding (backbone.py:101-110)."""
+
+    def __init__(self, hidden_dim, train_backbone=True):
+        super().__init__()
+        self.add_module("0", BackboneBase(train_backbone))
+        self.add_module("1", PosHolder(hidden_dim // 2))
+        self.num_channels = 2048
+
+    def forward(self, images_pm, pad_mask):
+        feats = self._modules["0"].body(images_pm)
+        masks = [F.interpolate(pad_mask[None].float(), size=f.shape[1:3]).to(torch.bool)[0] for f in feats]
+        return feats, masks
+
+
+# ------------------------------------------------------------------------------------ DETR branch
+class MultiheadAttention(nn.Module):
+    """Packed in-proj attention, /root/reference/src/models/multi_head_attention.py:117-380, batch-major."""
+
+    def __init__(self, dim, heads, dropout):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * dim, dim))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * dim))
+        self.out_proj = Linear(dim, dim)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        self.dim, self.heads, self.dropout = dim, heads, dropout
+
+    def forward(self, query, key, value, key_padding_mask=None):
+        B, L, E = query.shape
+        S = key.shape[1]
+        H, hd = self.heads, E // self.heads
+        W, b = self.in_proj_weight, self.in_proj_bias
+        if query is key:
+            qk = ops.linear(query, W[: 2 * E], b[: 2 * E])
+            q, k = qk[..., :E], qk[..., E:]
+        else:
+            q = ops.linear(query, W[:E], b[:E])
+            k = ops.linear(key, W[E: 2 * E], b[E: 2 * E])
+        v = ops.linear(value, W[2 * E:], b[2 * E:])
+        q = (q * (float(hd) ** -0.5)).reshape(B, L, H, hd).transpose(1, 2)
+        k = k.reshape(B, S, H, hd).transpose(1, 2)
+        v = v.reshape(B, S, H, hd).transpose(1, 2)
+        att = q @ k.transpose(-2, -1)
+        if key_padding_mask is not None:
+            att = att.masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
+        att = ops.softmax_lastdim(att)
+        att = F.dropout(att, self.dropout, self.training)
+        out = (att @ v).transpose(1, 2).reshape(B, L, E)
+        return self.out_proj(out)
+
+
+class EncoderLayer(nn.Module):
+    def __init__(self, d, heads, ff, dropout):
+        super().__init__()
+        self.self_attn = MultiheadAttention(d, heads, dropout)
+        self.linear1, self.linear2 = Linear(d, ff), Linear(ff, d)
+        self.norm1, self.norm2 = LayerNorm(d), LayerNorm(d)
+        self.p = dropout
+
+    def forward(self, x, pos, kpm):
+        """TransformerEncoderLayer.forward_post, /root/reference/src/models/transformer.py:149-162."""
+        qk = x + pos
+        x = self.norm1(x + F.dropout(self.self_attn(qk, qk, x, kpm), self.p, self.training))
+        ff = self.linear2(F.dropout(self.linear1(x, ACT_RELU), self.p, self.training))
+        return self.norm2(x + F.dropout(ff, self.p, self.training))
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, d, heads, ff, dropout):
+        super().__init__()
+        self.self_attn = MultiheadAttention(d, heads, dropout)
+        self.multihead_attn = MultiheadAttention(d, heads, dropout)
+        self.linear1, self.linear2 = Linear(d, ff), Linear(ff, d)
+        self.norm1, self.norm2, self.norm3 = LayerNorm(d), LayerNorm(d), LayerNorm(d)
+        self.p = dropout
+
+    def forward(self, tgt, memory, mem_pos, pos, qpos, kpm):
+        """TransformerDecoderLayer.forward_post, /root/reference/src/models/transformer.py:212-233."""
+        qk = tgt + qpos
+        tgt = self.norm1(tgt + F.dropout(self.self_attn(qk, qk, tgt), self.p, self.training))
+        t2 = self.multihead_attn(tgt + qpos, mem_pos, memory, kpm)
+        tgt = self.norm2(tgt + F.dropout(t2, self.p, self.training))
+        ff = self.linear2(F.dropout(self.linear1(tgt, ACT_RELU), self.p, self.training))
+        return self.norm3(tgt + F.dropout(ff, self.p, self.training))
+
+
+class Stack(nn.Module):
+    def __init__(self, layers, norm=None):
+        super().__init__()
+        self.layers = nn.ModuleList(layers)
+        if norm is not None:
+            self.norm = norm
+
+
+class Transformer(nn.Module):
+    """DETR encoder/decoder, /root/reference/src/models/transformer.py:18-125 (post-norm)."""
+
+    def __init__(self, d=256, heads=8, enc=6, dec=6, ff=2048, dropout=0.1):
+        super().__init__()
+        self.encoder = Stack([EncoderLayer(d, heads, ff, dropout) for _ in range(enc)])
+        self.decoder = Stack([DecoderLayer(d, heads, ff, dropout) for _ in range(dec)], LayerNorm(d))
+        self.d_model, self.nhead = d, heads
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, src, mask, query_embed, pos):
+        """src, pos (B,h,w,d); mask (B,h,w) -> hs (layers, B, Q, d)."""
+        B = src.shape[0]
+        x = src.flatten(1, 2)
+        pos = pos.flatten(1, 2).to(x.dtype)
+        kpm = mask.flatten(1)
+        for layer in self.encoder.layers:
+            x = layer(x, pos, kpm)
+        memory, mem_pos = x, x + pos
+        qpos = query_embed.to(x.dtype).unsqueeze(0).expand(B, -1, -1)
+        tgt = torch.zeros_like(qpos)
+        inter = []
+        for layer in self.decoder.layers:
+            tgt = layer(tgt, memory, mem_pos, pos, qpos, kpm)
+            inter.append(self.decoder.norm(tgt))
+        return torch.stack(inter)
+
+
+class MLP(nn.Module):
+    """glassrgbd.py:30-42."""
+
+    def __init__(self, cin, hidden, cout, n):
+        super().__init__()
+        dims = [cin] + [hidden] * (n - 1) + [cout]
+        self.layers = nn.ModuleList(Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+        self.n = n
+
+    def forward(self, x):
+        for i, l in enumerate(self.layers):
+            x = l(x, ACT_RELU if i < self.n - 1 else ACT_NONE)
+        return x
+
+
+# ------------------------------------------------------------------------------------ window stages
+def window_partition(x):
+    B, H, W, C = x.shape
+    x = x.view(B, H // WS, WS, W // WS, WS, C)
+    return x.permute(0, 1, 3, 2, 4, 5).reshape(-1, WS * WS, C)
+
+
+def window_reverse(win, H, W):
+    B = win.shape[0] // ((H // WS) * (W // WS))
+    x = win.view(B, H // WS, W // WS, WS, WS, -1)
+    return x.permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, -1)
+
+
+_MASK_CACHE = {}
+
+
+def shift_mask(Hp, Wp, device, dtype):
+    """SW-MSA mask with fill -100 (multiscale_transformerr.py:937-955); a pure function of (Hp, Wp)."""
+    key = (Hp, Wp, str(device), dtype)
+    if key not in _MASK_CACHE:
+        shift = WS // 2
+        img = torch.zeros(1, Hp, Wp, 1)
+        cnt = 0
+        for h in (slice(0, -WS), slice(-WS, -shift), slice(-shift, None)):
+            for w in (slice(0, -WS), slice(-WS, -shift), slice(-shift, None)):
+                img[:, h, w, :] = cnt
+                cnt += 1
+        mw = window_partition(img).view(-1, WS * WS)
+        am = mw.unsqueeze(1) - mw.unsqueeze(2)
+        am = am.masked_fill(am != 0, -100.0).masked_fill(am == 0, 0.0)
+        _MASK_CACHE[key] = am.to(device=device, dtype=dtype)
+    return _MASK_CACHE[key]
+
+
+def relative_position_index():
+    coords = torch.stack(torch.meshgrid(torch.arange(WS), torch.arange(WS), indexing="ij")).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += WS - 1
+    rel[:, :, 1] += WS - 1
+    rel[:, :, 0] *= 2 * WS - 1
+    return rel.sum(-1)
+
+
+class WindowAttnBase(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+        self.scale = (dim // HEADS) ** -0.5
+        self.diff_mu = nn.Parameter(torch.randn(1, 1, dim))
+        self.diff_logsigma = nn.Parameter(torch.zeros(1, 1, dim))
+        nn.init.xavier_uniform_(self.diff_logsigma)
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * WS - 1) ** 2, HEADS))
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+        self.register_buffer("relative_position_index", relative_position_index())
+        self.qkv = Linear(dim, dim * 3)
+        self.proj = Linear(dim, dim)
+
+    def qkv_heads(self, xw):
+        B_, N, C = xw.shape
+        qkv = self.qkv(xw).reshape(B_, N, 3, HEADS, C // HEADS).permute(2, 0, 3, 1, 4)
+        return qkv[0], qkv[1], qkv[2]
+
+    def attend(self, scores, v, mask):
+        """+ relative position bias (+ shift mask), softmax, @v, proj (multiscale_transformerr.py:313-329)."""
+        B_, nH, N, _ = scores.shape
+        bias = self.relative_position_bias_table[self.relative_position_index.view(-1)].view(N, N, -1)
+        att = scores + bias.permute(2, 0, 1).to(scores.dtype).unsqueeze(0)
+        if mask is not None:
+            nW = mask.shape[0]
+            att = (att.view(B_ // nW, nW, nH, N, N) + mask.unsqueeze(1).unsqueeze(0)).view(-1, nH, N, N)
+        att = ops.softmax_lastdim(att)
+        x = (att @ v).transpose(1, 2).reshape(B_, N, -1)
+        return self.proj(x)
+
+
+class WindowAttention(WindowAttnBase):
+    """Line-point-guided window attention of the 1/32 stage (multiscale_transformerr.py:202-332)."""
+
+    def __init__(self, dim):
+        super().__init__(dim)
+        self.ref_qk = Linear(dim, dim * 2)
+        self.ref_attn_diffusion = Conv(HEADS, HEADS, 3, bias=True)
+
+    def forward(self, xw, x_ref, mask):
+        B_, N, C = xw.shape
+        hd = C // HEADS
+        q, k, v = self.qkv_heads(xw)
+        rqk = self.ref_qk(x_ref)
+        rB, nrf = rqk.shape[0], rqk.shape[1]
+        nwin = B_ // rB
+        ref_q = self.diff_mu.to(rqk.dtype) + self.diff_logsigma.exp().to(rqk.dtype) * rqk[..., :C]
+        ref_k = ref_q.reshape(rB, nrf, HEADS, hd).permute(0, 2, 1, 3)            # (rB, nH, nrf, hd)
+        ref_v = rqk[..., C:].reshape(rB, nrf, HEADS, hd).permute(0, 2, 1, 3)
+        q = (q * self.scale).reshape(rB, nwin, HEADS, N, hd)
+        ra = torch.einsum("bwhnd,bhrd->bwnrh", q, ref_k).reshape(rB, nwin * N, nrf, HEADS)   # pixel-major (B, nWin*N, nrf, heads)
+        for _ in range(3):                                                        # :299-302
+            upd = ops.conv2d(ra.contiguous(), self.ref_attn_diffusion.weight, self.ref_attn_diffusion.bias, pad=1)
+            uf = upd.float()
+            mu = uf.mean(dim=(1, 2), keepdim=True)
+            var = uf.var(dim=(1, 2), keepdim=True, unbiased=False)
+            ra = ra + F.gelu((uf - mu) * torch.rsqrt(var + 1e-5)).to(ra.dtype)
+        ra = ra.reshape(rB, nwin, N, nrf, HEADS).permute(0, 1, 4, 2, 3)          # (rB, nwin, nH, N, nrf)
+        att = ops.softmax_lastdim(ra)
+        q_new = torch.einsum("bwhnr,bhrd->bwhnd", att, ref_v).reshape(B_, HEADS, N, hd) * self.scale
+        return self.attend(q_new @ k.transpose(-2, -1), v, mask)
+
+
+class WindowClassAttention(WindowAttnBase):
+    """Window attention + depth/seg class-token cross attention (multiscale_transformerr.py:375-580,
+    group_attention=False).  border_* and proj_seg exist for state-dict parity and never get a gradient."""
+
+    def __init__(self, dim, tdim):
+        super().__init__(dim)
+        self.border_mu = nn.Parameter(torch.randn(1, 1, dim))
+        self.border_logsigma = nn.Parameter(torch.zeros(1, 1, dim))
+        self.cls_dth_q, self.cls_seg_q = Linear(tdim, tdim), Linear(tdim, tdim)
+        self.global_k, self.global_v = Linear(dim + 2 * tdim, dim + 2 * tdim), Linear(dim + 2 * tdim, dim + 2 * tdim)
+        self.proj_dth, self.proj_seg = Linear(tdim, tdim), Linear(tdim, tdim)
+
+    def forward(self, xw, dtok, stok, mask):
+        B_, N, C = xw.shape
+        q, k, v = self.qkv_heads(xw)
+        x = self.attend((q * self.scale) @ k.transpose(-2, -1), v, mask)
+        tdim = dtok.shape[-1]
+        tx = torch.cat([x, dtok, stok], dim=-1)
+        tC = tx.shape[-1]
+        tk = self.global_k(tx).reshape(B_, N, HEADS, tC // HEADS).permute(0, 2, 1, 3)
+        tv = self.global_v(tx).reshape(B_, N, HEADS, tC // HEADS).permute(0, 2, 1, 3)
+
+        def tok(q_lin, t):
+            qh = q_lin(t).reshape(B_, N, HEADS, tdim // HEADS).permute(0, 2, 3, 1) * self.scale   # (B_, nH, 4, N)
+            a = ops.softmax_lastdim(qh @ tk)                                                       # (B_, nH, 4, tC/16)
+            o = (a @ tv.transpose(-2, -1)).reshape(B_, -1, N).permute(0, 2, 1)
+            return self.proj_dth(o)                                                                # :572,578 (both!)
+
+        return x, tok(self.cls_dth_q, dtok), tok(self.cls_seg_q, stok)
+
+
+def pad_roll(t, H, W, shift):
+    pr, pb = (WS - W % WS) % WS, (WS - H % WS) % WS
+    if pr or pb:
+        t = F.pad(t, (0, 0, 0, pr, 0, pb))
+    if shift:
+        t = torch.roll(t, shifts=(-shift, -shift), dims=(1, 2))
+    return t, H + pb, W + pr
+
+
+def unroll_crop(win, H, W, Hp, Wp, shift):
+    t = window_reverse(win, Hp, Wp)
+    if shift:
+        t = torch.roll(t, shifts=(shift, shift), dims=(1, 2))
+    return t[:, :H, :W, :]
+
+
+class SwinBlock(nn.Module):
+    """SwinTransformerBlock.forward, multiscale_transformerr.py:646-788."""
+
+    def __init__(self, dim, shift, tdim=None):
+        super().__init__()
+        self.shift = shift
+        self.norm1 = LayerNorm(dim)
+        self.attn = WindowAttention(dim) if tdim is None else WindowClassAttention(dim, tdim)
+        self.norm2 = LayerNorm(dim)
+        self.mlp = Mlp(dim, dim * 2)
+        if tdim is not None:
+            self.norm_seg1, self.norm_depth1 = LayerNorm(tdim), LayerNorm(tdim)
+            self.mlp_seg, self.norm_seg2 = Mlp(tdim, tdim * 2), LayerNorm(tdim)
+            self.mlp_depth, self.norm_depth2 = Mlp(tdim, tdim * 2), LayerNorm(tdim)
+
+    def forward(self, x, H, W, ref_coors=None, ref_pos=None, dtok=None, stok=None):
+        B, L, C = x.shape
+        shift = self.shift
+        sx, Hp, Wp = pad_roll(self.norm1(x).view(B, H, W, C), H, W, shift)
+        mask = shift_mask(Hp, Wp, x.device, x.dtype) if shift else None
+        if dtok is None:
+            if shift:                                                             # :678-686
+                rc = torch.stack([ref_coors[..., 0] - (shift / (Wp - 1)) * 2,
+                                  ref_coors[..., 1] - (shift / (Hp - 1)) * 2], dim=-1)
+                rc = torch.where(rc < -1, -2 - rc, rc)
+                rpos = torch.roll(ref_pos, shifts=(-shift, -shift), dims=(1, 2))
+            else:
+                rc, rpos = ref_coors, ref_pos
+            x_ref = F.grid_sample(to_nchw(sx).float(), rc, mode="nearest", align_corners=False)
+            x_ref = x_ref + F.grid_sample(to_nchw(rpos), rc, mode="nearest", align_corners=False)
+            x_ref = x_ref.reshape(B, C, -1).permute(0, 2, 1).to(x.dtype)
+            aw = self.attn(window_partition(sx), x_ref, mask)
+        else:
+            tC = dtok.shape[-1]
+            dn, _, _ = pad_roll(self.norm_depth1(dtok).view(B, H, W, tC), H, W, shift)
+            sn, _, _ = pad_roll(self.norm_seg1(stok).view(B, H, W, tC), H, W, shift)
+            aw, dw, sw = self.attn(window_partition(sx), window_partition(dn), window_partition(sn), mask)
+        x = x + unroll_crop(aw, H, W, Hp, Wp, shift).reshape(B, H * W, C)
+        x = x + self.mlp(self.norm2(x))
+        if dtok is None:
+            return x, None, None
+        d = dtok + unroll_crop(dw, H, W, Hp, Wp, shift).reshape(B, H * W, tC)
+        d = d + self.mlp_depth(self.norm_depth2(d))
+        s = stok + unroll_crop(sw, H, W, Hp, Wp, shift).reshape(B, H * W, tC)
+        s = s + self.mlp_seg(self.norm_seg2(s))
+        return x, d, s
+
+
+class BasicLayer(nn.Module):
+    def __init__(self, dim, depth, tdim=None, pre_class_pred=False):
+        super().__init__()
+        self.blocks = nn.ModuleList(SwinBlock(dim, 0 if i % 2 == 0 else WS // 2, tdim) for i in range(depth))
+        if pre_class_pred:      # built by the reference (multiscale_transformerr.py:911-915), never executed
+            self.pre_depth_pred = Seq(_0=Linear(dim + tdim, tdim), _1=Linear(tdim, 1))
+
+    def forward(self, x, H, W, **kw):
+        d, s = kw.pop("dtok", None), kw.pop("stok", None)
+        for blk in self.blocks:
+            x, d, s = blk(x, H, W, dtok=d, stok=s, **kw)
+        return x, d, s
+
+
+# ------------------------------------------------------------------------------------ pyramid heads
+class ConvLn(nn.Module):
+    """conv (no bias) -> LayerNorm over channels [-> GELU], points_sample.py:12-25."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.conv = Conv(cin, cout, k)
+        self.layer_norm = LayerNorm(cout)
+        self.pad = k // 2
+
+    def forward(self, x, gelu=False):
+        return self.layer_norm(ops.conv2d(x, self.conv.weight, pad=self.pad), gelu)
+
+
+class PyrBlock(nn.Module):
+    """BasicBlock, points_sample.py:27-43 (no downsample at these widths)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.conv1 = Seq(_0=ConvLn(c, c, 3))
+        self.conv2 = ConvLn(c, c, 3)
+
+    def forward(self, x):
+        return self.conv2(self.conv1[0](x, True)) + x
+
+
+class PyramidLayer(nn.Module):
+    """PyramidLayer, points_sample.py:45-125; layer4 is constructed (state dict) but never called."""
+
+    def __init__(self, c, pools=(16, 8, 4, 2)):
+        super().__init__()
+        self.pools = pools
+        self.firstconv = Seq(_0=ConvLn(c, c, 3), _2=ConvLn(c, 2 * c, 3))
+        c2 = 2 * c
+        self.layer1 = nn.Sequential(PyrBlock(c2))
+        self.layer2 = nn.Sequential(PyrBlock(c2), PyrBlock(c2))
+        self.layer3 = nn.Sequential(PyrBlock(c2), PyrBlock(c2))
+        self.layer4 = nn.Sequential(PyrBlock(c2))
+        for i in range(1, 5):
+            setattr(self, f"branch{i}", Seq(_1=ConvLn(c2, c2, 3)))
+        self.lastconv = Seq(_0=ConvLn(5 * c2, 2 * c2, 3), _2=Conv(2 * c2, c, 1))
+
+    def forward(self, x):
+        x = self.firstconv[2](self.firstconv[0](x, True), True)
+        x = self.layer3(self.layer2(self.layer1(x)))
+        B, H, W, C = x.shape
+        if H < self.pools[0] or W < self.pools[0]:
+            x = F.pad(x, (0, 0, 0, max(self.pools[0] - W, 0), 0, max(self.pools[0] - H, 0)))
+        size = x.shape[1:3]
+        outs = [x]
+        xn = to_nchw(x)
+        for i, k in enumerate(self.pools, start=1):
+            y = getattr(self, f"branch{i}")[1](to_pixel_major(F.avg_pool2d(xn, k, k)), True)
+            outs.append(to_pixel_major(F.interpolate(to_nchw(y), size=size, mode="bilinear", align_corners=True)))
+        x = self.lastconv[0](torch.cat(outs, dim=-1), True)
+        return ops.conv2d(x, self.lastconv[2].weight)
+
+
+class PointBasedPred(nn.Module):
+    """PointBasedPred.forward, points_sample.py:257-280."""
+
+    def __init__(self, dim, tdim, point_num):
+        super().__init__()
+        self.dim = dim
+        self.pre_proj = Linear(dim + tdim, dim)
+        self.refer_proj = Linear(dim, dim * 2)
+        self.pyramid = PyramidLayer(point_num)
+
+    def forward(self, x, dtok, pre_depth, coords, H, W, pos):
+        B = x.shape[0]
+        xg_xr = self.refer_proj(self.pre_proj(torch.cat([x, dtok], dim=-1)))
+        xg, xr = xg_xr[..., : self.dim], xg_xr[..., self.dim:]
+        xr_map = to_nchw(xr.reshape(B, H, W, self.dim))
+        refer = F.grid_sample(xr_map.float(), coords, align_corners=False) + \
+            F.grid_sample(to_nchw(pos), coords, align_corners=False)                     # (B, dim, S, 1)
+        anchor = F.grid_sample(pre_depth.float(), coords, align_corners=False)          # (B, 1, S, 1)
+        rg = torch.bmm(xg, refer.flatten(2).to(xg.dtype)) * (self.dim ** -2)            # (B, HW, S) = pixel-major map
+        # NB: when H or W < 16 the pyramid zero-pads its map and the reference keeps the padded size (:94-125)
+        att = ops.softmax_lastdim(self.pyramid(rg.view(B, H, W, -1)))
+        pred = (att.float() * anchor.view(B, 1, 1, -1)).sum(dim=-1, keepdim=True)
+        return pred.permute(0, 3, 1, 2)                                                   # (B,1,H',W') fp32
+
+
+@torch.no_grad()
+def certain_sample(pred_small, pred_large, interval, sample_num, min_depth):
+    """CertainSample.forward, points_sample.py:291-364: interval histogram decides HOW MANY points,
+    every top-k is over the whole variance map; integer coordinates, no gradient."""
+    B, _, H, W = pred_large.shape
+    small = F.interpolate(pred_small, size=(H, W), mode="bilinear", align_corners=True)
+    var = ((small - pred_large) ** 2).flatten(1)
+    edges = torch.tensor([min_depth] + list(interval) + [1.0], device=pred_large.device, dtype=pred_large.dtype)
+    flat = pred_large.flatten(1)
+    n_i = ((flat[:, None, :] >= edges[:-1, None]) & (flat[:, None, :] < edges[1:, None])).sum(-1)       # (B, I)
+    k_i = torch.minimum(torch.floor((n_i / (H * W)) * sample_num), n_i.to(torch.float32)).long().tolist()   # one host sync
+    order = torch.argsort(var, dim=1, descending=True, stable=True)                                       # lowest index wins ties
+    outs = []
+    for b in range(B):
+        groups = [order[b, :k].sort()[0] for k in k_i[b] if k > 0]
+        counts = [int(g.numel()) for g in groups]
+        already = sum(counts)
+        if groups:
+            cat = torch.cat(groups)
+            remain = sample_num - already
+        else:
+            cat = order[b, :sample_num].sort()[0]
+            remain = 0
+        if remain > 0 and remain >= already:
+            times = remain // already + 1
+            cat = cat.repeat(times)
+            remain = sample_num - already * times
+        if remain > 0:
+            cat = torch.cat([cat, cat[-remain:]])
+        if remain < 0:
+            mid = max(range(len(counts)), key=lambda i: (counts[i], -i))
+            groups[mid] = groups[mid][:remain]
+            cat = torch.cat(groups)
+        outs.append(cat)
+    idx = torch.stack(outs)
+    col, row = (idx % W).float(), torch.div(idx, W, rounding_mode="floor").float()
+    return torch.stack([(col / W) * 2 - 1, (row / H) * 2 - 1], dim=-1)[:, :, None]
+
+
+# ------------------------------------------------------------------------------------ dense encoder
+class ConvA(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = Conv(cin, cout, 3, bias=True)
+
+    def forward(self, x):
+        return ops.conv2d(x, self.conv.weight, self.conv.bias, pad=1, act=ACT_GELU)
+
+
+def sig_head(x, seq):
+    return ops.linear(seq[0](x), seq[1].weight, seq[1].bias, ACT_SIGMOID)
+
+
+def nearest_up_tokens(tok, Hs, Ws, size):
+    """(B, Hs*Ws, C) -> nearest-upsampled (B, H*W, C)."""
+    B, _, C = tok.shape
+    t = F.interpolate(to_nchw(tok.view(B, Hs, Ws, C)), size=size, mode="nearest")
+    return to_pixel_major(t).view(B, size[0] * size[1], C)
+
+
+class ReferTransformer(nn.Module):
+    """ReferTransformer, multiscale_transformerr.py:1025-1319 (flags with_line, not with_line_depth)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        D, T = cfg.dense_trans_dim, cfg.class_token_dim
+        self.cfg = cfg
+        self.depth_token = nn.Parameter(torch.zeros(1, 1, T))
+        self.seg_token = nn.Parameter(torch.zeros(1, 1, T))
+        nn.init.trunc_normal_(self.depth_token, std=0.02)
+        nn.init.trunc_normal_(self.seg_token, std=0.02)
+        self.dense_transformer = BasicLayer(D, cfg.dense_trans_layers[0])
+        self.depth_pred32 = Seq(_0=Linear(D, T), _1=Linear(T, 1))
+        self.proj_class1, self.proj_backbn1 = Linear(D, D // 2), ConvA(1024, D // 2)
+        self.class_transformer1 = BasicLayer(D // 2, cfg.class_trans_layers[0], T, pre_class_pred=True)
+        self.depth_pred16 = Seq(_0=Linear(D // 2 + T, T), _1=Linear(T, 1))
+        self.point_based_pred1 = PointBasedPred(D // 4, T, cfg.interval_sample_num[0])
+        self.old_depth_token_proj8, self.old_seg_token_proj8 = MlpNorm(T, 2 * T), MlpNorm(T, 2 * T)
+        self.proj_class2, self.proj_backbn2 = Linear(D // 2, D // 4), ConvA(512, D // 4)
+        self.class_transformer2 = BasicLayer(D // 4, cfg.class_trans_layers[1], T)
+        self.point_based_pred2 = PointBasedPred(D // 8, T, cfg.interval_sample_num[1])
+        self.old_depth_token_proj4, self.old_seg_token_proj4 = MlpNorm(T, 2 * T), MlpNorm(T, 2 * T)
+        self.proj_class3, self.proj_backbn3 = Linear(D // 4, D // 8), ConvA(256, D // 8)
+        self.class_transformer3 = BasicLayer(D // 8, cfg.class_trans_layers[2], T)
+        self.depth_pred4 = Seq(_0=Linear(D // 8 + T, T), _1=Linear(T, 1))      # never executed (:1288-1292)
+
+    def forward(self, top, feats, masks, pred_lines, pred_logits, taps=None):
+        cfg = self.cfg
+        B, H, W, C = top.shape
+        dt = top.dtype
+        ids = torch.topk(pred_logits[:, :, 0].float(), cfg.num_ref, dim=-1)[1]                  # :1166 (raw logit)
+        pts = torch.gather(pred_lines.float(), 1, ids[..., None].expand(-1, -1, pred_lines.shape[-1]))
+        pts = (pts.reshape(B, cfg.num_ref, -1, 2) * 2 - 1.0)[:, :, :2]                          # :1175-1179
+        pos = pos_sine(masks[3], cfg.dense_trans_dim // 2, False)
+        x, _, _ = self.dense_transformer(top.flatten(1, 2), H, W, ref_coors=pts, ref_pos=pos)
+        depth0 = sig_head(x, self.depth_pred32).float().view(B, 1, H, W)
+
+        def stage(x_prev, Hs, Ws, feat, proj, proj_bb):
+            Hn, Wn = feat.shape[1:3]
+            up = nearest_up_tokens(x_prev, Hs, Ws, (Hn, Wn))
+            return proj(up) + proj_bb(feat).flatten(1, 2), Hn, Wn
+
+        x1, H1, W1 = stage(x, H, W, feats[2], self.proj_class1, self.proj_backbn1)
+        dtok = self.depth_token.to(dt).expand(B, H1 * W1, -1)
+        stok = self.seg_token.to(dt).expand(B, H1 * W1, -1)
+        x1, dtok, stok = self.class_transformer1(x1, H1, W1, dtok=dtok, stok=stok)
+        depth1 = sig_head(torch.cat([x1, dtok], dim=-1), self.depth_pred16).float().view(B, 1, H1, W1)
+        md = cfg.min_depth_eval / cfg.max_depth_eval
+        pts1 = certain_sample(depth0, depth1, cfg.depth_interval, cfg.interval_sample_num[0], md)
+        if taps is not None:
+            taps["points1"] = pts1
+            pts1 = taps.get("force_points1", pts1)     # teacher forcing for parity tests (identical index operands)
+
+        x2, H2, W2 = stage(x1, H1, W1, feats[1], self.proj_class2, self.proj_backbn2)
+        pos2 = pos_sine(masks[1], cfg.dense_trans_dim // 8, False)
+        dtok = self.old_depth_token_proj8(nearest_up_tokens(dtok, H1, W1, (H2, W2)))
+        stok = self.old_seg_token_proj8(nearest_up_tokens(stok, H1, W1, (H2, W2)))
+        x2, dtok, stok = self.class_transformer2(x2, H2, W2, dtok=dtok, stok=stok)
+        depth2 = self.point_based_pred1(x2, dtok, depth1, pts1, H2, W2, pos2)
+        pts2 = certain_sample(depth1, depth2, cfg.depth_interval, cfg.interval_sample_num[1], md)
+        if taps is not None:
+            taps["points2"] = pts2
+            pts2 = taps.get("force_points2", pts2)
+
+        x3, H3, W3 = stage(x2, H2, W2, feats[0], self.proj_class3, self.proj_backbn3)
+        pos3 = pos_sine(masks[0], cfg.dense_trans_dim // 16, False)
+        dtok = self.old_depth_token_proj4(nearest_up_tokens(dtok, H2, W2, (H3, W3)))
+        stok = self.old_seg_token_proj4(nearest_up_tokens(stok, H2, W2, (H3, W3)))
+        x3, dtok, stok = self.class_transformer3(x3, H3, W3, dtok=dtok, stok=stok)
+        depth3 = self.point_based_pred2(x3, dtok, depth2, pts2, H3, W3, pos3)
+        if taps is not None:
+            taps["topk_ids"] = ids
+        as_map = lambda t: t.view(B, H3, W3, -1)
+        return as_map(x3), as_map(dtok), as_map(stok), [depth1, depth2, depth3]
+
+
+# ------------------------------------------------------------------------------------ full-res decoder
+class UpConv(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = Conv(cin, cout, 3)
+
+    def forward(self, x, size):
+        """nearest upsample fused into the conv's gather, ELU in its epilogue (dense_upsample.py:82-90)."""
+        return ops.conv2d(x, self.conv.weight, pad=1, act=ACT_ELU, upsample_to=size)
+
+
+class DensePrediction(nn.Module):
+    """DensePrediction.forward, /root/reference/src/models/dense_upsample.py:160-182."""
+
+    def __init__(self, max_depth, tdim, feat=64):
+        super().__init__()
+        self.max_depth = max_depth
+        self.depth_token_fuse = Mlp(feat + 1 + tdim, None, tdim)
+        self.seg_token_fuse = Mlp(feat + tdim, None, tdim)
+        for tag in ("depth", "seg"):
+            setattr(self, f"upconv1_{tag}", UpConv(tdim, tdim))
+            setattr(self, f"norm_{tag}", LayerNorm(tdim))
+            setattr(self, f"conv1_{tag}", Seq(_0=Conv(tdim, tdim, 3)))
+            setattr(self, f"upconv2_{tag}", UpConv(tdim, tdim // 2))
+            setattr(self, f"conv2_{tag}", Seq(_0=Conv(tdim // 2, tdim // 2, 3)))
+        self.get_depth = Seq(_0=Conv(tdim // 2, 1, 3))
+        self.get_seg = Conv(tdim // 2, 2, 3)
+
+    def branch(self, fuse_in, tag, fuse, size):
+        B, H, W, _ = fuse_in.shape
+        f = fuse(fuse_in)
+        u1 = getattr(self, f"norm_{tag}")(getattr(self, f"upconv1_{tag}")(f, (2 * H, 2 * W)))
+        c1 = ops.conv2d(u1, getattr(self, f"conv1_{tag}")[0].weight, pad=1, act=ACT_ELU)
+        u2 = getattr(self, f"upconv2_{tag}")(c1, size)
+        return ops.conv2d(u2, getattr(self, f"conv2_{tag}")[0].weight, pad=1, act=ACT_ELU)
+
+    def forward(self, feat, depth3, dtok, stok, size):
+        B, H, W, _ = feat.shape
+        d3 = depth3.view(B, H, W, 1).to(feat.dtype)
+        d = self.branch(torch.cat([feat, d3, dtok], dim=-1), "depth", self.depth_token_fuse, size)
+        depth = ops.conv2d(d, self.get_depth[0].weight, pad=1, act=ACT_SIGMOID, act_scale=float(self.max_depth))
+        s = self.branch(torch.cat([feat, stok], dim=-1), "seg", self.seg_token_fuse, size)
+        seg = ops.conv2d(s, self.get_seg.weight, pad=1)
+        return depth.float().view(B, 1, size[0], size[1]), seg.permute(0, 3, 1, 2)
+
+
+# ------------------------------------------------------------------------------------ assembly
+class GlassRGBD(nn.Module):
+    """GlassRGBD, /root/reference/src/models/glassrgbd.py:44-131 (with_line, with_center, with_dense)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.num_queries = cfg.num_queries
+        self.transformer = Transformer(cfg.hidden_dim, cfg.nheads, cfg.enc_layers, cfg.dec_layers,
+                                       cfg.dim_feedforward, cfg.dropout)
+        self.class_embed = Linear(cfg.hidden_dim, 2)
+        self.query_embed = nn.Embedding(cfg.num_queries, cfg.hidden_dim)
+        self.input_proj = Conv(2048, cfg.hidden_dim, 1, bias=True)
+        self.lines_embed = MLP(cfg.hidden_dim, cfg.hidden_dim, 6, 3)
+        self.backbone = Joiner(cfg.hidden_dim, cfg.lr_backbone > 0)
+        self.aux_loss = cfg.aux_loss
+        self.dense_input_proj = Conv(2048, 512, 1, bias=True)
+        self.dense_encoder = ReferTransformer(cfg)
+        self.depth_decoder = DensePrediction(cfg.max_depth, cfg.class_token_dim)
+        self.compute_dtype = torch.float32
+
+    def forward(self, samples, reflc_points=None, reflc_mat=None, img_name=None, taps=None):
+        if isinstance(samples, (list, torch.Tensor)):
+            samples = nested_tensor_from_tensor_list(samples)
+        images, pad_mask = samples.decompose()
+        H, W = images.shape[-2:]
+        x = to_pixel_major(images).to(self.compute_dtype)
+        feats, masks = self.backbone(x, pad_mask)
+        src, mask = feats[3], masks[3]
+        pos = pos_sine(mask, self.cfg.hidden_dim // 2, True)
+        hs = self.transformer(ops.conv2d(src, self.input_proj.weight, self.input_proj.bias), mask,
+                              self.query_embed.weight, pos)
+        logits = self.class_embed(hs).float()
+        lines = torch.sigmoid(self.lines_embed(hs).float())
+        out = {"pred_logits": logits[-1], "pred_lines": lines[-1]}
+        if self.aux_loss:
+            out["aux_outputs"] = [{"pred_logits": a, "pred_lines": b} for a, b in zip(logits[:-1], lines[:-1])]
+        dense_in = ops.conv2d(src, self.dense_input_proj.weight, self.dense_input_proj.bias)
+        feat4, dtok, stok, depths = self.dense_encoder(dense_in, feats, masks, out["pred_lines"], out["pred_logits"], taps)
+        depth, seg = self.depth_decoder(feat4, depths[-1], dtok, stok, (H, W))
+        out["pred_depth"] = depths + [depth]
+        out["pred_seg"] = seg
+        return out

@@ -64,6 +64,7 @@ def run_case(name, cfg, train=True):
         return hook
 
     handles = [model.register_forward_hook(keep("outputs")),
+               model.dense_encoder.depth_pred32.register_forward_hook(keep("depth0_tokens")),
                model.dense_encoder.certainSample1.register_forward_hook(keep("points1")),
                model.dense_encoder.certainSample2.register_forward_hook(keep("points2"))]
     match_log = []
@@ -108,6 +109,7 @@ def run_case(name, cfg, train=True):
     for i, d in enumerate(o["pred_depth"]):
         out[f"pred_depth{i}"] = d.detach().numpy()
     out["pred_seg"] = o["pred_seg"].detach().numpy()
+    out["depth0_tokens"] = cap["depth0_tokens"].detach().numpy()      # (B, H/32*W/32, 1): 1/32-scale sigmoid head
     out["points1"] = cap["points1"].detach().numpy()
     out["points2"] = cap["points2"].detach().numpy()
     # top-k line ids as the reference picks them (multiscale_transformerr.py:1166)

@@ -1,0 +1,62 @@
+"""GPU parity proper: one full fp32 train step of the product, through the C ABI on the MI355X, against
+the golden vectors of the real reference (outputs, 17 loss terms, per-parameter gradient norms, global
+norm, AdamW update).  north_star tolerance: 1e-3 relative fp32; index outputs bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from gw_depth_amd import hip
+from tests.golden_check import build, check_train_step, rel, to_device
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def real_library():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    hip.set_library(None)
+    assert not getattr(hip.library(), "is_fake", False)
+    yield
+
+
+@pytest.mark.parametrize("case", ["tiny_b2_96x128", "ragged_b2_96x128", "mid_b1_224x288"])
+def test_fp32_train_step_matches_reference(golden_dir, case):
+    check_train_step(case, golden_dir, "cuda", tol=1e-3, grad_tol=5e-3)
+
+
+def test_bf16_step_runs_and_stays_close(golden_dir):
+    """bf16 storage / fp32 accumulate is the bench mode; index ops make end-to-end equality meaningless
+    (BASELINE.md §3), so check the parts in front of the first index op and that the step is finite."""
+    import os
+    from gw_depth_amd.engine import TrainStep
+    from gw_depth_amd.synth import synth_batch
+    from oracle.make_golden import CASES
+    g = np.load(os.path.join(golden_dir, "tiny_b2_96x128.npz"))
+    c = CASES["tiny_b2_96x128"]
+    cfg, model, crits = build(device="cuda")
+    b = to_device(synth_batch(c["batch"], c["height"], c["width"], seed=c["seed"], n_lines=c["n_lines"]), "cuda")
+    step = TrainStep(model, crits, cfg, compute_dtype=torch.bfloat16)
+    out, total, terms = step(b)
+    assert torch.isfinite(total)
+    assert rel(out["pred_lines"].detach(), g["pred_lines"]) < 5e-2
+    assert rel(out["pred_logits"].detach(), g["pred_logits"]) < 1e-1
+    assert abs(float(total) - float(g["stat/loss"])) / float(g["stat/loss"]) < 0.1
+
+
+def test_index_ops_bit_exact_on_identical_operands():
+    """top-k line selection and CertainSample are integer-valued: given bit-identical operands the GPU
+    path must return exactly the oracle's indices / coordinates (SURVEY.md §8a a12, §7 'index-op chaos')."""
+    from gw_depth_amd.model import certain_sample
+    from oracle import gwdepth_ref as R
+    g = torch.Generator().manual_seed(3)
+    for (hs, ws, hl, wl, S) in ((15, 20, 30, 40, 30), (30, 40, 60, 80, 80), (6, 8, 12, 16, 30), (3, 4, 6, 8, 30)):
+        small = torch.zeros(4, 1, hs, ws)       # bilinear(0) == 0 on every device: variance = large^2, one exact multiply
+        large = torch.rand(4, 1, hl, wl, generator=g) * 0.98 + 0.01
+        large[1] = large[1] * 0.05            # everything in the lowest interval
+        large[2] = 0.95 + large[2] * 0.04     # everything in the highest interval
+        ref = R.certain_sample(small, large, (0.1, 0.3, 0.5, 0.7, 0.9), S, 1e-4)
+        got = certain_sample(small.cuda(), large.cuda(), (0.1, 0.3, 0.5, 0.7, 0.9), S, 1e-4)
+        assert torch.equal(got.cpu(), ref), (hs, ws)
+    logits = torch.randn(8, 100, 2, generator=g)
+    assert torch.equal(torch.topk(logits[:, :, 0].cuda(), 20, dim=-1)[1].cpu(), torch.topk(logits[:, :, 0], 20, dim=-1)[1])
