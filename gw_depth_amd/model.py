@@ -596,7 +596,13 @@ def certain_sample(pred_small, pred_large, interval, sample_num, min_depth):
     edges = torch.tensor([min_depth] + list(interval) + [1.0], device=pred_large.device, dtype=pred_large.dtype)
     flat = pred_large.flatten(1)
     n_i = ((flat[:, None, :] >= edges[:-1, None]) & (flat[:, None, :] < edges[1:, None])).sum(-1)       # (B, I)
-    k_i = torch.minimum(torch.floor((n_i / (H * W)) * sample_num), n_i.to(torch.float32)).long().tolist()   # one host sync
+    # k_i = min(floor(n_i / HW * S), n_i) in IEEE fp32 exactly as the CPU reference evaluates it.  Done on the host
+    # (n_i is needed there anyway): a device-side `tensor / python_scalar` multiplies by the rounded reciprocal,
+    # which turns 1200/1200*30 into 29.999998 and floors to 29 — one sample fewer than the reference.
+    import numpy as np
+    n_host = np.asarray(n_i.tolist(), dtype=np.int64)                                                    # one host sync
+    k_host = np.floor(n_host.astype(np.float32) / np.float32(H * W) * np.float32(sample_num))
+    k_i = np.minimum(k_host, n_host.astype(np.float32)).astype(np.int64).tolist()
     order = torch.argsort(var, dim=1, descending=True, stable=True)                                       # lowest index wins ties
     outs = []
     for b in range(B):
