@@ -16,12 +16,14 @@ LIB_PATH = os.path.join(_HERE, "libgwdepth_hip.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 GATHER_CONV, GATHER_TRANSPOSED, GATHER_UPSAMPLED = 0, 1, 2
+RESAMPLE_BILINEAR_AC, RESAMPLE_NEAREST = 0, 1
 
 ENTRY_POINTS = [
     "gwd_version", "gwd_arch", "gwd_conv_forward", "gwd_conv_wgrad", "gwd_weight_prep", "gwd_act_backward",
     "gwd_colsum", "gwd_layernorm_forward", "gwd_layernorm_backward", "gwd_softmax_forward",
     "gwd_softmax_backward", "gwd_silog_sums", "gwd_silog_backward", "gwd_seg_ce_sum", "gwd_seg_ce_backward",
-    "gwd_sqnorm", "gwd_adamw_step",
+    "gwd_sqnorm", "gwd_adamw_step", "gwd_resample_forward", "gwd_resample_backward", "gwd_avgpool_forward",
+    "gwd_avgpool_backward",
 ]
 
 
@@ -82,6 +84,10 @@ class HipLibrary:
         L.gwd_silog_backward.argtypes = [vp, vp, vp, vp, f32, f32, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_seg_ce_sum.argtypes = [vp, vp, vp, i64, i32, vp]
         L.gwd_seg_ce_backward.argtypes = [vp, vp, vp, f32, vp, i64, i32, vp]
+        L.gwd_resample_forward.argtypes = [vp, vp] + [i32] * 8 + [vp]
+        L.gwd_resample_backward.argtypes = [vp, vp] + [i32] * 8 + [vp]
+        L.gwd_avgpool_forward.argtypes = [vp, vp] + [i32] * 6 + [vp]
+        L.gwd_avgpool_backward.argtypes = [vp, vp] + [i32] * 6 + [vp]
         L.gwd_sqnorm.argtypes = [vp, vp, i64, vp]
         L.gwd_adamw_step.argtypes = [vp, vp, vp, vp, vp, vp, i64] + [f32] * 9 + [vp]
 
@@ -169,6 +175,22 @@ class HipLibrary:
     def seg_ce_backward(self, logits, target, gloss, scale, glogits, P):
         self._check(self.lib.gwd_seg_ce_backward(_ptr(logits), _ptr(target), _ptr(gloss), scale, _ptr(glogits), P,
                                                  dtype_code(logits), self._stream(logits, glogits)), "gwd_seg_ce_backward")
+
+    def resample_forward(self, x, y, B, Hs, Ws, Ho, Wo, C, mode):
+        self._check(self.lib.gwd_resample_forward(_ptr(x), _ptr(y), B, Hs, Ws, Ho, Wo, C, mode, dtype_code(x),
+                                                  self._stream(x, y)), "gwd_resample_forward")
+
+    def resample_backward(self, gy, gx, B, Hs, Ws, Ho, Wo, C, mode):
+        self._check(self.lib.gwd_resample_backward(_ptr(gy), _ptr(gx), B, Hs, Ws, Ho, Wo, C, mode, dtype_code(gy),
+                                                   self._stream(gy, gx)), "gwd_resample_backward")
+
+    def avgpool_forward(self, x, y, B, H, W, C, k):
+        self._check(self.lib.gwd_avgpool_forward(_ptr(x), _ptr(y), B, H, W, C, k, dtype_code(x), self._stream(x, y)),
+                    "gwd_avgpool_forward")
+
+    def avgpool_backward(self, gy, gx, B, H, W, C, k):
+        self._check(self.lib.gwd_avgpool_backward(_ptr(gy), _ptr(gx), B, H, W, C, k, dtype_code(gy),
+                                                  self._stream(gy, gx)), "gwd_avgpool_backward")
 
     def sqnorm(self, g, sq, n):
         self._check(self.lib.gwd_sqnorm(_ptr(g), _ptr(sq), n, self._stream(g, sq)), "gwd_sqnorm")

@@ -553,10 +553,9 @@ class PyramidLayer(nn.Module):
             x = F.pad(x, (0, 0, 0, max(self.pools[0] - W, 0), 0, max(self.pools[0] - H, 0)))
         size = x.shape[1:3]
         outs = [x]
-        xn = to_nchw(x)
         for i, k in enumerate(self.pools, start=1):
-            y = getattr(self, f"branch{i}")[1](to_pixel_major(F.avg_pool2d(xn, k, k)), True)
-            outs.append(to_pixel_major(F.interpolate(to_nchw(y), size=size, mode="bilinear", align_corners=True)))
+            y = getattr(self, f"branch{i}")[1](ops.avg_pool(x, k), True)
+            outs.append(ops.upsample_bilinear_ac(y, size))
         x = self.lastconv[0](torch.cat(outs, dim=-1), True)
         return ops.conv2d(x, self.lastconv[2].weight)
 
@@ -628,7 +627,9 @@ def certain_sample(pred_small, pred_large, interval, sample_num, min_depth):
         outs.append(cat)
     idx = torch.stack(outs)
     col, row = (idx % W).float(), torch.div(idx, W, rounding_mode="floor").float()
-    return torch.stack([(col / W) * 2 - 1, (row / H) * 2 - 1], dim=-1)[:, :, None]
+    # tensor / tensor is an IEEE division on the device; tensor / python_scalar multiplies by 1/W (1 ulp off the CPU path)
+    wt, ht = torch.full_like(col, float(W)), torch.full_like(row, float(H))
+    return torch.stack([(col / wt) * 2 - 1, (row / ht) * 2 - 1], dim=-1)[:, :, None]
 
 
 # ------------------------------------------------------------------------------------ dense encoder
@@ -648,8 +649,7 @@ def sig_head(x, seq):
 def nearest_up_tokens(tok, Hs, Ws, size):
     """(B, Hs*Ws, C) -> nearest-upsampled (B, H*W, C)."""
     B, _, C = tok.shape
-    t = F.interpolate(to_nchw(tok.view(B, Hs, Ws, C)), size=size, mode="nearest")
-    return to_pixel_major(t).view(B, size[0] * size[1], C)
+    return ops.upsample_nearest(tok.reshape(B, Hs, Ws, C), size).view(B, size[0] * size[1], C)
 
 
 class ReferTransformer(nn.Module):

@@ -264,3 +264,55 @@ class _SegCEFn(torch.autograd.Function):
 def seg_cross_entropy(logits_pixel_major, target, scale=1.0):
     """scale * mean CE of (B,H,W,2) logits against (B,H,W) int64 targets."""
     return _SegCEFn.apply(logits_pixel_major, target.contiguous(), float(scale))
+
+
+class _ResampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, size, mode):
+        x = x.contiguous()
+        B, Hs, Ws, C = x.shape
+        y = torch.empty((B, size[0], size[1], C), dtype=x.dtype, device=x.device)
+        _lib().resample_forward(x, y, B, Hs, Ws, size[0], size[1], C, mode)
+        ctx.cfg = (B, Hs, Ws, size[0], size[1], C, mode)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, Hs, Ws, Ho, Wo, C, mode = ctx.cfg
+        gy = gy.contiguous()
+        gx = torch.empty((B, Hs, Ws, C), dtype=gy.dtype, device=gy.device)
+        _lib().resample_backward(gy, gx, B, Hs, Ws, Ho, Wo, C, mode)
+        return gx, None, None
+
+
+def upsample_bilinear_ac(x, size):
+    """(B,Hs,Ws,C) -> (B,H,W,C), bilinear with align_corners=True."""
+    return _ResampleFn.apply(x, tuple(size), hip.RESAMPLE_BILINEAR_AC)
+
+
+def upsample_nearest(x, size):
+    """(B,Hs,Ws,C) -> (B,H,W,C), legacy nearest (floor(dst * in / out))."""
+    return _ResampleFn.apply(x, tuple(size), hip.RESAMPLE_NEAREST)
+
+
+class _AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k):
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        y = torch.empty((B, H // k, W // k, C), dtype=x.dtype, device=x.device)
+        _lib().avgpool_forward(x, y, B, H, W, C, k)
+        ctx.cfg = (B, H, W, C, k)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, H, W, C, k = ctx.cfg
+        gx = torch.empty((B, H, W, C), dtype=gy.dtype, device=gy.device)
+        _lib().avgpool_backward(gy.contiguous(), gx, B, H, W, C, k)
+        return gx, None
+
+
+def avg_pool(x, k):
+    """k x k average pooling with stride k on a pixel-major map."""
+    return _AvgPoolFn.apply(x, int(k))

@@ -116,6 +116,21 @@ int gwd_seg_ce_sum(const void *logits, const int64_t *target, double *sum, int64
 int gwd_seg_ce_backward(const void *logits, const int64_t *target, const float *gloss, float scale,
                         void *glogits, int64_t P, int32_t dtype, void *stream);
 
+/* Pixel-major resampling ([B][H][W][C]).  mode 0 = bilinear align_corners=True (PSP branches of
+ * src/models/points/points_sample.py:114-121, CertainSample :293), mode 1 = legacy nearest
+ * floor(dst*in/out) (src/models/multiscale_transformerr.py:1193,1230,1240,1267).  The backward kernels are
+ * gathers over each source pixel's footprint (no atomics, bitwise reproducible).                    */
+enum { GWD_RESAMPLE_BILINEAR_AC = 0, GWD_RESAMPLE_NEAREST = 1 };
+int gwd_resample_forward(const void *x, void *y, int32_t B, int32_t Hs, int32_t Ws, int32_t Ho, int32_t Wo,
+                         int32_t C, int32_t mode, int32_t dtype, void *stream);
+int gwd_resample_backward(const void *gy, void *gx, int32_t B, int32_t Hs, int32_t Ws, int32_t Ho, int32_t Wo,
+                          int32_t C, int32_t mode, int32_t dtype, void *stream);
+/* k x k / stride k average pooling (nn.AvgPool2d(k, stride=k), points_sample.py:61-75), floor mode.  */
+int gwd_avgpool_forward(const void *x, void *y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
+                        int32_t dtype, void *stream);
+int gwd_avgpool_backward(const void *gy, void *gx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
+                         int32_t dtype, void *stream);
+
 /* sq[0] += sum g^2 over a flat fp32 buffer (double; caller zeroes).  clip_grad_norm_ numerator.    */
 int gwd_sqnorm(const float *g, double *sq, int64_t n, void *stream);
 /* Fused clip_grad_norm_(max_norm) + torch.optim.AdamW step on a flat fp32 range

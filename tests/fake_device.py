@@ -174,3 +174,26 @@ class FakeDevice:
         p[:n].addcdiv_(m[:n], (v[:n].sqrt() / (bc2 ** 0.5)).add_(eps), value=-lr / bc1)
         if p16 is not None:
             p16[:n].copy_(p[:n])
+
+    def resample_forward(self, x, y, B, Hs, Ws, Ho, Wo, C, mode):
+        xn = x.reshape(B, Hs, Ws, C).permute(0, 3, 1, 2).float()
+        o = F.interpolate(xn, size=(Ho, Wo), mode="nearest") if mode == hip.RESAMPLE_NEAREST else \
+            F.interpolate(xn, size=(Ho, Wo), mode="bilinear", align_corners=True)
+        y.copy_(o.permute(0, 2, 3, 1).reshape(y.shape))
+
+    def resample_backward(self, gy, gx, B, Hs, Ws, Ho, Wo, C, mode):
+        x0 = torch.zeros(B, C, Hs, Ws, requires_grad=True)
+        with torch.enable_grad():
+            o = F.interpolate(x0, size=(Ho, Wo), mode="nearest") if mode == hip.RESAMPLE_NEAREST else \
+                F.interpolate(x0, size=(Ho, Wo), mode="bilinear", align_corners=True)
+            (g,) = torch.autograd.grad(o, x0, gy.reshape(B, Ho, Wo, C).permute(0, 3, 1, 2).float())
+        gx.copy_(g.permute(0, 2, 3, 1).reshape(gx.shape))
+
+    def avgpool_forward(self, x, y, B, H, W, C, k):
+        y.copy_(F.avg_pool2d(x.reshape(B, H, W, C).permute(0, 3, 1, 2).float(), k, k).permute(0, 2, 3, 1).reshape(y.shape))
+
+    def avgpool_backward(self, gy, gx, B, H, W, C, k):
+        x0 = torch.zeros(B, C, H, W, requires_grad=True)
+        with torch.enable_grad():
+            (g,) = torch.autograd.grad(F.avg_pool2d(x0, k, k), x0, gy.reshape(B, H // k, W // k, C).permute(0, 3, 1, 2).float())
+        gx.copy_(g.permute(0, 2, 3, 1).reshape(gx.shape))

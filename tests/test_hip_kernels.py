@@ -228,3 +228,39 @@ def test_sqnorm_adamw(dev):
     torch.cuda.synchronize()
     for a, b in zip(outs[1], outs[0]):
         assert rel(a, b) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", [hip.RESAMPLE_BILINEAR_AC, hip.RESAMPLE_NEAREST])
+@pytest.mark.parametrize("shape", [(2, 7, 10, 120, 160, 32), (2, 15, 20, 30, 40, 1), (1, 60, 80, 120, 160, 24),
+                                   (2, 1, 1, 16, 16, 60), (2, 6, 8, 12, 16, 64), (1, 9, 11, 24, 32, 8), (2, 30, 40, 30, 40, 16)])
+def test_resample(dev, shape, mode, dtype):
+    fake = FakeDevice()
+    B, Hs, Ws, Ho, Wo, C = shape
+    x = rnd(B, Hs, Ws, C, dtype=dtype, seed=1)
+    gy = rnd(B, Ho, Wo, C, dtype=dtype, seed=2)
+    y_r, gx_r = torch.empty(B, Ho, Wo, C, dtype=dtype), torch.empty(B, Hs, Ws, C, dtype=dtype)
+    fake.resample_forward(x, y_r, B, Hs, Ws, Ho, Wo, C, mode)
+    fake.resample_backward(gy, gx_r, B, Hs, Ws, Ho, Wo, C, mode)
+    y, gx = torch.empty_like(y_r).cuda(), torch.empty_like(gx_r).cuda()
+    dev.resample_forward(x.cuda(), y, B, Hs, Ws, Ho, Wo, C, mode)
+    dev.resample_backward(gy.cuda(), gx, B, Hs, Ws, Ho, Wo, C, mode)
+    torch.cuda.synchronize()
+    assert rel(y, y_r) < TOL[dtype] and rel(gx, gx_r) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 120, 160, 32, 16), (2, 16, 16, 60, 2), (1, 30, 41, 8, 4), (2, 17, 19, 16, 8)])
+def test_avgpool(dev, shape, dtype):
+    fake = FakeDevice()
+    B, H, W, C, k = shape
+    x = rnd(B, H, W, C, dtype=dtype, seed=1)
+    gy = rnd(B, H // k, W // k, C, dtype=dtype, seed=2)
+    y_r, gx_r = torch.empty(B, H // k, W // k, C, dtype=dtype), torch.empty(B, H, W, C, dtype=dtype)
+    fake.avgpool_forward(x, y_r, B, H, W, C, k)
+    fake.avgpool_backward(gy, gx_r, B, H, W, C, k)
+    y, gx = torch.empty_like(y_r).cuda(), torch.empty_like(gx_r).cuda()
+    dev.avgpool_forward(x.cuda(), y, B, H, W, C, k)
+    dev.avgpool_backward(gy.cuda(), gx, B, H, W, C, k)
+    torch.cuda.synchronize()
+    assert rel(y, y_r) < TOL[dtype] and rel(gx, gx_r) < TOL[dtype]
