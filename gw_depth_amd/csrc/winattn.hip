@@ -1,0 +1,308 @@
+// Fused 7x7 window attention (N = 49 tokens, head_dim 4/8/16/32), forward and backward.
+//
+//   S = scale * Q K^T + rel_pos_bias[head] (+ shift mask: -100 where the two tokens come from different
+//   regions of the cyclic shift);  P = softmax(S);  O = P V
+//
+// One 64-lane wave owns one (window, head) problem at a time: lane i is query row i in the forward and in
+// backward pass A (dQ, dBias), lane j is key row j in backward pass B (dK, dV), so every reduction is
+// lane-local and the 49x49 score matrix only ever lives in registers.  K/V (and Q/dO in the backward) tiles
+// of the head sit in LDS as fp32 and are read as broadcasts.  A workgroup (4 waves) works on ONE head
+// (blockIdx.y) so the dense bias of that head is staged in LDS once and dBias is accumulated in registers
+// across all windows the wave visits, then reduced through LDS and flushed with 2401 atomics per workgroup.
+// head_dim <= 32 and FLOPs are tiny (9.6 kFLOP * hd per problem): this is a latency/HBM kernel, VALU math.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 49;   // tokens per window
+
+struct Operand {
+    const void *p;
+    long ws, ts, hs;     // window / token / head strides in elements
+};
+struct OperandW {
+    void *p;
+    long ws, ts, hs;
+};
+
+template <typename T, int HD>
+__device__ __forceinline__ void load_tile(float *dst, const Operand &op, long w, int h, int lane) {
+    const T *base = (const T *)op.p + w * op.ws + h * op.hs;
+    for (int e = lane; e < NT * HD; e += 64) {
+        const int t = e / HD, d = e - t * HD;
+        dst[e] = to_f32(base[t * op.ts + d]);
+    }
+}
+
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void winattn_fwd_kernel(Operand q, Operand k, Operand v, OperandW o,
+                                                          const float *__restrict__ bias, const int *__restrict__ region,
+                                                          long n_windows, int windows_per_image, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *bias_s = smem;                                  // [49*49]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = blockIdx.y;
+    float *ks = smem + NT * NT + wave * (2 * NT * HD + 64);
+    float *vs = ks + NT * HD;
+    int *reg_s = (int *)(vs + NT * HD);
+    for (int e = threadIdx.x; e < NT * NT; e += blockDim.x) bias_s[e] = bias[(long)h * NT * NT + e];
+    __syncthreads();
+    const int i = lane < NT ? lane : NT - 1;               // idle lanes shadow the last row (keeps loops uniform)
+    for (long w = (long)blockIdx.x * 4 + wave; w < n_windows; w += (long)gridDim.x * 4) {
+        load_tile<T, HD>(ks, k, w, h, lane);
+        load_tile<T, HD>(vs, v, w, h, lane);
+        if (region) reg_s[lane] = lane < NT ? region[(w % windows_per_image) * NT + lane] : 0;
+        float qr[HD];
+        {
+            const T *qp = (const T *)q.p + w * q.ws + i * q.ts + h * q.hs;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) qr[d] = to_f32(qp[d]) * scale;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes are visible to itself
+        const int my_reg = region ? reg_s[i] : 0;
+        float s[NT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float a = bias_s[i * NT + j];
+#pragma unroll
+            for (int d = 0; d < HD; ++d) a += qr[d] * ks[j * HD + d];
+            if (region && reg_s[j] != my_reg) a += -100.0f;
+            s[j] = a;
+            mx = fmaxf(mx, a);
+        }
+        float l = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            s[j] = __expf(s[j] - mx);
+            l += s[j];
+        }
+        const float inv = 1.0f / l;
+        float acc[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] += s[j] * vs[j * HD + d];
+        if (lane < NT) {
+            T *op = (T *)o.p + w * o.ws + i * o.ts + h * o.hs;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) op[d] = from_f32<T>(acc[d] * inv);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void winattn_bwd_kernel(Operand q, Operand k, Operand v, Operand go, OperandW gq,
+                                                          OperandW gk, OperandW gv, const float *__restrict__ bias,
+                                                          float *__restrict__ dbias, const int *__restrict__ region,
+                                                          long n_windows, int windows_per_image, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *bias_s = smem;                                  // [49*49]
+    float *dbias_s = smem + NT * NT;                       // [49*49]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = blockIdx.y;
+    float *qs = smem + 2 * NT * NT + wave * (4 * NT * HD + 4 * 64);
+    float *ks = qs + NT * HD, *vs = ks + NT * HD, *os = vs + NT * HD;
+    float *m_s = os + NT * HD, *l_s = m_s + 64, *dl_s = l_s + 64;
+    int *reg_s = (int *)(dl_s + 64);
+    for (int e = threadIdx.x; e < NT * NT; e += blockDim.x) {
+        bias_s[e] = bias[(long)h * NT * NT + e];
+        dbias_s[e] = 0.f;
+    }
+    __syncthreads();
+    const int i = lane < NT ? lane : NT - 1;
+    const bool live = lane < NT;
+    float db[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) db[j] = 0.f;
+
+    for (long w = (long)blockIdx.x * 4 + wave; w < n_windows; w += (long)gridDim.x * 4) {
+        load_tile<T, HD>(qs, q, w, h, lane);
+        load_tile<T, HD>(ks, k, w, h, lane);
+        load_tile<T, HD>(vs, v, w, h, lane);
+        load_tile<T, HD>(os, go, w, h, lane);
+        if (region) reg_s[lane] = lane < NT ? region[(w % windows_per_image) * NT + lane] : 0;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        const int my_reg = region ? reg_s[i] : 0;
+        // ---------------- pass A: lane = query row i -> dQ_i, dBias row i, softmax statistics
+        float qr[HD], dor[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            qr[d] = qs[i * HD + d] * scale;
+            dor[d] = os[i * HD + d];
+        }
+        float s[NT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float a = bias_s[i * NT + j];
+#pragma unroll
+            for (int d = 0; d < HD; ++d) a += qr[d] * ks[j * HD + d];
+            if (region && reg_s[j] != my_reg) a += -100.0f;
+            s[j] = a;
+            mx = fmaxf(mx, a);
+        }
+        float l = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            s[j] = __expf(s[j] - mx);
+            l += s[j];
+        }
+        const float inv = 1.0f / l;
+        // delta_i = sum_j P_ij dP_ij = dO_i . O_i  (keeps the 49 dP values out of registers)
+        float oacc[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) oacc[d] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int d = 0; d < HD; ++d) oacc[d] += s[j] * vs[j * HD + d];
+        float delta = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) delta += dor[d] * oacc[d];
+        delta *= inv;
+        float dq[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) dq[d] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) a += dor[d] * vs[j * HD + d];
+            const float ds = s[j] * inv * (a - delta);
+            if (live) db[j] += ds;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) dq[d] += ds * ks[j * HD + d];
+        }
+        if (live) {
+            T *gp = (T *)gq.p + w * gq.ws + i * gq.ts + h * gq.hs;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) gp[d] = from_f32<T>(dq[d] * scale);
+        }
+        m_s[lane] = mx;
+        l_s[lane] = inv;
+        dl_s[lane] = delta;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        // ---------------- pass B: lane = key row j -> dK_j, dV_j
+        const int jj = i;
+        float kr[HD], vr[HD], dk[HD], dv[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            kr[d] = ks[jj * HD + d];
+            vr[d] = vs[jj * HD + d];
+            dk[d] = 0.f;
+            dv[d] = 0.f;
+        }
+#pragma unroll 7
+        for (int r = 0; r < NT; ++r) {
+            float a = bias_s[r * NT + jj], b = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                a += qs[r * HD + d] * scale * kr[d];
+                b += os[r * HD + d] * vr[d];
+            }
+            if (region && reg_s[r] != my_reg) a += -100.0f;
+            const float p = __expf(a - m_s[r]) * l_s[r];
+            const float ds = p * (b - dl_s[r]);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                dk[d] += ds * qs[r * HD + d];
+                dv[d] += p * os[r * HD + d];
+            }
+        }
+        if (live) {
+            T *kp = (T *)gk.p + w * gk.ws + jj * gk.ts + h * gk.hs;
+            T *vp = (T *)gv.p + w * gv.ws + jj * gv.ts + h * gv.hs;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                kp[d] = from_f32<T>(dk[d] * scale);
+                vp[d] = from_f32<T>(dv[d]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (dbias) {
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) atomicAdd(&dbias_s[i * NT + j], db[j]);
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < NT * NT; e += blockDim.x) unsafeAtomicAdd(dbias + (long)h * NT * NT + e, dbias_s[e]);
+    }
+}
+
+struct Args {
+    Operand q, k, v, go;
+    OperandW o, gq, gk, gv;
+};
+
+template <typename T, int HD>
+int launch(bool backward, const Args &a, const float *bias, float *dbias, const int *region, long n_windows,
+           int windows_per_image, int heads, float scale, hipStream_t s) {
+    long bx = (n_windows + 3) / 4;
+    if (bx > 512) bx = 512;
+    dim3 grid((unsigned)bx, heads);
+    if (!backward) {
+        const size_t lds = (NT * NT + 4 * (2 * NT * HD + 64)) * sizeof(float);
+        winattn_fwd_kernel<T, HD><<<grid, 256, lds, s>>>(a.q, a.k, a.v, a.o, bias, region, n_windows, windows_per_image, scale);
+    } else {
+        const size_t lds = (2 * NT * NT + 4 * (4 * NT * HD + 4 * 64)) * sizeof(float);
+        winattn_bwd_kernel<T, HD><<<grid, 256, lds, s>>>(a.q, a.k, a.v, a.go, a.gq, a.gk, a.gv, bias, dbias, region, n_windows,
+                                                        windows_per_image, scale);
+    }
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T>
+int dispatch_hd(int hd, bool backward, const Args &a, const float *bias, float *dbias, const int *region, long nw, int wpi,
+                int heads, float scale, hipStream_t s) {
+    switch (hd) {
+        case 4: return launch<T, 4>(backward, a, bias, dbias, region, nw, wpi, heads, scale, s);
+        case 8: return launch<T, 8>(backward, a, bias, dbias, region, nw, wpi, heads, scale, s);
+        case 16: return launch<T, 16>(backward, a, bias, dbias, region, nw, wpi, heads, scale, s);
+        case 32: return launch<T, 32>(backward, a, bias, dbias, region, nw, wpi, heads, scale, s);
+        default: return -4;
+    }
+}
+
+}  // namespace
+
+extern "C" int gwd_winattn_forward(const gwd_strided *q, const gwd_strided *k, const gwd_strided *v, const gwd_strided *o,
+                                   const float *bias, const int32_t *region, int64_t n_windows, int32_t windows_per_image,
+                                   int32_t heads, int32_t head_dim, float scale, int32_t dtype, void *stream) {
+    if (!q || !k || !v || !o || !q->p || !k->p || !v->p || !o->p || !bias || n_windows <= 0 || heads <= 0) return -1;
+    if (region && windows_per_image <= 0) return -1;
+    Args a{};
+    a.q = {q->p, q->ws, q->ts, q->hs};
+    a.k = {k->p, k->ws, k->ts, k->hs};
+    a.v = {v->p, v->ws, v->ts, v->hs};
+    a.o = {o->p, o->ws, o->ts, o->hs};
+    if (dtype == GWD_BF16) return dispatch_hd<__bf16>(head_dim, false, a, bias, nullptr, region, n_windows, windows_per_image, heads, scale, (hipStream_t)stream);
+    if (dtype == GWD_F32) return dispatch_hd<float>(head_dim, false, a, bias, nullptr, region, n_windows, windows_per_image, heads, scale, (hipStream_t)stream);
+    return -2;
+}
+
+extern "C" int gwd_winattn_backward(const gwd_strided *q, const gwd_strided *k, const gwd_strided *v, const gwd_strided *go,
+                                    const gwd_strided *gq, const gwd_strided *gk, const gwd_strided *gv, const float *bias,
+                                    float *dbias, const int32_t *region, int64_t n_windows, int32_t windows_per_image,
+                                    int32_t heads, int32_t head_dim, float scale, int32_t dtype, void *stream) {
+    if (!q || !k || !v || !go || !gq || !gk || !gv || !bias || n_windows <= 0 || heads <= 0) return -1;
+    if (!q->p || !k->p || !v->p || !go->p || !gq->p || !gk->p || !gv->p) return -1;
+    if (region && windows_per_image <= 0) return -1;
+    Args a{};
+    a.q = {q->p, q->ws, q->ts, q->hs};
+    a.k = {k->p, k->ws, k->ts, k->hs};
+    a.v = {v->p, v->ws, v->ts, v->hs};
+    a.go = {go->p, go->ws, go->ts, go->hs};
+    a.gq = {gq->p, gq->ws, gq->ts, gq->hs};
+    a.gk = {gk->p, gk->ws, gk->ts, gk->hs};
+    a.gv = {gv->p, gv->ws, gv->ts, gv->hs};
+    if (dtype == GWD_BF16) return dispatch_hd<__bf16>(head_dim, true, a, bias, dbias, region, n_windows, windows_per_image, heads, scale, (hipStream_t)stream);
+    if (dtype == GWD_F32) return dispatch_hd<float>(head_dim, true, a, bias, dbias, region, n_windows, windows_per_image, heads, scale, (hipStream_t)stream);
+    return -2;
+}

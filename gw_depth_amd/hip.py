@@ -23,7 +23,7 @@ ENTRY_POINTS = [
     "gwd_colsum", "gwd_layernorm_forward", "gwd_layernorm_backward", "gwd_softmax_forward",
     "gwd_softmax_backward", "gwd_silog_sums", "gwd_silog_backward", "gwd_seg_ce_sum", "gwd_seg_ce_backward",
     "gwd_sqnorm", "gwd_adamw_step", "gwd_resample_forward", "gwd_resample_backward", "gwd_avgpool_forward",
-    "gwd_avgpool_backward",
+    "gwd_avgpool_backward", "gwd_winattn_forward", "gwd_winattn_backward",
 ]
 
 
@@ -37,6 +37,17 @@ class ConvDesc(ctypes.Structure):
                [(n, ctypes.c_int32) for n in ("B", "Hi", "Wi", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad",
                                               "gather", "Hv", "Wv", "act")] + \
                [("act_scale", ctypes.c_float), ("dtype", ctypes.c_int32)]
+
+
+class Strided(ctypes.Structure):
+    _fields_ = [("p", ctypes.c_void_p), ("ws", ctypes.c_int64), ("ts", ctypes.c_int64), ("hs", ctypes.c_int64)]
+
+
+def _strided(t):
+    """(windows, tokens, heads, head_dim) tensor or view with unit channel stride."""
+    if t.dim() != 4 or t.stride(3) != 1:
+        raise ValueError("window-attention operand must be (W, N, heads, hd) with unit last stride")
+    return Strided(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
 
 
 def dtype_code(t):
@@ -88,6 +99,9 @@ class HipLibrary:
         L.gwd_resample_backward.argtypes = [vp, vp] + [i32] * 8 + [vp]
         L.gwd_avgpool_forward.argtypes = [vp, vp] + [i32] * 6 + [vp]
         L.gwd_avgpool_backward.argtypes = [vp, vp] + [i32] * 6 + [vp]
+        sp = ctypes.POINTER(Strided)
+        L.gwd_winattn_forward.argtypes = [sp, sp, sp, sp, vp, vp, i64, i32, i32, i32, f32, i32, vp]
+        L.gwd_winattn_backward.argtypes = [sp] * 7 + [vp, vp, vp, i64, i32, i32, i32, f32, i32, vp]
         L.gwd_sqnorm.argtypes = [vp, vp, i64, vp]
         L.gwd_adamw_step.argtypes = [vp, vp, vp, vp, vp, vp, i64] + [f32] * 9 + [vp]
 
@@ -191,6 +205,20 @@ class HipLibrary:
     def avgpool_backward(self, gy, gx, B, H, W, C, k):
         self._check(self.lib.gwd_avgpool_backward(_ptr(gy), _ptr(gx), B, H, W, C, k, dtype_code(gy),
                                                   self._stream(gy, gx)), "gwd_avgpool_backward")
+
+    def winattn_forward(self, q, k, v, o, bias, region, wpi, scale):
+        """q,k,v,o: (W, 49, heads, hd) tensors or views; bias (heads,49,49) fp32; region (wpi,49) int32 or None."""
+        W, N, H, D = q.shape
+        s = [_strided(t) for t in (q, k, v, o)]
+        self._check(self.lib.gwd_winattn_forward(*[ctypes.byref(x) for x in s], _ptr(bias), _ptr(region), W, wpi, H, D,
+                                                 scale, dtype_code(q), self._stream(q, k, v, o)), "gwd_winattn_forward")
+
+    def winattn_backward(self, q, k, v, go, gq, gk, gv, bias, dbias, region, wpi, scale):
+        W, N, H, D = q.shape
+        s = [_strided(t) for t in (q, k, v, go, gq, gk, gv)]
+        self._check(self.lib.gwd_winattn_backward(*[ctypes.byref(x) for x in s], _ptr(bias), _ptr(dbias), _ptr(region), W,
+                                                  wpi, H, D, scale, dtype_code(q), self._stream(q, go, gq)),
+                    "gwd_winattn_backward")
 
     def sqnorm(self, g, sq, n):
         self._check(self.lib.gwd_sqnorm(_ptr(g), _ptr(sq), n, self._stream(g, sq)), "gwd_sqnorm")

@@ -300,13 +300,14 @@ def window_reverse(win, H, W):
     return x.permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, -1)
 
 
-_MASK_CACHE = {}
+_REGION_CACHE = {}
 
 
-def shift_mask(Hp, Wp, device, dtype):
-    """SW-MSA mask with fill -100 (multiscale_transformerr.py:937-955); a pure function of (Hp, Wp)."""
-    key = (Hp, Wp, str(device), dtype)
-    if key not in _MASK_CACHE:
+def shift_regions(Hp, Wp, device):
+    """SW-MSA mask (multiscale_transformerr.py:937-955) in compact form: the 9-region label of every token of
+    every window, int32 (nW, 49).  The kernels add -100 where two tokens of a window carry different labels."""
+    key = (Hp, Wp, str(device))
+    if key not in _REGION_CACHE:
         shift = WS // 2
         img = torch.zeros(1, Hp, Wp, 1)
         cnt = 0
@@ -314,11 +315,8 @@ def shift_mask(Hp, Wp, device, dtype):
             for w in (slice(0, -WS), slice(-WS, -shift), slice(-shift, None)):
                 img[:, h, w, :] = cnt
                 cnt += 1
-        mw = window_partition(img).view(-1, WS * WS)
-        am = mw.unsqueeze(1) - mw.unsqueeze(2)
-        am = am.masked_fill(am != 0, -100.0).masked_fill(am == 0, 0.0)
-        _MASK_CACHE[key] = am.to(device=device, dtype=dtype)
-    return _MASK_CACHE[key]
+        _REGION_CACHE[key] = window_partition(img).view(-1, WS * WS).to(torch.int32).to(device).contiguous()
+    return _REGION_CACHE[key]
 
 
 def relative_position_index():
@@ -344,22 +342,10 @@ class WindowAttnBase(nn.Module):
         self.qkv = Linear(dim, dim * 3)
         self.proj = Linear(dim, dim)
 
-    def qkv_heads(self, xw):
-        B_, N, C = xw.shape
-        qkv = self.qkv(xw).reshape(B_, N, 3, HEADS, C // HEADS).permute(2, 0, 3, 1, 4)
-        return qkv[0], qkv[1], qkv[2]
-
-    def attend(self, scores, v, mask):
-        """+ relative position bias (+ shift mask), softmax, @v, proj (multiscale_transformerr.py:313-329)."""
-        B_, nH, N, _ = scores.shape
-        bias = self.relative_position_bias_table[self.relative_position_index.view(-1)].view(N, N, -1)
-        att = scores + bias.permute(2, 0, 1).to(scores.dtype).unsqueeze(0)
-        if mask is not None:
-            nW = mask.shape[0]
-            att = (att.view(B_ // nW, nW, nH, N, N) + mask.unsqueeze(1).unsqueeze(0)).view(-1, nH, N, N)
-        att = ops.softmax_lastdim(att)
-        x = (att @ v).transpose(1, 2).reshape(B_, N, -1)
-        return self.proj(x)
+    def bias_dense(self):
+        """(heads, 49, 49) fp32 relative-position bias (multiscale_transformerr.py:313-315)."""
+        n = WS * WS
+        return self.relative_position_bias_table[self.relative_position_index.view(-1)].view(n, n, -1).permute(2, 0, 1)
 
 
 class WindowAttention(WindowAttnBase):
@@ -370,18 +356,19 @@ class WindowAttention(WindowAttnBase):
         self.ref_qk = Linear(dim, dim * 2)
         self.ref_attn_diffusion = Conv(HEADS, HEADS, 3, bias=True)
 
-    def forward(self, xw, x_ref, mask):
+    def forward(self, xw, x_ref, regions):
         B_, N, C = xw.shape
         hd = C // HEADS
-        q, k, v = self.qkv_heads(xw)
+        qkv = self.qkv(xw).view(B_, N, 3, HEADS, hd)
+        q = qkv[:, :, 0].permute(0, 2, 1, 3)                                        # (B_, nH, N, hd) view
         rqk = self.ref_qk(x_ref)
         rB, nrf = rqk.shape[0], rqk.shape[1]
         nwin = B_ // rB
         ref_q = self.diff_mu.to(rqk.dtype) + self.diff_logsigma.exp().to(rqk.dtype) * rqk[..., :C]
         ref_k = ref_q.reshape(rB, nrf, HEADS, hd).permute(0, 2, 1, 3)            # (rB, nH, nrf, hd)
         ref_v = rqk[..., C:].reshape(rB, nrf, HEADS, hd).permute(0, 2, 1, 3)
-        q = (q * self.scale).reshape(rB, nwin, HEADS, N, hd)
-        ra = torch.einsum("bwhnd,bhrd->bwnrh", q, ref_k).reshape(rB, nwin * N, nrf, HEADS)   # pixel-major (B, nWin*N, nrf, heads)
+        qs = (q * self.scale).reshape(rB, nwin, HEADS, N, hd)
+        ra = torch.einsum("bwhnd,bhrd->bwnrh", qs, ref_k).reshape(rB, nwin * N, nrf, HEADS)  # pixel-major (B, nWin*N, nrf, heads)
         for _ in range(3):                                                        # :299-302
             upd = ops.conv2d(ra.contiguous(), self.ref_attn_diffusion.weight, self.ref_attn_diffusion.bias, pad=1)
             uf = upd.float()
@@ -390,8 +377,10 @@ class WindowAttention(WindowAttnBase):
             ra = ra + F.gelu((uf - mu) * torch.rsqrt(var + 1e-5)).to(ra.dtype)
         ra = ra.reshape(rB, nwin, N, nrf, HEADS).permute(0, 1, 4, 2, 3)          # (rB, nwin, nH, N, nrf)
         att = ops.softmax_lastdim(ra)
-        q_new = torch.einsum("bwhnr,bhrd->bwhnd", att, ref_v).reshape(B_, HEADS, N, hd) * self.scale
-        return self.attend(q_new @ k.transpose(-2, -1), v, mask)
+        q_new = torch.einsum("bwhnr,bhrd->bwnhd", att, ref_v).reshape(B_, N, HEADS, hd)      # second *scale: in-kernel
+        wpi = regions.shape[0] if regions is not None else 1
+        x = ops.window_attention(q_new, qkv[:, :, 1], qkv[:, :, 2], self.bias_dense(), regions, wpi, self.scale)
+        return self.proj(x)
 
 
 class WindowClassAttention(WindowAttnBase):
@@ -406,10 +395,11 @@ class WindowClassAttention(WindowAttnBase):
         self.global_k, self.global_v = Linear(dim + 2 * tdim, dim + 2 * tdim), Linear(dim + 2 * tdim, dim + 2 * tdim)
         self.proj_dth, self.proj_seg = Linear(tdim, tdim), Linear(tdim, tdim)
 
-    def forward(self, xw, dtok, stok, mask):
+    def forward(self, xw, dtok, stok, regions):
         B_, N, C = xw.shape
-        q, k, v = self.qkv_heads(xw)
-        x = self.attend((q * self.scale) @ k.transpose(-2, -1), v, mask)
+        qkv = self.qkv(xw).view(B_, N, 3, HEADS, C // HEADS)
+        wpi = regions.shape[0] if regions is not None else 1
+        x = self.proj(ops.window_attention_packed(qkv, self.bias_dense(), regions, wpi, self.scale))
         tdim = dtok.shape[-1]
         tx = torch.cat([x, dtok, stok], dim=-1)
         tC = tx.shape[-1]
@@ -460,7 +450,7 @@ class SwinBlock(nn.Module):
         B, L, C = x.shape
         shift = self.shift
         sx, Hp, Wp = pad_roll(self.norm1(x).view(B, H, W, C), H, W, shift)
-        mask = shift_mask(Hp, Wp, x.device, x.dtype) if shift else None
+        mask = shift_regions(Hp, Wp, x.device) if shift else None
         if dtok is None:
             if shift:                                                             # :678-686
                 rc = torch.stack([ref_coors[..., 0] - (shift / (Wp - 1)) * 2,

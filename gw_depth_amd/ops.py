@@ -316,3 +316,66 @@ class _AvgPoolFn(torch.autograd.Function):
 def avg_pool(x, k):
     """k x k average pooling with stride k on a pixel-major map."""
     return _AvgPoolFn.apply(x, int(k))
+
+
+class _WinAttnPackedFn(torch.autograd.Function):
+    """qkv (W, 49, 3, heads, hd) packed as the qkv Linear writes it -> (W, 49, heads*hd)."""
+
+    @staticmethod
+    def forward(ctx, qkv, bias, region, wpi, scale):
+        qkv = qkv.contiguous()
+        W, N, _, H, D = qkv.shape
+        out = torch.empty((W, N, H, D), dtype=qkv.dtype, device=qkv.device)
+        bias = bias.contiguous().float()
+        _lib().winattn_forward(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], out, bias, region, wpi, scale)
+        ctx.save_for_backward(qkv, bias, region)
+        ctx.cfg = (wpi, scale)
+        return out.view(W, N, H * D)
+
+    @staticmethod
+    def backward(ctx, go):
+        qkv, bias, region = ctx.saved_tensors
+        wpi, scale = ctx.cfg
+        W, N, _, H, D = qkv.shape
+        go = go.contiguous().view(W, N, H, D)
+        g = torch.empty_like(qkv)
+        dbias = torch.zeros_like(bias)
+        _lib().winattn_backward(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], go, g[:, :, 0], g[:, :, 1], g[:, :, 2], bias,
+                                dbias, region, wpi, scale)
+        return g, dbias, None, None, None
+
+
+class _WinAttnFn(torch.autograd.Function):
+    """Separate q (W,49,H,D), k, v operands (any window/token/head strides, unit channel stride)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, bias, region, wpi, scale):
+        W, N, H, D = q.shape
+        out = torch.empty((W, N, H, D), dtype=q.dtype, device=q.device)
+        bias = bias.contiguous().float()
+        fix = lambda t: t if t.stride(3) == 1 else t.contiguous()
+        q, k, v = fix(q), fix(k), fix(v)
+        _lib().winattn_forward(q, k, v, out, bias, region, wpi, scale)
+        ctx.save_for_backward(q, k, v, bias, region)
+        ctx.cfg = (wpi, scale)
+        return out.view(W, N, H * D)
+
+    @staticmethod
+    def backward(ctx, go):
+        q, k, v, bias, region = ctx.saved_tensors
+        wpi, scale = ctx.cfg
+        W, N, H, D = q.shape
+        go = go.contiguous().view(W, N, H, D)
+        gq, gk, gv = (torch.empty((W, N, H, D), dtype=q.dtype, device=q.device) for _ in range(3))
+        dbias = torch.zeros_like(bias)
+        _lib().winattn_backward(q, k, v, go, gq, gk, gv, bias, dbias, region, wpi, scale)
+        return gq, gk, gv, dbias, None, None, None
+
+
+def window_attention_packed(qkv, bias, region, windows_per_image, scale):
+    """softmax(scale*q k^T + bias (+shift mask)) v over 49-token windows; qkv (W,49,3,H,D); bias (H,49,49)."""
+    return _WinAttnPackedFn.apply(qkv, bias, region, int(windows_per_image), float(scale))
+
+
+def window_attention(q, k, v, bias, region, windows_per_image, scale):
+    return _WinAttnFn.apply(q, k, v, bias, region, int(windows_per_image), float(scale))

@@ -116,6 +116,26 @@ int gwd_seg_ce_sum(const void *logits, const int64_t *target, double *sum, int64
 int gwd_seg_ce_backward(const void *logits, const int64_t *target, const float *gloss, float scale,
                         void *glogits, int64_t P, int32_t dtype, void *stream);
 
+/* A (window, token, head, channel) operand: element = p[w*ws + t*ts + h*hs + d], channel stride 1.      */
+typedef struct {
+    void *p;
+    int64_t ws, ts, hs;
+} gwd_strided;
+
+/* Fused 7x7 window attention, 49 tokens per window, head_dim in {4, 8, 16, 32}:
+ *   O = softmax(scale * Q K^T + bias[head] (+ -100 where region[token_i] != region[token_j])) V
+ * bias is the dense [heads][49][49] fp32 relative-position bias; region (optional, int32
+ * [windows_per_image][49]) encodes the SW-MSA shift mask.  Replaces the attention core of
+ * WindowAttention / WindowClassAttention (src/models/multiscale_transformerr.py:311-328, 538-556, mask
+ * :937-955).  The backward recomputes P, writes dQ/dK/dV and ACCUMULATES dbias (fp32 atomics; caller zeroes). */
+int gwd_winattn_forward(const gwd_strided *q, const gwd_strided *k, const gwd_strided *v, const gwd_strided *o,
+                        const float *bias, const int32_t *region, int64_t n_windows, int32_t windows_per_image,
+                        int32_t heads, int32_t head_dim, float scale, int32_t dtype, void *stream);
+int gwd_winattn_backward(const gwd_strided *q, const gwd_strided *k, const gwd_strided *v, const gwd_strided *go,
+                         const gwd_strided *gq, const gwd_strided *gk, const gwd_strided *gv, const float *bias,
+                         float *dbias, const int32_t *region, int64_t n_windows, int32_t windows_per_image,
+                         int32_t heads, int32_t head_dim, float scale, int32_t dtype, void *stream);
+
 /* Pixel-major resampling ([B][H][W][C]).  mode 0 = bilinear align_corners=True (PSP branches of
  * src/models/points/points_sample.py:114-121, CertainSample :293), mode 1 = legacy nearest
  * floor(dst*in/out) (src/models/multiscale_transformerr.py:1193,1230,1240,1267).  The backward kernels are

@@ -197,3 +197,31 @@ class FakeDevice:
         with torch.enable_grad():
             (g,) = torch.autograd.grad(F.avg_pool2d(x0, k, k), x0, gy.reshape(B, H // k, W // k, C).permute(0, 3, 1, 2).float())
         gx.copy_(g.permute(0, 2, 3, 1).reshape(gx.shape))
+
+    @staticmethod
+    def _winattn_scores(q, k, bias, region, wpi, scale):
+        # q,k: (W, N, H, D) -> scores (W, H, N, N)
+        s = torch.einsum("wihd,wjhd->whij", q.float() * scale, k.float()) + bias[None]
+        if region is not None:
+            r = region.long()                                             # (wpi, N)
+            m = torch.where(r[:, :, None] != r[:, None, :], -100.0, 0.0)  # (wpi, N, N)
+            W = q.shape[0]
+            s = s + m.repeat(W // wpi, 1, 1)[:, None]
+        return s
+
+    def winattn_forward(self, q, k, v, o, bias, region, wpi, scale):
+        p = F.softmax(self._winattn_scores(q, k, bias, region, wpi, scale), dim=-1)
+        o.copy_(torch.einsum("whij,wjhd->wihd", p, v.float()))
+
+    def winattn_backward(self, q, k, v, go, gq, gk, gv, bias, dbias, region, wpi, scale):
+        qf, kf, vf = (t.detach().float().clone().requires_grad_(True) for t in (q, k, v))
+        bf = bias.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            p = F.softmax(self._winattn_scores(qf, kf, bf, region, wpi, scale), dim=-1)
+            out = torch.einsum("whij,wjhd->wihd", p, vf)
+            g = torch.autograd.grad(out, [qf, kf, vf, bf], go.float())
+        gq.copy_(g[0])
+        gk.copy_(g[1])
+        gv.copy_(g[2])
+        if dbias is not None:
+            dbias.add_(g[3])

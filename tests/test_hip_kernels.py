@@ -264,3 +264,34 @@ def test_avgpool(dev, shape, dtype):
     dev.avgpool_backward(gy.cuda(), gx, B, H, W, C, k)
     torch.cuda.synchronize()
     assert rel(y, y_r) < TOL[dtype] and rel(gx, gx_r) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("hd,nwin,wpi,shifted", [(4, 37, 1, False), (4, 24, 12, True), (8, 20, 4, True), (16, 9, 9, True),
+                                                  (32, 6, 3, True), (32, 5, 1, False), (8, 2100, 4, True)])
+def test_window_attention(dev, hd, nwin, wpi, shifted, dtype):
+    fake = FakeDevice()
+    H = 16
+    qkv = rnd(nwin, 49, 3, H, hd, dtype=dtype, seed=1)
+    bias = rnd(H, 49, 49, seed=2, scale=0.5)
+    g = torch.Generator().manual_seed(7)
+    region = torch.randint(0, 3, (wpi, 49), generator=g, dtype=torch.int32) if shifted else None
+    go = rnd(nwin, 49, H, hd, dtype=dtype, seed=3)
+    scale = hd ** -0.5
+    o_r = torch.empty(nwin, 49, H, hd, dtype=dtype)
+    fake.winattn_forward(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], o_r, bias, region, wpi, scale)
+    g_r, db_r = torch.empty_like(qkv), torch.zeros_like(bias)
+    fake.winattn_backward(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], go, g_r[:, :, 0], g_r[:, :, 1], g_r[:, :, 2], bias, db_r,
+                          region, wpi, scale)
+    Q = qkv.cuda()
+    rg = None if region is None else region.cuda()
+    o = torch.full_like(o_r, float("nan")).cuda()
+    dev.winattn_forward(Q[:, :, 0], Q[:, :, 1], Q[:, :, 2], o, bias.cuda(), rg, wpi, scale)
+    G, db = torch.full_like(g_r, float("nan")).cuda(), torch.zeros_like(bias).cuda()
+    dev.winattn_backward(Q[:, :, 0], Q[:, :, 1], Q[:, :, 2], go.cuda(), G[:, :, 0], G[:, :, 1], G[:, :, 2], bias.cuda(), db,
+                         rg, wpi, scale)
+    torch.cuda.synchronize()
+    assert rel(o, o_r) < TOL[dtype], "forward"
+    for idx, name in enumerate(("dq", "dk", "dv")):
+        assert rel(G[:, :, idx], g_r[:, :, idx]) < TOL[dtype], name
+    assert rel(db, db_r) < TOL[dtype], "dbias"
