@@ -101,18 +101,20 @@ __device__ __forceinline__ f32x16 mma(float a, float b, const f32x16 &c) {
 // ----------------------------------------------------------------------------------------------
 // forward / data gradient
 // ----------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int BK>
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(const gwd_conv_desc d) {
-    constexpr int VEC = Cfg<T>::VEC, BK = Cfg<T>::BK;
+    constexpr int VEC = Cfg<T>::VEC;
     constexpr int KV = BK / VEC;        // 16-byte vectors per tile row (4)
     constexpr int LDK = BK + VEC;       // padded LDS row: 80 bytes, conflict-free ds_read_b128
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int ROWS_PER_PASS = 256 / KV;  // 64
     constexpr int A_IT = BM / ROWS_PER_PASS;
     constexpr int B_IT = (BN + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
+    constexpr int TILE_ELEMS = 2 * (BM + BN) * LDK;
+    constexpr int STAGE_ELEMS = 4 * 32 * 36 * (int)(sizeof(float) / sizeof(T));   // epilogue staging (bf16 only)
     static_assert(WM * WN == 4, "4 waves");
 
-    __shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * LDK];
+    __shared__ __attribute__((aligned(16))) T smem[TILE_ELEMS > STAGE_ELEMS ? TILE_ELEMS : STAGE_ELEMS];
     T *As = smem;
     T *Bs = smem + 2 * BM * LDK;
 
@@ -121,6 +123,10 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const gwd_conv_desc d) {
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const bool fastA = (d.Cin % VEC) == 0, fastB = (K % VEC) == 0;
+    // When Cin is a multiple of BK every K tile lies inside ONE filter tap: (kh, kw, c0) are then
+    // workgroup-uniform (scalar registers, advanced incrementally) and the per-thread gather costs a
+    // bounds test and one multiply-add chain instead of two integer divisions per 16-byte vector.
+    const bool uni = (d.Cin % BK) == 0;
 
     const int lv = tid % KV, lr = tid / KV;
     int a_b[A_IT], a_oh[A_IT], a_ow[A_IT];
@@ -146,11 +152,32 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const gwd_conv_desc d) {
 
     const int KT = (K + BK - 1) / BK;
     uint4 ra[A_IT], rb[B_IT];
+    int u_kh = 0, u_kw = 0, u_c0 = 0;      // tap of the NEXT tile to load (uniform path)
 
     auto load_tiles = [&](int kt) {
         const int k0 = kt * BK + lv * VEC;
+        if (uni) {
+            const T *x = (const T *)d.x;
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) ra[i] = gather_vec<T>(d, a_ok[i], a_b[i], a_oh[i], a_ow[i], k0, K, fastA);
+            for (int i = 0; i < A_IT; ++i) {
+                int ih, iw;
+                uint4 r = make_uint4(0u, 0u, 0u, 0u);
+                if (a_ok[i] && src_pixel(d, a_oh[i], a_ow[i], u_kh, u_kw, ih, iw))
+                    r = *(const uint4 *)(x + ((size_t)(a_b[i] * d.Hi + ih) * d.Wi + iw) * d.Cin + u_c0 + lv * VEC);
+                ra[i] = r;
+            }
+            u_c0 += BK;
+            if (u_c0 >= d.Cin) {
+                u_c0 = 0;
+                if (++u_kw == d.KW) {
+                    u_kw = 0;
+                    ++u_kh;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) ra[i] = gather_vec<T>(d, a_ok[i], a_b[i], a_oh[i], a_ow[i], k0, K, fastA);
+        }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int row = lr + i * ROWS_PER_PASS;
@@ -167,15 +194,8 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const gwd_conv_desc d) {
             if (row < BN) *(uint4 *)(Bs + (size_t)buf * BN * LDK + row * LDK + lv * VEC) = rb[i];
         }
     };
-
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-
     const int fr = lane & 31, fh = lane >> 5;
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) load_tiles(kt + 1);
+    auto compute = [&](int cur) {
         const T *Ab = As + (size_t)cur * BM * LDK + (wm * (BM / WM) + fr) * LDK;
         const T *Bb = Bs + (size_t)cur * BN * LDK + (wn * (BN / WN) + fr) * LDK;
         if constexpr (sizeof(T) == 2) {
@@ -205,14 +225,79 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const gwd_conv_desc d) {
                     for (int j = 0; j < TN; ++j) acc[i][j] = mma(af[i], bfr[j], acc[i][j]);
             }
         }
+    };
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) load_tiles(kt + 1);
+        compute(cur);
         if (kt + 1 < KT) store_tiles(cur ^ 1);
         __syncthreads();
     }
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     T *y = (T *)d.y;
     T *z = (T *)d.z;
     const T *res = (const T *)d.residual;
+    if constexpr (sizeof(T) == 2) {
+        if ((N & 7) == 0) {
+            // each wave transposes one 32x32 accumulator tile at a time through a private LDS patch, then every
+            // lane emits 16-byte stores of 8 consecutive channels (8x fewer store instructions than the
+            // column-per-lane layout; scale/shift/residual are read as vectors too)
+            float *stage = (float *)smem + wave * (32 * 36);
+            const int vr = lane >> 2, vc = (lane & 3) * 8;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * fh) * 36 + fr] = acc[i][j][r];
+                    __builtin_amdgcn_wave_barrier();
+                    const int nb = n0 + wn * (BN / WN) + j * 32 + vc;
+                    if (nb < N) {
+                        float sc[8], sh[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            sc[e] = d.scale ? d.scale[nb + e] : 1.0f;
+                            sh[e] = d.shift ? d.shift[nb + e] : 0.0f;
+                        }
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            const int row = vr + 16 * half;
+                            const int m = m0 + wm * (BM / WM) + i * 32 + row;
+                            if (m >= M) continue;
+                            const f32x4 lo = *(const f32x4 *)(stage + row * 36 + vc);
+                            const f32x4 hi = *(const f32x4 *)(stage + row * 36 + vc + 4);
+                            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            const size_t o = (size_t)m * N + nb;
+                            if (res) {
+                                const bf16x8 rv = *(const bf16x8 *)(res + o);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e] + (float)rv[e];
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+                            }
+                            bf16x8 out;
+                            if (z) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) out[e] = (__bf16)v[e];
+                                *(bf16x8 *)(z + o) = out;
+                            }
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) out[e] = (__bf16)(apply_act(v[e], d.act) * d.act_scale);
+                            *(bf16x8 *)(y + o) = out;
+                        }
+                    }
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / WN) + j * 32 + fr;
@@ -273,6 +358,27 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const gwd_conv_desc d,
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     uint4 ry[Y_IT], rx[X_IT];
+    // Per-thread constants of the im2col gather: the k range of a workgroup is fixed, so the filter tap of each of
+    // this thread's vectors is decoded once; the output pixel of its row advances by RM per step (no divisions).
+    int x_kh[X_IT], x_kw[X_IT], x_c[X_IT], x_b[X_IT], x_oh[X_IT], x_ow[X_IT];
+    bool x_kok[X_IT];
+    const int HoWo = d.Ho * d.Wo;
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+        const int idx = tid + i * 256, row = idx / XV, v = idx % XV;
+        const int k0 = kb0 + v * VEC;
+        x_kok[i] = k0 < K;
+        const int kk = x_kok[i] ? k0 : 0;
+        const int tap = kk / d.Cin;
+        x_c[i] = kk - tap * d.Cin;
+        x_kh[i] = tap / d.KW;
+        x_kw[i] = tap - x_kh[i] * d.KW;
+        const int m = m_begin + row;
+        x_b[i] = m / HoWo;
+        const int rem = m - x_b[i] * HoWo;
+        x_oh[i] = rem / d.Wo;
+        x_ow[i] = rem - x_oh[i] * d.Wo;
+    }
     auto load_tiles = [&](int mbase) {
 #pragma unroll
         for (int i = 0; i < Y_IT; ++i) {
@@ -283,13 +389,29 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const gwd_conv_desc d,
 #pragma unroll
         for (int i = 0; i < X_IT; ++i) {
             const int idx = tid + i * 256, row = idx / XV, v = idx % XV;
-            const int m = mbase + row;
-            const bool ok = m < m_end;
-            const int mm = ok ? m : 0;
-            const int b = mm / (d.Ho * d.Wo);
-            const int rem = mm - b * (d.Ho * d.Wo);
-            const int oh = rem / d.Wo, ow = rem - oh * d.Wo;
-            rx[i] = gather_vec<T>(d, ok, b, oh, ow, kb0 + v * VEC, K, fastA);
+            const bool ok = (mbase + row) < m_end;
+            if (fastA) {
+                uint4 r = make_uint4(0u, 0u, 0u, 0u);
+                int ih, iw;
+                if (ok && x_kok[i] && src_pixel(d, x_oh[i], x_ow[i], x_kh[i], x_kw[i], ih, iw))
+                    r = *(const uint4 *)((const T *)d.x + ((size_t)(x_b[i] * d.Hi + ih) * d.Wi + iw) * d.Cin + x_c[i]);
+                rx[i] = r;
+            } else {
+                rx[i] = gather_vec<T>(d, ok, x_b[i], x_oh[i], x_ow[i], kb0 + v * VEC, K, false);
+            }
+            // advance this row's output pixel by RM for the next step
+            if (HoWo == 1) {
+                x_b[i] += RM;
+            } else {
+                x_ow[i] += RM;
+                while (x_ow[i] >= d.Wo) {
+                    x_ow[i] -= d.Wo;
+                    if (++x_oh[i] == d.Ho) {
+                        x_oh[i] = 0;
+                        ++x_b[i];
+                    }
+                }
+            }
         }
     };
     auto store_tiles = [&](int buf) {
@@ -411,15 +533,16 @@ int check_desc(const gwd_conv_desc *d) {
 template <typename T>
 int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
     const int M = d->B * d->Ho * d->Wo, N = d->Cout;
-    if (N > 64) {
-        dim3 grid((M + 127) / 128, (N + 127) / 128);
-        igemm_fwd_kernel<T, 128, 128, 2, 2><<<grid, 256, 0, s>>>(*d);
+    constexpr int BK = Cfg<T>::BK;
+    const unsigned gm = (M + 127) / 128;
+    if (N % 160 == 0) {                       // 160 / 320 channel pyramids: exact tiles, no padded columns
+        igemm_fwd_kernel<T, 128, 160, 4, 1, BK><<<dim3(gm, N / 160), 256, 0, s>>>(*d);
+    } else if (N > 64) {
+        igemm_fwd_kernel<T, 128, 128, 2, 2, BK><<<dim3(gm, (N + 127) / 128), 256, 0, s>>>(*d);
     } else if (N > 32) {
-        dim3 grid((M + 127) / 128, 1);
-        igemm_fwd_kernel<T, 128, 64, 2, 2><<<grid, 256, 0, s>>>(*d);
+        igemm_fwd_kernel<T, 128, 64, 2, 2, BK><<<dim3(gm, 1), 256, 0, s>>>(*d);
     } else {
-        dim3 grid((M + 127) / 128, 1);
-        igemm_fwd_kernel<T, 128, 32, 4, 1><<<grid, 256, 0, s>>>(*d);
+        igemm_fwd_kernel<T, 128, 32, 4, 1, BK><<<dim3(gm, 1), 256, 0, s>>>(*d);
     }
     GWD_CHECK_LAUNCH();
     return 0;
