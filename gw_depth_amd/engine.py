@@ -31,14 +31,14 @@ def _align(n):
 
 class TrainStep:
     def __init__(self, model, criterions, cfg, compute_dtype=torch.float32, bucket_mb=32.0, process_group=None,
-                 check_finite=True):
+                 check_finite=True, data_parallel=True):
         self.model, self.cfg = model, cfg
         self.criterion, self.criterion_depth, self.criterion_seg, _ = criterions
         self.compute_dtype = compute_dtype
         model.compute_dtype = compute_dtype
         self.check_finite = check_finite
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.world = dist.get_world_size(process_group) if (data_parallel and dist.is_available() and dist.is_initialized()) else 1
         self.step_count = 0
 
         named = dict(model.named_parameters())
@@ -179,8 +179,8 @@ class TrainStep:
         """Un-clipped global gradient norm of the last step (host sync)."""
         return math.sqrt(float(self.sq.item())) / self.world
 
-    def __call__(self, batch, taps=None):
-        """batch: dict(images (B,3,H,W), pad_mask (B,H,W) bool, depth (B,1,H,W), seg (B,1,H,W) i64, targets)."""
+    def forward_backward(self, batch, taps=None):
+        """Forward, losses, backward and (N > 1) the bucketed gradient all-reduce; leaves SUMMED grads in flat_g."""
         self.model.train()
         out = self.model(NestedTensor(batch["images"], batch["pad_mask"]), taps=taps)
         total, terms = self.losses(out, batch["depth"], batch["seg"], batch["targets"])
@@ -188,6 +188,11 @@ class TrainStep:
         self._begin_backward()
         total.backward()
         self._finish_backward()
+        return out, total, terms
+
+    def __call__(self, batch, taps=None):
+        """batch: dict(images (B,3,H,W), pad_mask (B,H,W) bool, depth (B,1,H,W), seg (B,1,H,W) i64, targets)."""
+        out, total, terms = self.forward_backward(batch, taps)
         self.optimizer_step()
         if self.check_finite:                       # engine_glassrgbd.py:143-153 (one host sync, after all launches)
             v = float(total.detach())

@@ -1,0 +1,48 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every entry point include/gwdepth.h declares
+(no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from gw_depth_amd import hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_entry_points():
+    text = open(os.path.join(ROOT, "include", "gwdepth.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gwd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    names = declared_entry_points()
+    assert len(names) >= 20
+    assert sorted(hip.ENTRY_POINTS) == names
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(hip.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    for name in declared_entry_points():
+        assert hasattr(lib, name), name
+    lib.gwd_arch.restype = ctypes.c_char_p
+    assert lib.gwd_version() == 1 and lib.gwd_arch() == b"gfx950"
+
+
+def test_code_object_targets_gfx950_only():
+    data = open(hip.LIB_PATH, "rb").read()
+    assert b"gfx950" in data and b"gfx942" not in data and b"gfx90a" not in data
+
+
+def test_compute_entry_points_refuse_cpu_tensors():
+    import torch
+    hip.set_library(None)
+    lib = hip.library()
+    x = torch.zeros(4, 8)
+    with pytest.raises(hip.HipUnavailable):
+        lib.softmax_forward(x, torch.empty_like(x), 4, 8)
