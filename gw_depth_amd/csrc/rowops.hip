@@ -213,6 +213,250 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ g, fl
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Vectorised LayerNorm: LPR lanes share one row, each lane owns NCH chunks of VEC = 16 bytes of channels, a wave
+// normalises 64/LPR rows at once (C = 64 bf16 -> 8 rows per wave, one 1 KiB coalesced load per instruction).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T> struct VecOf { static constexpr int N = 16 / sizeof(T); };
+
+template <typename T, int LPR, int NCH>
+__global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T *__restrict__ x, const float *__restrict__ gamma,
+                                                                const float *__restrict__ beta, T *__restrict__ y,
+                                                                float *__restrict__ mean, float *__restrict__ rstd,
+                                                                int64_t rows, int C, int gelu) {
+    constexpr int VEC = VecOf<T>::N, RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, sub = lane % LPR, rsel = lane / LPR;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    float g[NCH][VEC], b[NCH][VEC];
+    bool okc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int ch = (sub + c * LPR) * VEC;
+        okc[c] = ch < C;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            g[c][e] = (gamma && okc[c]) ? gamma[ch + e] : 1.f;
+            b[c][e] = (beta && okc[c]) ? beta[ch + e] : 0.f;
+        }
+    }
+    for (int64_t r0 = wave * RPW; r0 < rows; r0 += nw * RPW) {
+        const int64_t r = r0 + rsel;
+        const bool okr = r < rows;
+        float v[NCH][VEC];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+            if (okr && okc[c]) raw = *(const uint4 *)(x + r * C + (sub + c * LPR) * VEC);
+            const T *pv = (const T *)&raw;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                v[c][e] = to_f32(pv[e]);
+                s += v[c][e];
+            }
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mu = s / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float dlt = okc[c] ? v[c][e] - mu : 0.f;
+                q += dlt * dlt;
+            }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        const float rs = rsqrtf(q / (float)C + 1e-5f);
+        if (okr && sub == 0) {
+            mean[r] = mu;
+            rstd[r] = rs;
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (!(okr && okc[c])) continue;
+            T outv[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float o = (v[c][e] - mu) * rs * g[c][e] + b[c][e];
+                if (gelu) o = gelu_f(o);
+                outv[e] = from_f32<T>(o);
+            }
+            *(uint4 *)(y + r * C + (sub + c * LPR) * VEC) = *(const uint4 *)outv;
+        }
+    }
+}
+
+template <typename T, int LPR, int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T *__restrict__ gy, const T *__restrict__ x,
+                                                                const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                                T *__restrict__ gx, float *__restrict__ dgamma,
+                                                                float *__restrict__ dbeta, int64_t rows, int C, int gelu) {
+    constexpr int VEC = VecOf<T>::N, RPW = 64 / LPR;
+    __shared__ float red[2][4][LPR * NCH * VEC];      // [gamma|beta][wave][channel slot]
+    const int lane = threadIdx.x & 63, sub = lane % LPR, rsel = lane / LPR, wv = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nw = (int64_t)gridDim.x * 4;
+    float g[NCH][VEC], b[NCH][VEC], ag[NCH][VEC], ab[NCH][VEC];
+    bool okc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int ch = (sub + c * LPR) * VEC;
+        okc[c] = ch < C;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            g[c][e] = (gamma && okc[c]) ? gamma[ch + e] : 1.f;
+            b[c][e] = (beta && okc[c]) ? beta[ch + e] : 0.f;
+            ag[c][e] = ab[c][e] = 0.f;
+        }
+    }
+    for (int64_t r0 = wave * RPW; r0 < rows; r0 += nw * RPW) {
+        const int64_t r = r0 + rsel;
+        const bool okr = r < rows;
+        const float mu = okr ? mean[r] : 0.f, rs = okr ? rstd[r] : 0.f;
+        float xh[NCH][VEC], gw[NCH][VEC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            uint4 rx = make_uint4(0u, 0u, 0u, 0u), rg = make_uint4(0u, 0u, 0u, 0u);
+            const bool ok = okr && okc[c];
+            if (ok) {
+                rx = *(const uint4 *)(x + r * C + (sub + c * LPR) * VEC);
+                rg = *(const uint4 *)(gy + r * C + (sub + c * LPR) * VEC);
+            }
+            const T *px = (const T *)&rx;
+            const T *pg = (const T *)&rg;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                xh[c][e] = ok ? (to_f32(px[e]) - mu) * rs : 0.f;
+                float gg = ok ? to_f32(pg[e]) : 0.f;
+                if (gelu) gg *= gelu_grad_f(xh[c][e] * g[c][e] + b[c][e]);
+                ag[c][e] += gg * xh[c][e];
+                ab[c][e] += gg;
+                gw[c][e] = gg * g[c][e];
+                s1 += gw[c][e];
+                s2 += gw[c][e] * xh[c][e];
+            }
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) {
+            s1 += __shfl_xor(s1, o, 64);
+            s2 += __shfl_xor(s2, o, 64);
+        }
+        s1 /= (float)C;
+        s2 /= (float)C;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (!(okr && okc[c])) continue;
+            T outv[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) outv[e] = from_f32<T>(rs * (gw[c][e] - s1 - xh[c][e] * s2));
+            *(uint4 *)(gx + r * C + (sub + c * LPR) * VEC) = *(const uint4 *)outv;
+        }
+    }
+    if (dgamma) {
+        // rows of the wave (lanes with equal `sub`) -> one value per channel, then across the 4 waves through LDS
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+#pragma unroll
+                for (int o = LPR; o < 64; o <<= 1) {
+                    ag[c][e] += __shfl_xor(ag[c][e], o, 64);
+                    ab[c][e] += __shfl_xor(ab[c][e], o, 64);
+                }
+                if (rsel == 0) {
+                    red[0][wv][(c * LPR + sub) * VEC + e] = ag[c][e];
+                    red[1][wv][(c * LPR + sub) * VEC + e] = ab[c][e];
+                }
+            }
+        __syncthreads();
+        for (int t = threadIdx.x; t < LPR * NCH * VEC; t += 256) {
+            const int slot = t / VEC, e = t % VEC;
+            const int c = slot / LPR, sb = slot % LPR;
+            const int ch = (sb + c * LPR) * VEC + e;
+            if (ch < C) {
+                unsafeAtomicAdd(dgamma + ch, red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t]);
+                unsafeAtomicAdd(dbeta + ch, red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t]);
+            }
+        }
+    }
+}
+
+// out[c] += column sums, 16-byte vector loads: thread = (row slot, vector column); rows stride over the grid.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T *__restrict__ gmat, float *__restrict__ out, int64_t rows, int C) {
+    constexpr int VEC = VecOf<T>::N;
+    __shared__ float red[256 * VEC];
+    const int vpr = C / VEC;                 // vectors per row (<= 256)
+    const int rpb = 256 / vpr;               // row slots per block
+    const int slot = threadIdx.x / vpr, v = threadIdx.x % vpr;
+    float s[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+    if (slot < rpb) {
+        for (int64_t r = (int64_t)blockIdx.x * rpb + slot; r < rows; r += (int64_t)gridDim.x * rpb) {
+            const uint4 raw = *(const uint4 *)(gmat + r * C + v * VEC);
+            const T *p = (const T *)&raw;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s[e] += to_f32(p[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) red[threadIdx.x * VEC + e] = s[e];
+    __syncthreads();
+    for (int t = threadIdx.x; t < vpr * VEC; t += 256) {
+        const int vv = t / VEC, e = t % VEC;
+        float a = 0.f;
+        for (int sl = 0; sl < rpb; ++sl) a += red[(sl * vpr + vv) * VEC + e];
+        unsafeAtomicAdd(out + t, a);
+    }
+}
+
+template <typename T>
+int launch_ln_fwd_vec(const T *x, const float *ga, const float *be, T *y, float *mean, float *rstd, int64_t rows, int C, int gelu,
+                      hipStream_t s) {
+    constexpr int VEC = VecOf<T>::N;
+    const int need = C / VEC;
+#define LN_FWD(LPR, NCH)                                                                                            \
+    {                                                                                                               \
+        const int64_t wv = (rows + (64 / LPR) - 1) / (64 / LPR);                                                    \
+        layernorm_fwd_vec_kernel<T, LPR, NCH><<<row_grid(wv, 4), 256, 0, s>>>(x, ga, be, y, mean, rstd, rows, C, gelu); \
+        return 0;                                                                                                   \
+    }
+    if (need <= 8) LN_FWD(8, 1)
+    if (need <= 16) LN_FWD(16, 1)
+    if (need <= 32) LN_FWD(32, 1)
+    if (need <= 64) LN_FWD(64, 1)
+    if (need <= 128) LN_FWD(64, 2)
+#undef LN_FWD
+    return -5;
+}
+
+template <typename T>
+int launch_ln_bwd_vec(const T *gy, const T *x, const float *ga, const float *be, const float *mean, const float *rstd, T *gx,
+                      float *dg, float *db, int64_t rows, int C, int gelu, hipStream_t s) {
+    constexpr int VEC = VecOf<T>::N;
+    const int need = C / VEC;
+#define LN_BWD(LPR, NCH)                                                                                            \
+    {                                                                                                               \
+        const int64_t wv = (rows + (64 / LPR) - 1) / (64 / LPR);                                                    \
+        int grid = row_grid(wv, 4);                                                                                 \
+        if (grid > 768) grid = 768;                                                                                 \
+        layernorm_bwd_vec_kernel<T, LPR, NCH><<<grid, 256, 0, s>>>(gy, x, ga, be, mean, rstd, gx, dg, db, rows, C, gelu); \
+        return 0;                                                                                                   \
+    }
+    if (need <= 8) LN_BWD(8, 1)
+    if (need <= 16) LN_BWD(16, 1)
+    if (need <= 32) LN_BWD(32, 1)
+    if (need <= 64) LN_BWD(64, 1)
+    if (need <= 128) LN_BWD(64, 2)
+#undef LN_BWD
+    return -5;
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, CALL_BF16, CALL_F32) \
@@ -226,6 +470,13 @@ extern "C" int gwd_layernorm_forward(const void *x, const float *gamma, const fl
     if ((gamma == nullptr) != (beta == nullptr)) return -1;
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == GWD_BF16 && C % 8 == 0) {
+        int rc = launch_ln_fwd_vec<__bf16>((const __bf16 *)x, gamma, beta, (__bf16 *)y, mean, rstd, rows, C, gelu, s);
+        if (rc == 0) { GWD_CHECK_LAUNCH(); return 0; }
+    } else if (dtype == GWD_F32 && C % 4 == 0) {
+        int rc = launch_ln_fwd_vec<float>((const float *)x, gamma, beta, (float *)y, mean, rstd, rows, C, gelu, s);
+        if (rc == 0) { GWD_CHECK_LAUNCH(); return 0; }
+    }
     const int grid = row_grid(rows, 4);
     DISPATCH_T(dtype,
                (layernorm_fwd_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)x, gamma, beta, (__bf16 *)y, mean, rstd, rows, C, gelu)),
@@ -241,6 +492,13 @@ extern "C" int gwd_layernorm_backward(const void *gy, const void *x, const float
     if ((dgamma == nullptr) != (dbeta == nullptr)) return -1;
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == GWD_BF16 && C % 8 == 0) {
+        int rc = launch_ln_bwd_vec<__bf16>((const __bf16 *)gy, (const __bf16 *)x, gamma, beta, mean, rstd, (__bf16 *)gx, dgamma, dbeta, rows, C, gelu, s);
+        if (rc == 0) { GWD_CHECK_LAUNCH(); return 0; }
+    } else if (dtype == GWD_F32 && C % 4 == 0) {
+        int rc = launch_ln_bwd_vec<float>((const float *)gy, (const float *)x, gamma, beta, mean, rstd, (float *)gx, dgamma, dbeta, rows, C, gelu, s);
+        if (rc == 0) { GWD_CHECK_LAUNCH(); return 0; }
+    }
     int grid = row_grid(rows, 4);
     if (grid > 1024) grid = 1024;
     DISPATCH_T(dtype,
@@ -294,6 +552,18 @@ extern "C" int gwd_colsum(const void *g, float *out, int64_t rows, int32_t C, in
     if (!g || !out || rows < 0 || C <= 0) return -1;
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    {
+        const int vec = dtype == GWD_BF16 ? 8 : 4;
+        if (C % vec == 0 && C / vec <= 256 && (dtype == GWD_BF16 || dtype == GWD_F32)) {
+            const int rpb = 256 / (C / vec);
+            int64_t nb = (rows + (int64_t)rpb * 16 - 1) / ((int64_t)rpb * 16);     // >= 16 rows per row slot
+            const int grid = (int)(nb > 512 ? 512 : (nb < 1 ? 1 : nb));
+            if (dtype == GWD_BF16) colsum_vec_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)g, out, rows, C);
+            else colsum_vec_kernel<float><<<grid, 256, 0, s>>>((const float *)g, out, rows, C);
+            GWD_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     int64_t b = (rows + 63) / 64;
     const int grid = (int)(b > 512 ? 512 : (b < 1 ? 1 : b));
     DISPATCH_T(dtype, (colsum_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)g, out, rows, C)),

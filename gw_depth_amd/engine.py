@@ -71,6 +71,8 @@ class TrainStep:
             p.grad = self.flat_g[o:o + k].view(p.shape)
             if self.flat_p16 is not None:
                 p._gwd_bf16 = self.flat_p16[o:o + k].view(p.shape)
+            p._gwd_grad = p.grad          # kernels accumulate weight/bias/LN gradients straight into the flat buffer
+            p._gwd_hook = None
             self.params[n] = p
         if self.flat_p16 is not None:
             self.flat_p16.copy_(self.flat_p)
@@ -88,22 +90,26 @@ class TrainStep:
             self.buckets.append((start, off, members))
         self.live = None            # learned on the first step
         self._pending, self._works = None, []
+        self._expect = {}           # gradient contributions per parameter and step (a shared weight fires once per use)
         if self.world > 1:
             for bi, (_, _, mem) in enumerate(self.buckets):
                 for n in mem:
-                    self.params[n].register_post_accumulate_grad_hook(self._make_hook(bi, n))
+                    hook = self._make_hook(bi, n)
+                    self.params[n].register_post_accumulate_grad_hook(hook)     # gradients that arrive through autograd
+                    self.params[n]._gwd_hook = (lambda h=hook: h(None))          # gradients accumulated by the kernels
 
     # ------------------------------------------------------------------ DDP
     def _make_hook(self, bi, name):
         def hook(_p):
             if self._pending is None:
                 return
+            self._got[name] = self._got.get(name, 0) + 1
             if self.live is None:
                 self._seen.add(name)
             elif name not in self.live:            # a parameter that was dead on step 1 woke up
                 self.live.add(name)
                 self._late.append(name)
-            else:
+            elif self._got[name] == self._expect.get(name, 1):
                 self._pending[bi] -= 1
                 if self._pending[bi] == 0:
                     self._launch(self.buckets[bi][0], self.buckets[bi][1])
@@ -116,7 +122,7 @@ class TrainStep:
     def _begin_backward(self):
         if self.world == 1:
             return
-        self._works, self._late, self._launched = [], [], set()
+        self._works, self._late, self._launched, self._got = [], [], set(), {}
         if self.live is None:
             self._seen, self._pending = set(), [0] * len(self.buckets)
         else:
@@ -127,6 +133,7 @@ class TrainStep:
             return
         if self.live is None:                      # first step: no overlap, learn the live set
             self.live = set(self._seen)
+            self._expect = dict(self._got)
             for s, e, _ in self.buckets:
                 self._launch(s, e)
         else:

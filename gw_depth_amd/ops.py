@@ -45,7 +45,7 @@ class _ConvFn(torch.autograd.Function):
     """y = act_scale * act(conv(x, w * row_scale) + shift + residual), all in one kernel launch."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual, row_scale, shift_const, stride, pad, act, act_scale, virt, shadow):
+    def forward(ctx, x, w, bias, residual, row_scale, shift_const, stride, pad, act, act_scale, virt, shadow, sinks):
         lib = _lib()
         B, Hi, Wi, Cin = x.shape
         Cout, KH, KW, Cw = w.shape
@@ -70,6 +70,7 @@ class _ConvFn(torch.autograd.Function):
         lib.conv_forward(x, wk, y, dims, z=z, shift=shift, residual=residual, stride=stride, pad=pad, gather=gather,
                          virt=vv, act=act, act_scale=act_scale)
         ctx.cfg = (dims, stride, pad, act, act_scale, gather, vv, bias is not None, residual is not None)
+        ctx.sinks = sinks
         ctx.save_for_backward(x, w, row_scale, z if act == ACT_GELU else (y if act != ACT_NONE else None))
         return y
 
@@ -98,16 +99,28 @@ class _ConvFn(torch.autograd.Function):
                 gx = torch.empty_like(x)
                 lib.conv_forward(dv, wt, gx, (B, Ho, Wo, Cout, Hi, Wi, Cin, KH, KW), stride=stride, pad=pad,
                                  gather=GATHER_TRANSPOSED)
+        w_sink, b_sink = ctx.sinks if ctx.sinks is not None else (None, None)
         if ctx.needs_input_grad[1]:
-            gw = torch.zeros(w.shape, dtype=torch.float32, device=w.device)
-            lib.conv_wgrad(x, dv, gw, dims, stride=stride, pad=pad, gather=gather, virt=vv)
-            if row_scale is not None:
-                gw.mul_(row_scale.view(-1, 1, 1, 1))
+            if w_sink is not None and row_scale is None:
+                # the kernel ACCUMULATES (fp32 atomics): add straight into the flat gradient buffer, no temporary
+                lib.conv_wgrad(x, dv, w_sink[0], dims, stride=stride, pad=pad, gather=gather, virt=vv)
+                if w_sink[1] is not None:
+                    w_sink[1]()
+            else:
+                gw = torch.zeros(w.shape, dtype=torch.float32, device=w.device)
+                lib.conv_wgrad(x, dv, gw, dims, stride=stride, pad=pad, gather=gather, virt=vv)
+                if row_scale is not None:
+                    gw.mul_(row_scale.view(-1, 1, 1, 1))
         if has_bias and ctx.needs_input_grad[2]:
-            gb = torch.zeros(Cout, dtype=torch.float32, device=gy.device)
-            lib.colsum(dv, gb, rows, Cout)
+            if b_sink is not None:
+                lib.colsum(dv, b_sink[0], rows, Cout)
+                if b_sink[1] is not None:
+                    b_sink[1]()
+            else:
+                gb = torch.zeros(Cout, dtype=torch.float32, device=gy.device)
+                lib.colsum(dv, gb, rows, Cout)
         gres = dv if (has_res and ctx.needs_input_grad[3]) else None
-        return gx, gw, gb, gres, None, None, None, None, None, None, None, None
+        return gx, gw, gb, gres, None, None, None, None, None, None, None, None, None
 
 
 def _nearest_upsample_backward(gv, Hi, Wi):
@@ -123,13 +136,22 @@ def _nearest_upsample_backward(gv, Hi, Wi):
     return out.view(B, Hi, Wi, C).to(gv.dtype)
 
 
+def _sink(p, shape=None):
+    """(flat-gradient view, hook) of a parameter managed by engine.TrainStep, else None."""
+    g = getattr(p, "_gwd_grad", None)
+    if g is None:
+        return None
+    return (g if shape is None else g.view(shape), getattr(p, "_gwd_hook", None))
+
+
 def conv2d(x, w, bias=None, *, stride=1, pad=0, act=ACT_NONE, act_scale=1.0, residual=None, row_scale=None,
            shift=None, upsample_to=None):
     """x (B,H,W,Cin); w (Cout,KH,KW,Cin) fp32 master; bias fp32 parameter or None.
     row_scale / shift: constant per-Cout tensors of a folded FrozenBatchNorm.
     upsample_to=(Hv,Wv): convolve a nearest-upsampled view of x without materialising it."""
+    sinks = (_sink(w), _sink(bias) if bias is not None else None)
     return _ConvFn.apply(x, w, bias, residual, row_scale, shift, stride, pad, act, float(act_scale), upsample_to,
-                          getattr(w, "_gwd_bf16", None))
+                         getattr(w, "_gwd_bf16", None), sinks if (sinks[0] or sinks[1]) else None)
 
 
 def linear(x, w, bias=None, act=ACT_NONE):
@@ -138,15 +160,18 @@ def linear(x, w, bias=None, act=ACT_NONE):
     lead = x.shape[:-1]
     x2 = x.reshape(-1, 1, 1, K)
     shadow = getattr(w, "_gwd_bf16", None)
+    sinks = (_sink(w, (w.shape[0], 1, 1, K)), _sink(bias) if bias is not None else None)
     y = _ConvFn.apply(x2, w.view(w.shape[0], 1, 1, K), bias, None, None, None, 1, 0, act, 1.0, None,
-                      None if shadow is None else shadow.view(w.shape[0], 1, 1, K))
+                      None if shadow is None else shadow.view(w.shape[0], 1, 1, K),
+                      sinks if (sinks[0] or sinks[1]) else None)
     return y.view(*lead, w.shape[0])
 
 
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, gelu):
+    def forward(ctx, x, gamma, beta, gelu, sinks):
         lib = _lib()
+        ctx.sinks = sinks
         x = x.contiguous()
         C = x.shape[-1]
         rows = x.numel() // C
@@ -169,16 +194,28 @@ class _LayerNormFn(torch.autograd.Function):
         gy = gy.contiguous()
         gx = torch.empty_like(x)
         dg = db = None
-        if g is not None:
+        direct = ctx.sinks is not None
+        if direct:
+            (dg, h1), (db, h2) = ctx.sinks
+        elif g is not None:
             dg = torch.zeros(C, dtype=torch.float32, device=x.device)
             db = torch.zeros(C, dtype=torch.float32, device=x.device)
         lib.layernorm_backward(gy, x, g, b, mean, rstd, gx, dg, db, rows, C, ctx.gelu)
-        return gx, dg, db, None
+        if direct:
+            for h in (h1, h2):
+                if h is not None:
+                    h()
+            return gx, None, None, None, None
+        return gx, dg, db, None, None
 
 
 def layer_norm(x, gamma, beta, gelu=False):
     """LayerNorm over the last dim (eps 1e-5) with optional fused exact GELU."""
-    return _LayerNormFn.apply(x, gamma, beta, bool(gelu))
+    sinks = None
+    if gamma is not None:
+        sg, sb = _sink(gamma), _sink(beta)
+        sinks = (sg, sb) if (sg is not None and sb is not None) else None
+    return _LayerNormFn.apply(x, gamma, beta, bool(gelu), sinks)
 
 
 class _SoftmaxFn(torch.autograd.Function):
