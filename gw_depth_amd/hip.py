@@ -23,7 +23,8 @@ ENTRY_POINTS = [
     "gwd_colsum", "gwd_layernorm_forward", "gwd_layernorm_backward", "gwd_softmax_forward",
     "gwd_softmax_backward", "gwd_silog_sums", "gwd_silog_backward", "gwd_seg_ce_sum", "gwd_seg_ce_backward",
     "gwd_sqnorm", "gwd_adamw_step", "gwd_resample_forward", "gwd_resample_backward", "gwd_avgpool_forward",
-    "gwd_avgpool_backward", "gwd_winattn_forward", "gwd_winattn_backward",
+    "gwd_avgpool_backward", "gwd_winattn_forward", "gwd_winattn_backward", "gwd_tokattn_forward",
+    "gwd_tokattn_backward",
 ]
 
 
@@ -102,6 +103,8 @@ class HipLibrary:
         sp = ctypes.POINTER(Strided)
         L.gwd_winattn_forward.argtypes = [sp, sp, sp, sp, vp, vp, i64, i32, i32, i32, f32, i32, vp]
         L.gwd_winattn_backward.argtypes = [sp] * 7 + [vp, vp, vp, i64, i32, i32, i32, f32, i32, vp]
+        L.gwd_tokattn_forward.argtypes = [sp] * 4 + [i64, i32, i32, f32, i32, vp]
+        L.gwd_tokattn_backward.argtypes = [sp] * 7 + [i64, i32, i32, f32, i32, vp]
         L.gwd_sqnorm.argtypes = [vp, vp, i64, vp]
         L.gwd_adamw_step.argtypes = [vp, vp, vp, vp, vp, vp, i64] + [f32] * 9 + [vp]
 
@@ -219,6 +222,19 @@ class HipLibrary:
         self._check(self.lib.gwd_winattn_backward(*[ctypes.byref(x) for x in s], _ptr(bias), _ptr(dbias), _ptr(region), W,
                                                   wpi, H, D, scale, dtype_code(q), self._stream(q, go, gq)),
                     "gwd_winattn_backward")
+
+    def tokattn_forward(self, q, k, v, o, scale):
+        """q,o: (W,49,heads,4); k,v: (W,49,heads,e) tensors or views."""
+        W, N, H, _ = q.shape
+        s = [_strided(t) for t in (q, k, v, o)]
+        self._check(self.lib.gwd_tokattn_forward(*[ctypes.byref(x) for x in s], W, H, k.shape[3], scale, dtype_code(q),
+                                                 self._stream(q, k, v, o)), "gwd_tokattn_forward")
+
+    def tokattn_backward(self, q, k, v, go, gq, gk, gv, scale):
+        W, N, H, _ = q.shape
+        s = [_strided(t) for t in (q, k, v, go, gq, gk, gv)]
+        self._check(self.lib.gwd_tokattn_backward(*[ctypes.byref(x) for x in s], W, H, k.shape[3], scale, dtype_code(q),
+                                                  self._stream(q, go, gq)), "gwd_tokattn_backward")
 
     def sqnorm(self, g, sq, n):
         self._check(self.lib.gwd_sqnorm(_ptr(g), _ptr(sq), n, self._stream(g, sq)), "gwd_sqnorm")

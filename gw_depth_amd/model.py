@@ -403,14 +403,12 @@ class WindowClassAttention(WindowAttnBase):
         tdim = dtok.shape[-1]
         tx = torch.cat([x, dtok, stok], dim=-1)
         tC = tx.shape[-1]
-        tk = self.global_k(tx).reshape(B_, N, HEADS, tC // HEADS).permute(0, 2, 1, 3)
-        tv = self.global_v(tx).reshape(B_, N, HEADS, tC // HEADS).permute(0, 2, 1, 3)
+        tk = self.global_k(tx).view(B_, N, HEADS, tC // HEADS)
+        tv = self.global_v(tx).view(B_, N, HEADS, tC // HEADS)
 
-        def tok(q_lin, t):
-            qh = q_lin(t).reshape(B_, N, HEADS, tdim // HEADS).permute(0, 2, 3, 1) * self.scale   # (B_, nH, 4, N)
-            a = ops.softmax_lastdim(qh @ tk)                                                       # (B_, nH, 4, tC/16)
-            o = (a @ tv.transpose(-2, -1)).reshape(B_, -1, N).permute(0, 2, 1)
-            return self.proj_dth(o)                                                                # :572,578 (both!)
+        def tok(q_lin, t):                                   # :561-578; both tokens go through proj_dth
+            q = q_lin(t).view(B_, N, HEADS, tdim // HEADS)
+            return self.proj_dth(ops.token_attention(q, tk, tv, self.scale))
 
         return x, tok(self.cls_dth_q, dtok), tok(self.cls_seg_q, stok)
 

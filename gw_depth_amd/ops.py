@@ -416,3 +416,32 @@ def window_attention_packed(qkv, bias, region, windows_per_image, scale):
 
 def window_attention(q, k, v, bias, region, windows_per_image, scale):
     return _WinAttnFn.apply(q, k, v, bias, region, int(windows_per_image), float(scale))
+
+
+class _TokAttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        fix = lambda t: t if t.stride(3) == 1 else t.contiguous()
+        q, k, v = fix(q), fix(k), fix(v)
+        W, N, H, R = q.shape
+        out = torch.empty((W, N, H, R), dtype=q.dtype, device=q.device)
+        _lib().tokattn_forward(q, k, v, out, scale)
+        ctx.save_for_backward(q, k, v)
+        ctx.scale = scale
+        return out.view(W, N, H * R)
+
+    @staticmethod
+    def backward(ctx, go):
+        q, k, v = ctx.saved_tensors
+        W, N, H, R = q.shape
+        go = go.contiguous().view(W, N, H, R)
+        gq = torch.empty((W, N, H, R), dtype=q.dtype, device=q.device)
+        gk = torch.empty(k.shape, dtype=k.dtype, device=k.device)
+        gv = torch.empty(v.shape, dtype=v.dtype, device=v.device)
+        _lib().tokattn_backward(q, k, v, go, gq, gk, gv, ctx.scale)
+        return gq, gk, gv, None
+
+
+def token_attention(q, k, v, scale):
+    """Class-token attention: q (W,49,H,4), k/v (W,49,H,e) -> (W,49,4H); softmax over the e feature channels."""
+    return _TokAttnFn.apply(q, k, v, float(scale))

@@ -136,6 +136,15 @@ int gwd_winattn_backward(const gwd_strided *q, const gwd_strided *k, const gwd_s
                          float *dbias, const int32_t *region, int64_t n_windows, int32_t windows_per_image,
                          int32_t heads, int32_t head_dim, float scale, int32_t dtype, void *stream);
 
+/* Class-token attention of WindowClassAttention (src/models/multiscale_transformerr.py:560-578), per
+ * (window, head): A = softmax_c(scale * sum_n q[n][r] k[n][c]), o[n][r] = sum_c A[r][c] v[n][c]; 49 tokens n,
+ * r < 4, c < e with e in {12, 16, 24}.  q/o/gq are (W,49,heads,4) operands, k/v/gk/gv (W,49,heads,e).     */
+int gwd_tokattn_forward(const gwd_strided *q, const gwd_strided *k, const gwd_strided *v, const gwd_strided *o,
+                        int64_t n_windows, int32_t heads, int32_t e, float scale, int32_t dtype, void *stream);
+int gwd_tokattn_backward(const gwd_strided *q, const gwd_strided *k, const gwd_strided *v, const gwd_strided *go,
+                         const gwd_strided *gq, const gwd_strided *gk, const gwd_strided *gv, int64_t n_windows,
+                         int32_t heads, int32_t e, float scale, int32_t dtype, void *stream);
+
 /* Pixel-major resampling ([B][H][W][C]).  mode 0 = bilinear align_corners=True (PSP branches of
  * src/models/points/points_sample.py:114-121, CertainSample :293), mode 1 = legacy nearest
  * floor(dst*in/out) (src/models/multiscale_transformerr.py:1193,1230,1240,1267).  The backward kernels are

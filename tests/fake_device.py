@@ -225,3 +225,16 @@ class FakeDevice:
         gv.copy_(g[2])
         if dbias is not None:
             dbias.add_(g[3])
+
+    def tokattn_forward(self, q, k, v, o, scale):
+        a = F.softmax(torch.einsum("wnhr,wnhc->whrc", q.float(), k.float()) * scale, dim=-1)
+        o.copy_(torch.einsum("whrc,wnhc->wnhr", a, v.float()))
+
+    def tokattn_backward(self, q, k, v, go, gq, gk, gv, scale):
+        qf, kf, vf = (t.detach().float().clone().requires_grad_(True) for t in (q, k, v))
+        with torch.enable_grad():
+            a = F.softmax(torch.einsum("wnhr,wnhc->whrc", qf, kf) * scale, dim=-1)
+            g = torch.autograd.grad(torch.einsum("whrc,wnhc->wnhr", a, vf), [qf, kf, vf], go.float())
+        gq.copy_(g[0])
+        gk.copy_(g[1])
+        gv.copy_(g[2])

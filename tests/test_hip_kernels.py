@@ -295,3 +295,25 @@ def test_window_attention(dev, hd, nwin, wpi, shifted, dtype):
     for idx, name in enumerate(("dq", "dk", "dv")):
         assert rel(G[:, :, idx], g_r[:, :, idx]) < TOL[dtype], name
     assert rel(db, db_r) < TOL[dtype], "dbias"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("e,nwin", [(12, 40), (16, 9), (24, 3), (12, 3000)])
+def test_token_attention(dev, e, nwin, dtype):
+    fake = FakeDevice()
+    H = 16
+    q = rnd(nwin, 49, H, 4, dtype=dtype, seed=1)
+    kv = rnd(nwin, 49, 2, H, e, dtype=dtype, seed=2)          # k and v as strided views of one buffer
+    go = rnd(nwin, 49, H, 4, dtype=dtype, seed=3)
+    scale = 0.5
+    o_r = torch.empty_like(q)
+    fake.tokattn_forward(q, kv[:, :, 0], kv[:, :, 1], o_r, scale)
+    gq_r, gkv_r = torch.empty_like(q), torch.empty_like(kv)
+    fake.tokattn_backward(q, kv[:, :, 0], kv[:, :, 1], go, gq_r, gkv_r[:, :, 0], gkv_r[:, :, 1], scale)
+    Q, KV = q.cuda(), kv.cuda()
+    o = torch.full_like(o_r, float("nan")).cuda()
+    dev.tokattn_forward(Q, KV[:, :, 0], KV[:, :, 1], o, scale)
+    gq, gkv = torch.full_like(gq_r, float("nan")).cuda(), torch.full_like(gkv_r, float("nan")).cuda()
+    dev.tokattn_backward(Q, KV[:, :, 0], KV[:, :, 1], go.cuda(), gq, gkv[:, :, 0], gkv[:, :, 1], scale)
+    torch.cuda.synchronize()
+    assert rel(o, o_r) < TOL[dtype] and rel(gq, gq_r) < TOL[dtype] and rel(gkv, gkv_r) < TOL[dtype]
