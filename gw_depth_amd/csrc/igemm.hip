@@ -322,6 +322,235 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const gwd_conv_desc d) {
 }
 
 // ----------------------------------------------------------------------------------------------
+// forward / data gradient, LDS-DMA pipeline (bf16, Cin % 32 == 0)
+// ----------------------------------------------------------------------------------------------
+// Same tiling as igemm_fwd_kernel, but tiles travel HBM -> LDS with global_load_lds_dwordx4 (no VGPR staging, no
+// ds_write) through a ring of STAGES buffers: the gathers of tiles t+1 .. t+STAGES-1 are in flight while tile t
+// feeds the MFMAs, retired by a COUNTED s_waitcnt vmcnt(N) in front of one raw s_barrier per K step.  An LDS-DMA
+// wave instruction writes 64 x 16 B linearly (16 rows of 64 B), so the bank-conflict swizzle is applied to the
+// per-lane SOURCE address (chunk c of row r lands at position c ^ ((r >> 2) & 3)) and again on the fragment read.
+// Out-of-image taps / rows are fetched from a caller-provided zero page, which keeps every lane active.
+// GM: 0 = plain conv gather, 1 = transposed gather with stride 1 (data gradient of a stride-1 layer), 2 = any
+// (decided at run time): the two hot cases get a straight-line address path.
+template <int BN, int WM, int WN, int STAGES, int GM>
+__global__ __launch_bounds__(256) void igemm_dma_kernel(const gwd_conv_desc d) {
+    typedef __bf16 T;
+    constexpr int BM = 128, BK = 32;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_IT = 2;                              // 8 KiB A tile = 8 wave-instructions / 4 waves
+    constexpr int B_IT = (BN + 63) / 64;                 // B rows rounded up to 64 per pass (16 rows x 4 waves)
+    constexpr int BROWS = B_IT * 64;
+    constexpr int LOADS = A_IT + B_IT;                   // LDS-DMA instructions per wave and tile
+    constexpr int STAGE_BYTES = (BM + BROWS) * 64;
+    constexpr int EPI_BYTES = 4 * 32 * 36 * 4;
+    constexpr int SMEM = STAGES * STAGE_BYTES > EPI_BYTES ? STAGES * STAGE_BYTES : EPI_BYTES;
+    static_assert(WM * WN == 4, "4 waves");
+    __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+
+    const int M = d.B * d.Ho * d.Wo, N = d.Cout, K = d.KH * d.KW * d.Cin;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const T *x = (const T *)d.x;
+    const T *wgt = (const T *)d.w;
+    const char *zero = (const char *)d.zero_page;
+
+    // this lane's rows of the A tile (one per DMA instruction it issues) and its swizzled source chunk.
+    // p_h / p_w: the tap-independent part of the source coordinate (see src_pixel): ih = p_h + kh (plain and
+    // up-sampled gathers) or p_h - kh (transposed); a_pix = first pixel of the row's image.
+    int p_h[A_IT], p_w[A_IT], a_ck[A_IT];
+    size_t a_pix[A_IT];
+    bool a_ok[A_IT];
+    const int gmode = GM == 0 ? (int)GWD_GATHER_CONV : (GM == 1 ? (int)GWD_GATHER_TRANSPOSED : d.gather);
+    const int gstride = GM == 1 ? 1 : d.stride;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int row = 16 * (wave * A_IT + i) + (lane >> 2);
+        a_ck[i] = ((lane & 3) ^ ((row >> 2) & 3)) * 8;
+        const int m = m0 + row;
+        a_ok[i] = m < M;
+        const int mm = a_ok[i] ? m : 0;
+        const int b = mm / (d.Ho * d.Wo);
+        const int rem = mm - b * (d.Ho * d.Wo);
+        const int oh = rem / d.Wo, ow = rem - oh * d.Wo;
+        a_pix[i] = (size_t)b * d.Hi * d.Wi;
+        if (gmode == GWD_GATHER_CONV) {
+            p_h[i] = oh * d.stride - d.pad;
+            p_w[i] = ow * d.stride - d.pad;
+        } else if (gmode == GWD_GATHER_TRANSPOSED) {
+            p_h[i] = oh + d.pad;
+            p_w[i] = ow + d.pad;
+        } else {
+            p_h[i] = oh - d.pad;
+            p_w[i] = ow - d.pad;
+        }
+    }
+    const float up_sh = (float)d.Hi / (float)(d.Hv > 0 ? d.Hv : 1), up_sw = (float)d.Wi / (float)(d.Wv > 0 ? d.Wv : 1);
+    const char *b_src[B_IT];
+    bool b_ok[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int row = 16 * (wave * B_IT + i) + (lane >> 2);
+        const int ck = ((lane & 3) ^ ((row >> 2) & 3)) * 8;
+        const int n = n0 + row;
+        b_ok[i] = row < BN && n < N;
+        b_src[i] = (const char *)(wgt + (size_t)(b_ok[i] ? n : 0) * K + ck);
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int KT = K / BK;
+    int u_kh = 0, u_kw = 0, u_c0 = 0, u_kt = 0;          // filter tap of the next tile to issue (workgroup-uniform)
+    auto issue = [&](int stage) {
+        char *sb = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            int ih, iw;
+            bool ok;
+            if (gmode == GWD_GATHER_CONV) {                       // uniform branches, straight-line lanes
+                ih = p_h[i] + u_kh;
+                iw = p_w[i] + u_kw;
+                ok = ((unsigned)ih < (unsigned)d.Hi) & ((unsigned)iw < (unsigned)d.Wi);
+            } else if (gmode == GWD_GATHER_TRANSPOSED) {
+                const int th = p_h[i] - u_kh, tw = p_w[i] - u_kw;
+                if (gstride == 1) {
+                    ih = th;
+                    iw = tw;
+                    ok = ((unsigned)ih < (unsigned)d.Hi) & ((unsigned)iw < (unsigned)d.Wi);
+                } else {
+                    const int thc = th < 0 ? 0 : th, twc = tw < 0 ? 0 : tw;
+                    ih = thc / d.stride;
+                    iw = twc / d.stride;
+                    ok = (th >= 0) & (tw >= 0) & (ih * d.stride == th) & (iw * d.stride == tw) & (ih < d.Hi) & (iw < d.Wi);
+                }
+            } else {
+                const int vh = p_h[i] + u_kh, vw = p_w[i] + u_kw;
+                ok = ((unsigned)vh < (unsigned)d.Hv) & ((unsigned)vw < (unsigned)d.Wv);
+                ih = min((int)floorf((float)vh * up_sh), d.Hi - 1);
+                iw = min((int)floorf((float)vw * up_sw), d.Wi - 1);
+            }
+            ok = ok & a_ok[i];
+            const size_t off = (a_pix[i] + (size_t)(ok ? ih : 0) * d.Wi + (ok ? iw : 0)) * d.Cin + u_c0 + a_ck[i];
+            const char *src = ok ? (const char *)(x + off) : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(sb + (wave * A_IT + i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const char *src = b_ok[i] ? b_src[i] + (size_t)u_kt * (BK * 2) : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(sb + BM * 64 + (wave * B_IT + i) * 1024), 16, 0, 0);
+        }
+        ++u_kt;
+        u_c0 += BK;
+        if (u_c0 >= d.Cin) {
+            u_c0 = 0;
+            if (++u_kw == d.KW) {
+                u_kw = 0;
+                ++u_kh;
+            }
+        }
+    };
+    const int fr = lane & 31, fh = lane >> 5;
+    auto compute = [&](int stage) {
+        const T *As = (const T *)(smem + stage * STAGE_BYTES);
+        const T *Bs = (const T *)(smem + stage * STAGE_BYTES + BM * 64);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * (BM / WM) + i * 32 + fr;
+                af[i] = *(const bf16x8 *)(As + row * 32 + (((ks * 2 + fh) ^ ((row >> 2) & 3)) * 8));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn * (BN / WN) + j * 32 + fr;
+                bfr[j] = *(const bf16x8 *)(Bs + row * 32 + (((ks * 2 + fh) ^ ((row >> 2) & 3)) * 8));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mma(af[i], bfr[j], acc[i][j]);
+        }
+    };
+
+#pragma unroll
+    for (int t = 0; t < STAGES - 1; ++t)
+        if (t < KT) issue(t);
+    for (int kt = 0; kt < KT; ++kt) {
+        // tile kt has landed once at most (STAGES-2) newer tiles of this wave are still in flight
+        if (kt + STAGES - 2 < KT)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS * (STAGES - 2)) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                     // everybody's part of tile kt landed; compute(kt-1) is finished
+        if (kt + STAGES - 1 < KT) issue((kt + STAGES - 1) % STAGES);
+        compute(kt % STAGES);
+    }
+    __syncthreads();
+
+    // ---- epilogue (identical to igemm_fwd_kernel's vector path; N % 8 == 0 is a launch precondition)
+    T *y = (T *)d.y;
+    T *z = (T *)d.z;
+    const T *res = (const T *)d.residual;
+    float *stage = (float *)smem + wave * (32 * 36);
+    const int vr = lane >> 2, vc = (lane & 3) * 8;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * fh) * 36 + fr] = acc[i][j][r];
+            __builtin_amdgcn_wave_barrier();
+            const int nb = n0 + wn * (BN / WN) + j * 32 + vc;
+            if (nb < N) {
+                float sc[8], sh[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    sc[e] = d.scale ? d.scale[nb + e] : 1.0f;
+                    sh[e] = d.shift ? d.shift[nb + e] : 0.0f;
+                }
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int row = vr + 16 * half;
+                    const int m = m0 + wm * (BM / WM) + i * 32 + row;
+                    if (m >= M) continue;
+                    const f32x4 lo = *(const f32x4 *)(stage + row * 36 + vc);
+                    const f32x4 hi = *(const f32x4 *)(stage + row * 36 + vc + 4);
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    const size_t o = (size_t)m * N + nb;
+                    if (res) {
+                        const bf16x8 rv = *(const bf16x8 *)(res + o);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e] + (float)rv[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+                    }
+                    bf16x8 out;
+                    if (z) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) out[e] = (__bf16)v[e];
+                        *(bf16x8 *)(z + o) = out;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) out[e] = (__bf16)(apply_act(v[e], d.act) * d.act_scale);
+                    *(bf16x8 *)(y + o) = out;
+                }
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // weight gradient
 // ----------------------------------------------------------------------------------------------
 template <typename T, int BNW, int BKW>
@@ -530,11 +759,43 @@ int check_desc(const gwd_conv_desc *d) {
     return 0;
 }
 
+static bool dma_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GWD_IGEMM_DMA");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 template <typename T>
 int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
     const int M = d->B * d->Ho * d->Wo, N = d->Cout;
     constexpr int BK = Cfg<T>::BK;
     const unsigned gm = (M + 127) / 128;
+    if constexpr (sizeof(T) == 2) {
+        if (dma_enabled() && d->zero_page && (d->Cin % 32) == 0 && (N % 8) == 0) {
+            const int gmk = d->gather == GWD_GATHER_CONV ? 0 : ((d->gather == GWD_GATHER_TRANSPOSED && d->stride == 1) ? 1 : 2);
+#define DMA_LAUNCH(BN_, WM_, WN_, ST_, GRID)                                                         \
+    switch (gmk) {                                                                                    \
+        case 0: igemm_dma_kernel<BN_, WM_, WN_, ST_, 0><<<GRID, 256, 0, s>>>(*d); break;              \
+        case 1: igemm_dma_kernel<BN_, WM_, WN_, ST_, 1><<<GRID, 256, 0, s>>>(*d); break;              \
+        default: igemm_dma_kernel<BN_, WM_, WN_, ST_, 2><<<GRID, 256, 0, s>>>(*d); break;             \
+    }
+            if (N % 160 == 0) {
+                DMA_LAUNCH(160, 4, 1, 3, dim3(gm, N / 160))
+            } else if (N > 64) {
+                DMA_LAUNCH(128, 2, 2, 3, dim3(gm, (N + 127) / 128))
+            } else if (N > 32) {
+                DMA_LAUNCH(64, 2, 2, 4, dim3(gm, 1))
+            } else {
+                DMA_LAUNCH(32, 4, 1, 4, dim3(gm, 1))
+            }
+#undef DMA_LAUNCH
+            GWD_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (N % 160 == 0) {                       // 160 / 320 channel pyramids: exact tiles, no padded columns
         igemm_fwd_kernel<T, 128, 160, 4, 1, BK><<<dim3(gm, N / 160), 256, 0, s>>>(*d);
     } else if (N > 64) {

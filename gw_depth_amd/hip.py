@@ -34,7 +34,8 @@ class HipUnavailable(RuntimeError):
 
 class ConvDesc(ctypes.Structure):
     _fields_ = [("x", ctypes.c_void_p), ("w", ctypes.c_void_p), ("y", ctypes.c_void_p), ("z", ctypes.c_void_p),
-                ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("residual", ctypes.c_void_p)] + \
+                ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("residual", ctypes.c_void_p),
+                ("zero_page", ctypes.c_void_p)] + \
                [(n, ctypes.c_int32) for n in ("B", "Hi", "Wi", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad",
                                               "gather", "Hv", "Wv", "act")] + \
                [("act_scale", ctypes.c_float), ("dtype", ctypes.c_int32)]
@@ -49,6 +50,19 @@ def _strided(t):
     if t.dim() != 4 or t.stride(3) != 1:
         raise ValueError("window-attention operand must be (W, N, heads, hd) with unit last stride")
     return Strided(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
+
+
+_ZERO_PAGES = {}
+
+
+def _zero_page(device):
+    """256 zero bytes per device: the LDS-DMA convolution pipeline fetches out-of-image taps from here."""
+    if device.type != "cuda":
+        return None
+    z = _ZERO_PAGES.get(device)
+    if z is None:
+        z = _ZERO_PAGES[device] = torch.zeros(256, dtype=torch.uint8, device=device)
+    return ctypes.c_void_p(z.data_ptr())
 
 
 def dtype_code(t):
@@ -133,6 +147,7 @@ class HipLibrary:
         d = ConvDesc()
         d.x, d.w, d.y, d.z = _ptr(x), _ptr(w), _ptr(y), _ptr(z)
         d.scale, d.shift, d.residual = _ptr(scale), _ptr(shift), _ptr(residual)
+        d.zero_page = _zero_page(x.device)
         d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW = B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW
         d.stride, d.pad, d.gather, d.Hv, d.Wv = stride, pad, gather, virt[0], virt[1]
         d.act, d.act_scale, d.dtype = act, act_scale, dtype_code(x)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GWD_VERSION 1
+#define GWD_VERSION 2
 
 enum { GWD_F32 = 0, GWD_BF16 = 1 };
 enum { GWD_ACT_NONE = 0, GWD_ACT_RELU = 1, GWD_ACT_GELU = 2, GWD_ACT_ELU = 3, GWD_ACT_SIGMOID = 4 };
@@ -41,6 +41,8 @@ typedef struct {
     const float *scale;   /* optional per-Cout multiplier (FrozenBN scale)                      */
     const float *shift;   /* optional per-Cout addend (bias / FrozenBN shift)                   */
     const void *residual; /* optional [B][Ho][Wo][Cout] added before the activation             */
+    const void *zero_page;/* optional: >= 64 zero bytes of device memory.  Enables the LDS-DMA     */
+                          /* pipeline (out-of-image taps are fetched from it instead of branching) */
     int32_t B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
     int32_t gather;       /* GWD_GATHER_*                                                       */
     int32_t Hv, Wv;       /* virtual input size for GWD_GATHER_UPSAMPLED                        */
