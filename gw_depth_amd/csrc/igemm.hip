@@ -332,19 +332,20 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const gwd_conv_desc d) {
 // Out-of-image taps / rows are fetched from a caller-provided zero page, which keeps every lane active.
 // GM: 0 = plain conv gather, 1 = transposed gather with stride 1 (data gradient of a stride-1 layer), 2 = any
 // (decided at run time): the two hot cases get a straight-line address path.
-template <int BN, int WM, int WN, int STAGES, int GM>
-__global__ __launch_bounds__(256) void igemm_dma_kernel(const gwd_conv_desc d) {
+template <int BM, int BN, int WM, int WN, int STAGES, int GM>
+__global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_desc d) {
     typedef __bf16 T;
-    constexpr int BM = 128, BK = 32;
+    constexpr int BK = 32, NW = WM * WN;                 // 4 or 8 waves
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int A_IT = 2;                              // 8 KiB A tile = 8 wave-instructions / 4 waves
-    constexpr int B_IT = (BN + 63) / 64;                 // B rows rounded up to 64 per pass (16 rows x 4 waves)
-    constexpr int BROWS = B_IT * 64;
-    constexpr int LOADS = A_IT + B_IT;                   // LDS-DMA instructions per wave and tile
+    constexpr int A_IT = (BM / 16) / NW;                 // one wave-instruction moves 16 rows x 64 B
+    constexpr int B_INSTR = (BN + 15) / 16;              // wave w issues B instructions w, w+NW, ...
+    constexpr int B_IT = (B_INSTR + NW - 1) / NW;
+    constexpr int B_FULL = B_INSTR % NW;                 // waves below this index issue B_IT, the others B_IT-1 (0: all B_IT)
+    constexpr int BROWS = B_INSTR * 16;
     constexpr int STAGE_BYTES = (BM + BROWS) * 64;
-    constexpr int EPI_BYTES = 4 * 32 * 36 * 4;
+    constexpr int EPI_BYTES = NW * 32 * 36 * 4;
     constexpr int SMEM = STAGES * STAGE_BYTES > EPI_BYTES ? STAGES * STAGE_BYTES : EPI_BYTES;
-    static_assert(WM * WN == 4, "4 waves");
+    static_assert((BM / 16) % NW == 0 && TM >= 1 && TN >= 1, "tile / wave layout");
     __shared__ __attribute__((aligned(1024))) char smem[SMEM];
 
     const int M = d.B * d.Ho * d.Wo, N = d.Cout, K = d.KH * d.KW * d.Cin;
@@ -388,9 +389,10 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const gwd_conv_desc d) {
     const float up_sh = (float)d.Hi / (float)(d.Hv > 0 ? d.Hv : 1), up_sw = (float)d.Wi / (float)(d.Wv > 0 ? d.Wv : 1);
     const char *b_src[B_IT];
     bool b_ok[B_IT];
+    const int my_b_loads = (B_FULL == 0 || wave < B_FULL) ? B_IT : B_IT - 1;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-        const int row = 16 * (wave * B_IT + i) + (lane >> 2);
+        const int row = 16 * (wave + i * NW) + (lane >> 2);
         const int ck = ((lane & 3) ^ ((row >> 2) & 3)) * 8;
         const int n = n0 + row;
         b_ok[i] = row < BN && n < N;
@@ -443,9 +445,11 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const gwd_conv_desc d) {
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const char *src = b_ok[i] ? b_src[i] + (size_t)u_kt * (BK * 2) : zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(sb + BM * 64 + (wave * B_IT + i) * 1024), 16, 0, 0);
+            if (i < my_b_loads) {                                 // wave-uniform
+                const char *src = b_ok[i] ? b_src[i] + (size_t)u_kt * (BK * 2) : zero;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(sb + BM * 64 + (wave + i * NW) * 1024), 16, 0, 0);
+            }
         }
         ++u_kt;
         u_c0 += BK;
@@ -486,10 +490,14 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const gwd_conv_desc d) {
         if (t < KT) issue(t);
     for (int kt = 0; kt < KT; ++kt) {
         // tile kt has landed once at most (STAGES-2) newer tiles of this wave are still in flight
-        if (kt + STAGES - 2 < KT)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS * (STAGES - 2)) : "memory");
-        else
+        if (kt + STAGES - 2 < KT) {
+            if (my_b_loads == B_IT)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A_IT + B_IT) * (STAGES - 2)) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A_IT + B_IT - 1) * (STAGES - 2)) : "memory");
+        } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();                     // everybody's part of tile kt landed; compute(kt-1) is finished
         if (kt + STAGES - 1 < KT) issue((kt + STAGES - 1) % STAGES);
         compute(kt % STAGES);
@@ -759,6 +767,15 @@ int check_desc(const gwd_conv_desc *d) {
     return 0;
 }
 
+static bool big_tiles_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GWD_IGEMM_BIG");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 static bool dma_enabled() {
     static int v = -1;
     if (v < 0) {
@@ -776,20 +793,22 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         if (dma_enabled() && d->zero_page && (d->Cin % 32) == 0 && (N % 8) == 0) {
             const int gmk = d->gather == GWD_GATHER_CONV ? 0 : ((d->gather == GWD_GATHER_TRANSPOSED && d->stride == 1) ? 1 : 2);
-#define DMA_LAUNCH(BN_, WM_, WN_, ST_, GRID)                                                         \
-    switch (gmk) {                                                                                    \
-        case 0: igemm_dma_kernel<BN_, WM_, WN_, ST_, 0><<<GRID, 256, 0, s>>>(*d); break;              \
-        case 1: igemm_dma_kernel<BN_, WM_, WN_, ST_, 1><<<GRID, 256, 0, s>>>(*d); break;              \
-        default: igemm_dma_kernel<BN_, WM_, WN_, ST_, 2><<<GRID, 256, 0, s>>>(*d); break;             \
+#define DMA_LAUNCH(BM_, BN_, WM_, WN_, ST_, GRID)                                                              \
+    switch (gmk) {                                                                                              \
+        case 0: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 0><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d); break;       \
+        case 1: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 1><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d); break;       \
+        default: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 2><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d); break;      \
     }
+            const bool big = big_tiles_enabled() && M >= 256 * 512;      // >= 2 workgroups per CU with 256-row tiles
+            const unsigned gm2 = (M + 255) / 256;
             if (N % 160 == 0) {
-                DMA_LAUNCH(160, 4, 1, 3, dim3(gm, N / 160))
+                if (big) { DMA_LAUNCH(256, 160, 8, 1, 3, dim3(gm2, N / 160)) } else { DMA_LAUNCH(128, 160, 4, 1, 3, dim3(gm, N / 160)) }
             } else if (N > 64) {
-                DMA_LAUNCH(128, 2, 2, 3, dim3(gm, (N + 127) / 128))
+                if (big) { DMA_LAUNCH(256, 128, 4, 2, 3, dim3(gm2, (N + 127) / 128)) } else { DMA_LAUNCH(128, 128, 2, 2, 3, dim3(gm, (N + 127) / 128)) }
             } else if (N > 32) {
-                DMA_LAUNCH(64, 2, 2, 4, dim3(gm, 1))
+                DMA_LAUNCH(128, 64, 2, 2, 4, dim3(gm, 1))
             } else {
-                DMA_LAUNCH(32, 4, 1, 4, dim3(gm, 1))
+                DMA_LAUNCH(128, 32, 4, 1, 4, dim3(gm, 1))
             }
 #undef DMA_LAUNCH
             GWD_CHECK_LAUNCH();
