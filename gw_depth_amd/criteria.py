@@ -31,12 +31,39 @@ class HungarianMatcherLine(nn.Module):
         C = self.cost_line * torch.cdist(lines, tgt_lines, p=1) + self.cost_class * (-prob[:, tgt_ids])
         return C.view(B, Q, -1)
 
+    @staticmethod
+    def _solve(C, sizes):
+        res = [linear_sum_assignment(c[i]) for i, c in enumerate(C.split(sizes, -1))]
+        return [(torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)) for i, j in res]
+
     @torch.no_grad()
     def forward(self, outputs, targets):
         C = self.cost_matrix(outputs, targets).cpu()
-        sizes = [len(t["lines"]) for t in targets]
-        res = [linear_sum_assignment(c[i]) for i, c in enumerate(C.split(sizes, -1))]
-        return [(torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)) for i, j in res]
+        return self._solve(C, [len(t["lines"]) for t in targets])
+
+    @torch.no_grad()
+    def prefetch(self, layer_outputs, targets):
+        """Cost matrices of ALL decoder layers in one go, copied to pinned host memory asynchronously.  Called by the
+        model right after the DETR branch, so the single device->host hand-off overlaps the whole dense branch
+        instead of draining the GPU six times per step (the reference syncs in every matcher call, matcher.py:71)."""
+        Cs = torch.stack([self.cost_matrix(o, targets) for o in layer_outputs])          # (layers, B, Q, sum T)
+        if Cs.is_cuda:
+            host = torch.empty(Cs.shape, dtype=Cs.dtype, pin_memory=True)
+            host.copy_(Cs, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            host, ev = Cs, None
+        return {"host": host, "event": ev, "sizes": [len(t["lines"]) for t in targets], "next": 0}
+
+    def from_prefetch(self, handle):
+        """Assignment of the next decoder layer (order: final layer first, then aux 0..4) from a prefetch handle."""
+        if handle["event"] is not None:
+            handle["event"].synchronize()
+            handle["event"] = None
+        i = handle["next"]
+        handle["next"] += 1
+        return self._solve(handle["host"][i], handle["sizes"])
 
 
 class SetCriterion(nn.Module):
@@ -56,8 +83,8 @@ class SetCriterion(nn.Module):
         b = torch.cat([torch.full_like(s, i) for i, (s, _) in enumerate(indices)])
         return b, torch.cat([s for s, _ in indices])
 
-    def _one(self, out, targets, num_items, suffix):
-        idx = self.matcher(out, targets)
+    def _one(self, out, targets, num_items, suffix, handle=None):
+        idx = self.matcher.from_prefetch(handle) if handle is not None else self.matcher(out, targets)
         self.last_indices.append(idx)
         dev = out["pred_logits"].device
         bi, si = self._src_idx(idx)
@@ -77,9 +104,10 @@ class SetCriterion(nn.Module):
             torch.distributed.all_reduce(n)
             world = torch.distributed.get_world_size()
         num_items = torch.clamp(n / world, min=1).item()
-        losses = self._one({k: v for k, v in outputs.items() if k != "aux_outputs"}, targets, num_items, "")
+        handle = outputs.get("_match_prefetch") if hasattr(self.matcher, "from_prefetch") else None
+        losses = self._one({k: v for k, v in outputs.items() if k != "aux_outputs"}, targets, num_items, "", handle)
         for i, aux in enumerate(outputs.get("aux_outputs", [])):
-            losses.update(self._one(aux, targets, num_items, f"_{i}"))
+            losses.update(self._one(aux, targets, num_items, f"_{i}", handle))
         return losses
 
 

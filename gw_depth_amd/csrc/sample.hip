@@ -1,0 +1,166 @@
+// CertainSample on the device (src/models/points/points_sample.py:291-364) — no host round trip.
+// One workgroup per image: variance map = (bilinear_align_corners(pred_small) - pred_large)^2 in LDS, per-interval
+// pixel counts n_i, k_i = min(floor(fl32(n_i / HW) * S), n_i) in IEEE fp32 exactly as the CPU reference evaluates
+// it, the top-max(k_i) pixels of the WHOLE variance map by repeated block-wide arg-max (ties -> lowest index, i.e.
+// a stable descending order), then the reference's group / repeat / trim rules and the (x/W, y/H)*2-1 coordinates.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_PIX = 8192, MAX_S = 256, MAX_INT = 8, THREADS = 256;
+
+__global__ __launch_bounds__(THREADS) void certain_sample_kernel(const float *__restrict__ small, const float *__restrict__ large,
+                                                                  float *__restrict__ coords, int hs, int ws, int H, int W,
+                                                                  const float *__restrict__ edges, int n_int, int S) {
+    __shared__ float var[MAX_PIX];
+    __shared__ int order[MAX_S];            // top pixels, descending variance
+    __shared__ int outidx[4 * MAX_S];
+    __shared__ int cnt[MAX_INT];
+    __shared__ float red_v[THREADS / 64];
+    __shared__ int red_i[THREADS / 64];
+    __shared__ int kk[MAX_INT];
+    const int b = blockIdx.x, tid = threadIdx.x, HW = H * W;
+    const float *sm = small + (size_t)b * hs * ws;
+    const float *lg = large + (size_t)b * HW;
+    if (tid < MAX_INT) cnt[tid] = 0;
+    __syncthreads();
+    const float sh = H > 1 ? (float)(hs - 1) / (float)(H - 1) : 0.f, sw = W > 1 ? (float)(ws - 1) / (float)(W - 1) : 0.f;
+    int local[MAX_INT];
+#pragma unroll
+    for (int i = 0; i < MAX_INT; ++i) local[i] = 0;
+    for (int p = tid; p < HW; p += THREADS) {
+        const int y = p / W, x = p - y * W;
+        const float fy = sh * y, fx = sw * x;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < hs - 1), x1 = x0 + (x0 < ws - 1);
+        const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+        const float up = hy * (hx * sm[y0 * ws + x0] + lx * sm[y0 * ws + x1]) + ly * (hx * sm[y1 * ws + x0] + lx * sm[y1 * ws + x1]);
+        const float l = lg[p];
+        const float dlt = up - l;
+        var[p] = dlt * dlt;
+#pragma unroll
+        for (int i = 0; i < MAX_INT; ++i)
+            if (i < n_int && l >= edges[i] && l < edges[i + 1]) local[i]++;
+    }
+#pragma unroll
+    for (int i = 0; i < MAX_INT; ++i)
+        if (i < n_int && local[i]) atomicAdd(&cnt[i], local[i]);
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 0; i < n_int; ++i) {
+            const float n = (float)cnt[i];
+            const float k = floorf(__fmul_rn(__fdiv_rn(n, (float)HW), (float)S));
+            kk[i] = (int)fminf(k, n);
+        }
+    }
+    __syncthreads();
+    int kmax = 0, total = 0;
+    for (int i = 0; i < n_int; ++i) {
+        kmax = max(kmax, kk[i]);
+        total += kk[i];
+    }
+    if (total == 0) kmax = S;                     // "sample globally when no interval points found" (:331-339)
+    // ---- top-kmax by repeated arg-max, ties to the lowest pixel index
+    for (int r = 0; r < kmax; ++r) {
+        float bv = -1.f;
+        int bi = 0x7fffffff;
+        for (int p = tid; p < HW; p += THREADS) {
+            const float v = var[p];
+            if (v > bv) {
+                bv = v;
+                bi = p;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if ((tid & 63) == 0) {
+            red_v[tid >> 6] = bv;
+            red_i[tid >> 6] = bi;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int wv = 1; wv < THREADS / 64; ++wv)
+                if (red_v[wv] > bv || (red_v[wv] == bv && red_i[wv] < bi)) {
+                    bv = red_v[wv];
+                    bi = red_i[wv];
+                }
+            order[r] = bi;
+            var[bi] = -2.f;                       // taken (variances are >= 0)
+        }
+        __syncthreads();
+    }
+    // ---- group assembly (serial: <= a few hundred integers)
+    if (tid == 0) {
+        int n_out = 0;
+        auto emit_sorted_prefix = [&](int k, int at) {      // ascending pixel index of the k best (:320,335)
+            for (int a = 0; a < k; ++a) {
+                int rank = 0;
+                for (int c = 0; c < k; ++c) rank += order[c] < order[a];
+                outidx[at + rank] = order[a];
+            }
+        };
+        int gstart[MAX_INT], gcount[MAX_INT], ng = 0;
+        if (total > 0) {
+            for (int i = 0; i < n_int; ++i)
+                if (kk[i] > 0) {
+                    gstart[ng] = n_out;
+                    gcount[ng] = kk[i];
+                    emit_sorted_prefix(kk[i], n_out);
+                    n_out += kk[i];
+                    ++ng;
+                }
+        } else {
+            emit_sorted_prefix(S, 0);
+            n_out = S;
+        }
+        int remain = total > 0 ? S - total : 0;
+        const int already = total;
+        if (remain > 0 && remain >= already) {              // :343-346 repeat the whole list
+            const int times = remain / already + 1;
+            for (int t = 1; t < times; ++t)
+                for (int a = 0; a < already; ++a) outidx[t * already + a] = outidx[a];
+            n_out = already * times;
+            remain = S - n_out;
+        }
+        if (remain > 0) {                                    // :348-350 complement with the tail
+            for (int a = 0; a < remain; ++a) outidx[n_out + a] = outidx[n_out - remain + a];
+            n_out += remain;
+        }
+        if (remain < 0) {                                    // :351-355 trim the largest group (first on ties)
+            int mid = 0;
+            for (int gi = 1; gi < ng; ++gi)
+                if (gcount[gi] > gcount[mid]) mid = gi;
+            const int cut = -remain;                         // drop the last `cut` entries of group mid
+            const int from = gstart[mid] + gcount[mid];
+            for (int a = from; a < n_out; ++a) outidx[a - cut] = outidx[a];
+            n_out -= cut;
+        }
+        for (int a = 0; a < S; ++a) {
+            const int p = outidx[a];
+            const int row = p / W, col = p - row * W;
+            coords[((size_t)b * S + a) * 2 + 0] = __fdiv_rn((float)col, (float)W) * 2.f - 1.f;
+            coords[((size_t)b * S + a) * 2 + 1] = __fdiv_rn((float)row, (float)H) * 2.f - 1.f;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int gwd_certain_sample(const float *pred_small, const float *pred_large, float *coords, int32_t B, int32_t hs,
+                                  int32_t ws, int32_t H, int32_t W, const float *edges, int32_t n_intervals,
+                                  int32_t sample_num, void *stream) {
+    if (!pred_small || !pred_large || !coords || !edges || B <= 0 || hs <= 0 || ws <= 0 || H <= 0 || W <= 0) return -1;
+    if (H * W > MAX_PIX || sample_num <= 0 || sample_num > MAX_S || n_intervals <= 0 || n_intervals > MAX_INT) return -4;
+    if (sample_num > H * W) return -4;
+    certain_sample_kernel<<<B, THREADS, 0, (hipStream_t)stream>>>(pred_small, pred_large, coords, hs, ws, H, W, edges,
+                                                                  n_intervals, sample_num);
+    GWD_CHECK_LAUNCH();
+    return 0;
+}

@@ -189,7 +189,8 @@ class TrainStep:
     def forward_backward(self, batch, taps=None):
         """Forward, losses, backward and (N > 1) the bucketed gradient all-reduce; leaves SUMMED grads in flat_g."""
         self.model.train()
-        out = self.model(NestedTensor(batch["images"], batch["pad_mask"]), taps=taps)
+        match = (self.criterion.matcher, batch["targets"]) if hasattr(self.criterion.matcher, "prefetch") else None
+        out = self.model(NestedTensor(batch["images"], batch["pad_mask"]), taps=taps, match=match)
         total, terms = self.losses(out, batch["depth"], batch["seg"], batch["targets"])
         self.zero_grad()
         self._begin_backward()

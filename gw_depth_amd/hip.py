@@ -24,7 +24,7 @@ ENTRY_POINTS = [
     "gwd_softmax_backward", "gwd_silog_sums", "gwd_silog_backward", "gwd_seg_ce_sum", "gwd_seg_ce_backward",
     "gwd_sqnorm", "gwd_adamw_step", "gwd_resample_forward", "gwd_resample_backward", "gwd_avgpool_forward",
     "gwd_avgpool_backward", "gwd_winattn_forward", "gwd_winattn_backward", "gwd_tokattn_forward",
-    "gwd_tokattn_backward",
+    "gwd_tokattn_backward", "gwd_certain_sample",
 ]
 
 
@@ -119,6 +119,7 @@ class HipLibrary:
         L.gwd_winattn_backward.argtypes = [sp] * 7 + [vp, vp, vp, i64, i32, i32, i32, f32, i32, vp]
         L.gwd_tokattn_forward.argtypes = [sp] * 4 + [i64, i32, i32, f32, i32, vp]
         L.gwd_tokattn_backward.argtypes = [sp] * 7 + [i64, i32, i32, f32, i32, vp]
+        L.gwd_certain_sample.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp]
         L.gwd_sqnorm.argtypes = [vp, vp, i64, vp]
         L.gwd_adamw_step.argtypes = [vp, vp, vp, vp, vp, vp, i64] + [f32] * 9 + [vp]
 
@@ -250,6 +251,14 @@ class HipLibrary:
         s = [_strided(t) for t in (q, k, v, go, gq, gk, gv)]
         self._check(self.lib.gwd_tokattn_backward(*[ctypes.byref(x) for x in s], W, H, k.shape[3], scale, dtype_code(q),
                                                   self._stream(q, go, gq)), "gwd_tokattn_backward")
+
+    def certain_sample(self, small, large, coords, edges, sample_num):
+        """small (B,1,hs,ws), large (B,1,H,W) fp32; edges (I+1,) fp32; coords (B,S,1,2) fp32 out."""
+        B, _, hs, ws = small.shape
+        H, W = large.shape[-2:]
+        self._check(self.lib.gwd_certain_sample(_ptr(small), _ptr(large), _ptr(coords), B, hs, ws, H, W, _ptr(edges),
+                                                edges.numel() - 1, sample_num, self._stream(small, large, coords)),
+                    "gwd_certain_sample")
 
     def sqnorm(self, g, sq, n):
         self._check(self.lib.gwd_sqnorm(_ptr(g), _ptr(sq), n, self._stream(g, sq)), "gwd_sqnorm")

@@ -575,49 +575,24 @@ class PointBasedPred(nn.Module):
 
 @torch.no_grad()
 def certain_sample(pred_small, pred_large, interval, sample_num, min_depth):
-    """CertainSample.forward, points_sample.py:291-364: interval histogram decides HOW MANY points,
-    every top-k is over the whole variance map; integer coordinates, no gradient."""
-    B, _, H, W = pred_large.shape
-    small = F.interpolate(pred_small, size=(H, W), mode="bilinear", align_corners=True)
-    var = ((small - pred_large) ** 2).flatten(1)
-    edges = torch.tensor([min_depth] + list(interval) + [1.0], device=pred_large.device, dtype=pred_large.dtype)
-    flat = pred_large.flatten(1)
-    n_i = ((flat[:, None, :] >= edges[:-1, None]) & (flat[:, None, :] < edges[1:, None])).sum(-1)       # (B, I)
-    # k_i = min(floor(n_i / HW * S), n_i) in IEEE fp32 exactly as the CPU reference evaluates it.  Done on the host
-    # (n_i is needed there anyway): a device-side `tensor / python_scalar` multiplies by the rounded reciprocal,
-    # which turns 1200/1200*30 into 29.999998 and floors to 29 — one sample fewer than the reference.
-    import numpy as np
-    n_host = np.asarray(n_i.tolist(), dtype=np.int64)                                                    # one host sync
-    k_host = np.floor(n_host.astype(np.float32) / np.float32(H * W) * np.float32(sample_num))
-    k_i = np.minimum(k_host, n_host.astype(np.float32)).astype(np.int64).tolist()
-    order = torch.argsort(var, dim=1, descending=True, stable=True)                                       # lowest index wins ties
-    outs = []
-    for b in range(B):
-        groups = [order[b, :k].sort()[0] for k in k_i[b] if k > 0]
-        counts = [int(g.numel()) for g in groups]
-        already = sum(counts)
-        if groups:
-            cat = torch.cat(groups)
-            remain = sample_num - already
-        else:
-            cat = order[b, :sample_num].sort()[0]
-            remain = 0
-        if remain > 0 and remain >= already:
-            times = remain // already + 1
-            cat = cat.repeat(times)
-            remain = sample_num - already * times
-        if remain > 0:
-            cat = torch.cat([cat, cat[-remain:]])
-        if remain < 0:
-            mid = max(range(len(counts)), key=lambda i: (counts[i], -i))
-            groups[mid] = groups[mid][:remain]
-            cat = torch.cat(groups)
-        outs.append(cat)
-    idx = torch.stack(outs)
-    col, row = (idx % W).float(), torch.div(idx, W, rounding_mode="floor").float()
-    # tensor / tensor is an IEEE division on the device; tensor / python_scalar multiplies by 1/W (1 ulp off the CPU path)
-    wt, ht = torch.full_like(col, float(W)), torch.full_like(row, float(H))
-    return torch.stack([(col / wt) * 2 - 1, (row / ht) * 2 - 1], dim=-1)[:, :, None]
+    """CertainSample.forward, points_sample.py:291-364, as ONE device kernel (no host round trip): the interval
+    histogram decides HOW MANY points, every top-k is over the whole variance map; integer-valued, no gradient.
+    pred_small (B,1,hs,ws), pred_large (B,1,H,W) fp32 -> (B, S, 1, 2) normalised coordinates."""
+    B = pred_large.shape[0]
+    edges = _edges(tuple([min_depth] + list(interval) + [1.0]), pred_large.device)
+    coords = torch.empty((B, sample_num, 1, 2), dtype=torch.float32, device=pred_large.device)
+    ops.hip.library().certain_sample(pred_small.float().contiguous(), pred_large.float().contiguous(), coords, edges, sample_num)
+    return coords
+
+
+_EDGE_CACHE = {}
+
+
+def _edges(values, device):
+    key = (values, str(device))
+    if key not in _EDGE_CACHE:
+        _EDGE_CACHE[key] = torch.tensor(values, dtype=torch.float32, device=device)
+    return _EDGE_CACHE[key]
 
 
 # ------------------------------------------------------------------------------------ dense encoder
@@ -783,7 +758,7 @@ class GlassRGBD(nn.Module):
         self.depth_decoder = DensePrediction(cfg.max_depth, cfg.class_token_dim)
         self.compute_dtype = torch.float32
 
-    def forward(self, samples, reflc_points=None, reflc_mat=None, img_name=None, taps=None):
+    def forward(self, samples, reflc_points=None, reflc_mat=None, img_name=None, taps=None, match=None):
         if isinstance(samples, (list, torch.Tensor)):
             samples = nested_tensor_from_tensor_list(samples)
         images, pad_mask = samples.decompose()
@@ -799,6 +774,9 @@ class GlassRGBD(nn.Module):
         out = {"pred_logits": logits[-1], "pred_lines": lines[-1]}
         if self.aux_loss:
             out["aux_outputs"] = [{"pred_logits": a, "pred_lines": b} for a, b in zip(logits[:-1], lines[:-1])]
+        if match is not None:      # (matcher, targets): start the Hungarian hand-off now, consume it in the criterion
+            matcher, targets = match
+            out["_match_prefetch"] = matcher.prefetch([out] + out.get("aux_outputs", []), targets)
         dense_in = ops.conv2d(src, self.dense_input_proj.weight, self.dense_input_proj.bias)
         feat4, dtok, stok, depths = self.dense_encoder(dense_in, feats, masks, out["pred_lines"], out["pred_logits"], taps)
         depth, seg = self.depth_decoder(feat4, depths[-1], dtok, stok, (H, W))

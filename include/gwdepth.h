@@ -147,6 +147,13 @@ int gwd_tokattn_backward(const gwd_strided *q, const gwd_strided *k, const gwd_s
                          const gwd_strided *gq, const gwd_strided *gk, const gwd_strided *gv, int64_t n_windows,
                          int32_t heads, int32_t e, float scale, int32_t dtype, void *stream);
 
+/* CertainSample entirely on the device (src/models/points/points_sample.py:291-364): pred_small [B][hs][ws],
+ * pred_large [B][H][W] fp32 sigmoid maps, edges[n_intervals+1] fp32 interval bounds -> coords [B][S][2] fp32
+ * ((x/W)*2-1, (y/H)*2-1).  Integer-valued selection; bit-exact against the CPU reference on identical operands. */
+int gwd_certain_sample(const float *pred_small, const float *pred_large, float *coords, int32_t B, int32_t hs,
+                       int32_t ws, int32_t H, int32_t W, const float *edges, int32_t n_intervals,
+                       int32_t sample_num, void *stream);
+
 /* Pixel-major resampling ([B][H][W][C]).  mode 0 = bilinear align_corners=True (PSP branches of
  * src/models/points/points_sample.py:114-121, CertainSample :293), mode 1 = legacy nearest
  * floor(dst*in/out) (src/models/multiscale_transformerr.py:1193,1230,1240,1267).  The backward kernels are

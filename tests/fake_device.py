@@ -23,6 +23,51 @@ def _act(v, act):
     return v
 
 
+@torch.no_grad()
+def _certain_sample_reference(pred_small, pred_large, interval, sample_num, min_depth):
+    """CertainSample.forward, points_sample.py:291-364: interval histogram decides HOW MANY points,
+    every top-k is over the whole variance map; integer coordinates, no gradient."""
+    B, _, H, W = pred_large.shape
+    small = F.interpolate(pred_small, size=(H, W), mode="bilinear", align_corners=True)
+    var = ((small - pred_large) ** 2).flatten(1)
+    edges = torch.tensor([min_depth] + list(interval) + [1.0], device=pred_large.device, dtype=pred_large.dtype)
+    flat = pred_large.flatten(1)
+    n_i = ((flat[:, None, :] >= edges[:-1, None]) & (flat[:, None, :] < edges[1:, None])).sum(-1)       # (B, I)
+    import numpy as np
+    n_host = np.asarray(n_i.tolist(), dtype=np.int64)                                                    # one host sync
+    k_host = np.floor(n_host.astype(np.float32) / np.float32(H * W) * np.float32(sample_num))
+    k_i = np.minimum(k_host, n_host.astype(np.float32)).astype(np.int64).tolist()
+    order = torch.argsort(var, dim=1, descending=True, stable=True)                                       # lowest index wins ties
+    outs = []
+    for b in range(B):
+        groups = [order[b, :k].sort()[0] for k in k_i[b] if k > 0]
+        counts = [int(g.numel()) for g in groups]
+        already = sum(counts)
+        if groups:
+            cat = torch.cat(groups)
+            remain = sample_num - already
+        else:
+            cat = order[b, :sample_num].sort()[0]
+            remain = 0
+        if remain > 0 and remain >= already:
+            times = remain // already + 1
+            cat = cat.repeat(times)
+            remain = sample_num - already * times
+        if remain > 0:
+            cat = torch.cat([cat, cat[-remain:]])
+        if remain < 0:
+            mid = max(range(len(counts)), key=lambda i: (counts[i], -i))
+            groups[mid] = groups[mid][:remain]
+            cat = torch.cat(groups)
+        outs.append(cat)
+    idx = torch.stack(outs)
+    col, row = (idx % W).float(), torch.div(idx, W, rounding_mode="floor").float()
+    # tensor / tensor is an IEEE division on the device; tensor / python_scalar multiplies by 1/W (1 ulp off the CPU path)
+    wt, ht = torch.full_like(col, float(W)), torch.full_like(row, float(H))
+    return torch.stack([(col / wt) * 2 - 1, (row / ht) * 2 - 1], dim=-1)[:, :, None]
+
+
+
 class FakeDevice:
     is_fake = True
 
@@ -238,3 +283,7 @@ class FakeDevice:
         gq.copy_(g[0])
         gk.copy_(g[1])
         gv.copy_(g[2])
+
+    def certain_sample(self, small, large, coords, edges, sample_num):
+        e = [float(v) for v in edges.tolist()]
+        coords.copy_(_certain_sample_reference(small, large, e[1:-1], sample_num, e[0]))

@@ -55,6 +55,11 @@ def test_index_ops_bit_exact_on_identical_operands():
         large = torch.rand(4, 1, hl, wl, generator=g) * 0.98 + 0.01
         large[1] = large[1] * 0.05            # everything in the lowest interval
         large[2] = 0.95 + large[2] * 0.04     # everything in the highest interval
+        big = torch.rand(1, hl, wl, generator=g) * 0.5 + 1.2      # outside every interval ...
+        keep = torch.rand(1, hl, wl, generator=g) < 0.06          # ... except ~6 % of the pixels: repeat/complement rules
+        large[3] = torch.where(keep, large[3], big)
+        if hs == 6:
+            large[3] = big                    # no pixel in any interval: the global top-S branch
         ref = R.certain_sample(small, large, (0.1, 0.3, 0.5, 0.7, 0.9), S, 1e-4)
         got = certain_sample(small.cuda(), large.cuda(), (0.1, 0.3, 0.5, 0.7, 0.9), S, 1e-4)
         assert torch.equal(got.cpu(), ref), (hs, ws)

@@ -52,3 +52,22 @@ def test_no_cpu_path_without_device_library():
 @pytest.mark.parametrize("case", ["tiny_b2_96x128", "ragged_b2_96x128"])
 def test_train_step_wiring_matches_reference(fake, golden_dir, case):
     check_train_step(case, golden_dir, "cpu", tol=FP_TOL, grad_tol=3e-3)
+
+
+def test_matcher_prefetch_equals_per_layer_matching(fake):
+    """The single early Hungarian hand-off (HungarianMatcherLine.prefetch) returns, layer by layer, exactly what the
+    reference's per-call matcher returns."""
+    from gw_depth_amd.model import NestedTensor
+    cfg, model, crits = build()
+    b = synth_batch(2, 96, 128, seed=31, n_lines=[4, 2])
+    model.train()
+    matcher = crits[0].matcher
+    with torch.no_grad():
+        out = model(NestedTensor(b["images"], b["pad_mask"]), match=(matcher, b["targets"]))
+    handle = out["_match_prefetch"]
+    layers = [out] + out["aux_outputs"]
+    for lay in layers:
+        got = matcher.from_prefetch(handle)
+        want = matcher(lay, b["targets"])
+        for (gi, gj), (wi, wj) in zip(got, want):
+            assert torch.equal(gi, wi) and torch.equal(gj, wj)
