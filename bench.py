@@ -33,6 +33,8 @@ def parse():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="EXPERIMENTAL: replay zero_grad+forward+losses+backward from one HIP graph (see DESIGN.md §7)")
     ap.add_argument("--cpu-baseline-budget-s", type=float, default=25.0)
     ap.add_argument("--kernel-timing", action="store_true", default=True)
     return ap.parse_args()
@@ -90,7 +92,7 @@ def main():
     model.cuda()
     crits[0].cuda()
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    step = TrainStep(model, crits, cfg, compute_dtype=dtype)
+    step = TrainStep(model, crits, cfg, compute_dtype=dtype, graph=a.graph)
     b = synth_batch(a.batch, a.height, a.width, seed=1 + rank)                                   # data seed 1 + rank
     batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
     batch["targets"] = [{k: v.cuda() for k, v in t.items()} for t in b["targets"]]

@@ -96,6 +96,40 @@ class SetCriterion(nn.Module):
         l1 = F.l1_loss(out["pred_lines"].float()[bi, si], tl, reduction="none").sum() / num_items         # :239-242
         return {"loss_ce" + suffix: ce, "loss_line" + suffix: l1}
 
+    def forward_packed(self, outputs, packed, world=1):
+        """Same losses as forward(), with no host round trip: cost matrices of all decoder layers, the device LSAP
+        (gwd_lsap) and the 2 x layers loss terms are computed from static-shape device tensors, so the whole step can be
+        captured in a HIP graph.  `packed` comes from pack_targets(); packed["num_items"] must already hold the
+        GLOBAL target count when world > 1 (the caller all-reduces it outside the captured region)."""
+        from . import hip
+        layers = [outputs] + list(outputs.get("aux_outputs", []))
+        logits = torch.stack([o["pred_logits"] for o in layers]).float()               # (L,B,Q,2)
+        lines = torch.stack([o["pred_lines"] for o in layers]).float()                 # (L,B,Q,6)
+        L_, B, Q, _ = logits.shape
+        sumT = packed["lines"].shape[0]
+        with torch.no_grad():                                                          # matcher.py:52-70
+            prob = logits.softmax(-1)
+            cost = self.matcher.cost_line * torch.cdist(lines.reshape(L_ * B, Q, -1), packed["lines"][None].expand(L_ * B, -1, -1), p=1) \
+                + self.matcher.cost_class * (-prob.reshape(L_ * B, Q, -1)[..., packed["labels"]])
+            qot = torch.empty((L_, sumT), dtype=torch.int32, device=logits.device)
+            hip.library().lsap(cost.reshape(L_, B, Q, sumT).contiguous(), packed["col_off"], qot, max(packed["sizes"]))
+            qi = qot.long()
+        self.last_query_of_target = qi
+        li = torch.arange(L_, device=logits.device)[:, None]
+        bi = packed["bidx"][None].expand(L_, -1)
+        tc = torch.full((L_, B, Q), self.num_classes, dtype=torch.int64, device=logits.device)
+        tc[li, bi, qi] = packed["labels"][None].expand(L_, -1)
+        nll = F.cross_entropy(logits.reshape(L_ * B, Q, -1).transpose(1, 2), tc.reshape(L_ * B, Q), reduction="none")
+        w = self.empty_weight[tc.reshape(L_ * B, Q)]
+        ce = (nll * w).reshape(L_, -1).sum(1) / w.reshape(L_, -1).sum(1)                  # weighted mean per layer (:168)
+        num_items = torch.clamp(packed["num_items"] / world, min=1.0)
+        l1 = (lines[li, bi, qi] - packed["lines"][None]).abs().sum(dim=(1, 2)) / num_items   # (:239-242)
+        losses = {"loss_ce": ce[0], "loss_line": l1[0]}
+        for i in range(L_ - 1):
+            losses[f"loss_ce_{i}"] = ce[i + 1]
+            losses[f"loss_line_{i}"] = l1[i + 1]
+        return losses
+
     def forward(self, outputs, targets, origin_indices=None, depth_gt=None):
         self.last_indices = []
         n = torch.as_tensor([float(sum(len(t["labels"]) for t in targets))], device=outputs["pred_logits"].device)
@@ -109,6 +143,20 @@ class SetCriterion(nn.Module):
         for i, aux in enumerate(outputs.get("aux_outputs", [])):
             losses.update(self._one(aux, targets, num_items, f"_{i}", handle))
         return losses
+
+
+def pack_targets(targets, device):
+    """Static device-side form of the per-image target lists for the sync-free criterion: concatenated lines /
+    labels, the image index of every target and the column offsets of each image's block in the cost matrix."""
+    sizes = [int(len(t["labels"])) for t in targets]
+    off = [0]
+    for s in sizes:
+        off.append(off[-1] + s)
+    bidx = torch.cat([torch.full((s,), i, dtype=torch.int64) for i, s in enumerate(sizes)]) if off[-1] else torch.zeros(0, dtype=torch.int64)
+    return {"lines": torch.cat([t["lines"] for t in targets]).to(device).float().contiguous(),
+            "labels": torch.cat([t["labels"] for t in targets]).to(device),
+            "bidx": bidx.to(device), "col_off": torch.tensor(off, dtype=torch.int32, device=device),
+            "sizes": sizes, "num_items": torch.tensor([float(max(off[-1], 0))], device=device)}
 
 
 class SilogLoss(nn.Module):

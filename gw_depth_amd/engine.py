@@ -18,6 +18,7 @@ import torch
 import torch.distributed as dist
 
 from . import hip
+from .criteria import pack_targets
 from .model import NestedTensor
 
 FORWARD_ORDER = ["backbone", "input_proj", "query_embed", "transformer", "class_embed", "lines_embed",
@@ -31,12 +32,14 @@ def _align(n):
 
 class TrainStep:
     def __init__(self, model, criterions, cfg, compute_dtype=torch.float32, bucket_mb=32.0, process_group=None,
-                 check_finite=True, data_parallel=True):
+                 check_finite=True, data_parallel=True, graph=False):
         self.model, self.cfg = model, cfg
         self.criterion, self.criterion_depth, self.criterion_seg, _ = criterions
         self.compute_dtype = compute_dtype
         model.compute_dtype = compute_dtype
         self.check_finite = check_finite
+        self.use_graph = bool(graph)      # capture zero_grad+forward+losses+backward of a batch signature in one HIP graph
+        self._graphs = {}
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (data_parallel and dist.is_available() and dist.is_initialized()) else 1
         self.step_count = 0
@@ -150,9 +153,9 @@ class TrainStep:
         self._pending = None
 
     # ------------------------------------------------------------------ losses (engine_glassrgbd.py:62-115)
-    def losses(self, out, depth_gt, seg_gt, targets):
+    def losses(self, out, depth_gt, seg_gt, targets, packed=None):
         cfg = self.cfg
-        terms = self.criterion(out, targets)
+        terms = self.criterion.forward_packed(out, packed, self.world) if packed is not None else self.criterion(out, targets)
         wd = self.criterion.weight_dict
         total = sum(terms[k] * wd[k] for k in terms if k in wd)
         names = ["1/16", "1/8", "1/4", "1"]
@@ -198,12 +201,70 @@ class TrainStep:
         self._finish_backward()
         return out, total, terms
 
+    # ------------------------------------------------------------------ HIP-graph path (no host sync inside)
+    def _sync_free_fb(self, st):
+        """zero_grad + forward + 17 losses + backward on the static tensors `st`; contains no host round trip
+        (device LSAP, device CertainSample, fused losses), hence capturable."""
+        self.model.train()
+        out = self.model(NestedTensor(st["images"], st["pad_mask"]), taps=st.get("taps"))
+        total, terms = self.losses(out, st["depth"], st["seg"], None, packed=st["packed"])
+        self.flat_g.zero_()
+        total.backward()
+        return out, total.detach(), {k: v.detach() for k, v in terms.items()}
+
+    def _graph_entry(self, batch):
+        sizes = tuple(int(len(t["labels"])) for t in batch["targets"])
+        key = (tuple(batch["images"].shape), sizes)
+        ent = self._graphs.get(key)
+        if ent is not None:
+            return ent
+        dev = self.flat_p.device
+        st = {k: batch[k].clone() for k in ("images", "pad_mask", "depth", "seg")}
+        st["packed"] = pack_targets(batch["targets"], dev)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):              # warm-up off the capture stream (allocator, caches, autotuned state)
+            for _ in range(2):
+                self._sync_free_fb(st)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        # capture on the SAME stream the warm-up ran on: autograd's AccumulateGrad nodes (created lazily in the first
+        # backward) are bound to the stream they were created under; a different capture stream would run the in-place
+        # gradient accumulation of the non-kernel-accumulated parameters outside the captured order.
+        with torch.cuda.graph(g, stream=side):
+            res = self._sync_free_fb(st)
+        ent = self._graphs[key] = {"graph": g, "static": st, "result": res}
+        return ent
+
+    def _graph_step(self, batch):
+        ent = self._graph_entry(batch)
+        st = ent["static"]
+        for k in ("images", "pad_mask", "depth", "seg"):
+            st[k].copy_(batch[k], non_blocking=True)
+        lines = torch.cat([t["lines"] for t in batch["targets"]])
+        st["packed"]["lines"].copy_(lines, non_blocking=True)
+        st["packed"]["labels"].copy_(torch.cat([t["labels"] for t in batch["targets"]]), non_blocking=True)
+        n = st["packed"]["num_items"]
+        n.fill_(float(lines.shape[0]))
+        if self.world > 1:                          # global target count, outside the captured region
+            dist.all_reduce(n, group=self.pg)
+        ent["graph"].replay()
+        if self.world > 1:                          # gradients: bucketed all-reduce after the replay (no overlap in graph mode)
+            works = [dist.all_reduce(self.flat_g[s:e], group=self.pg, async_op=True) for s, e, _ in self.buckets]
+            for w in works:
+                w.wait()
+        return ent["result"]
+
     def __call__(self, batch, taps=None):
         """batch: dict(images (B,3,H,W), pad_mask (B,H,W) bool, depth (B,1,H,W), seg (B,1,H,W) i64, targets)."""
-        out, total, terms = self.forward_backward(batch, taps)
+        if self.use_graph and taps is None and batch["images"].is_cuda:
+            out, total, terms = self._graph_step(batch)
+        else:
+            out, total, terms = self.forward_backward(batch, taps)
         self.optimizer_step()
         if self.check_finite:                       # engine_glassrgbd.py:143-153 (one host sync, after all launches)
             v = float(total.detach())
             if not math.isfinite(v):
-                raise FloatingPointError("Loss is %r, stopping training" % v)
+                bad = {k: float(t) for k, t in terms.items() if not math.isfinite(float(t))}
+                raise FloatingPointError("Loss is %r at step %d, stopping training (non-finite terms: %r)" % (v, self.step_count, bad))
         return out, total.detach(), terms

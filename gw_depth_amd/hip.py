@@ -24,7 +24,7 @@ ENTRY_POINTS = [
     "gwd_softmax_backward", "gwd_silog_sums", "gwd_silog_backward", "gwd_seg_ce_sum", "gwd_seg_ce_backward",
     "gwd_sqnorm", "gwd_adamw_step", "gwd_resample_forward", "gwd_resample_backward", "gwd_avgpool_forward",
     "gwd_avgpool_backward", "gwd_winattn_forward", "gwd_winattn_backward", "gwd_tokattn_forward",
-    "gwd_tokattn_backward", "gwd_certain_sample",
+    "gwd_tokattn_backward", "gwd_certain_sample", "gwd_lsap",
 ]
 
 
@@ -120,6 +120,7 @@ class HipLibrary:
         L.gwd_tokattn_forward.argtypes = [sp] * 4 + [i64, i32, i32, f32, i32, vp]
         L.gwd_tokattn_backward.argtypes = [sp] * 7 + [i64, i32, i32, f32, i32, vp]
         L.gwd_certain_sample.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp]
+        L.gwd_lsap.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
         L.gwd_sqnorm.argtypes = [vp, vp, i64, vp]
         L.gwd_adamw_step.argtypes = [vp, vp, vp, vp, vp, vp, i64] + [f32] * 9 + [vp]
 
@@ -259,6 +260,12 @@ class HipLibrary:
         self._check(self.lib.gwd_certain_sample(_ptr(small), _ptr(large), _ptr(coords), B, hs, ws, H, W, _ptr(edges),
                                                 edges.numel() - 1, sample_num, self._stream(small, large, coords)),
                     "gwd_certain_sample")
+
+    def lsap(self, cost, col_offsets, out, max_targets):
+        """cost (layers,B,Q,sumT) fp32; col_offsets (B+1,) int32; out (layers,sumT) int32."""
+        L_, B, Q, sumT = cost.shape
+        self._check(self.lib.gwd_lsap(_ptr(cost), _ptr(col_offsets), _ptr(out), L_, B, Q, sumT, max_targets,
+                                      self._stream(cost, col_offsets, out)), "gwd_lsap")
 
     def sqnorm(self, g, sq, n):
         self._check(self.lib.gwd_sqnorm(_ptr(g), _ptr(sq), n, self._stream(g, sq)), "gwd_sqnorm")

@@ -687,6 +687,8 @@ class ReferTransformer(nn.Module):
         depth3 = self.point_based_pred2(x3, dtok, depth2, pts2, H3, W3, pos3)
         if taps is not None:
             taps["topk_ids"] = ids
+            taps.update(dbg_x32=x, dbg_depth0=depth0, dbg_x1=x1, dbg_depth1=depth1, dbg_x2=x2, dbg_depth2=depth2, dbg_x3=x3,
+                        dbg_pts=pts, dbg_pos=pos)
         as_map = lambda t: t.view(B, H3, W3, -1)
         return as_map(x3), as_map(dtok), as_map(stok), [depth1, depth2, depth3]
 
@@ -778,6 +780,8 @@ class GlassRGBD(nn.Module):
             matcher, targets = match
             out["_match_prefetch"] = matcher.prefetch([out] + out.get("aux_outputs", []), targets)
         dense_in = ops.conv2d(src, self.dense_input_proj.weight, self.dense_input_proj.bias)
+        if taps is not None:
+            taps.update(dbg_feats=feats, dbg_dense_in=dense_in, dbg_src=src)
         feat4, dtok, stok, depths = self.dense_encoder(dense_in, feats, masks, out["pred_lines"], out["pred_logits"], taps)
         depth, seg = self.depth_decoder(feat4, depths[-1], dtok, stok, (H, W))
         out["pred_depth"] = depths + [depth]

@@ -154,6 +154,13 @@ int gwd_certain_sample(const float *pred_small, const float *pred_large, float *
                        int32_t ws, int32_t H, int32_t W, const float *edges, int32_t n_intervals,
                        int32_t sample_num, void *stream);
 
+/* Linear sum assignment of the line matcher on the device (replaces scipy.optimize.linear_sum_assignment at
+ * src/models/matcher.py:74 and its 6 host syncs per step).  cost [layers][B][Q][sum_targets] fp32 is the block
+ * cost matrix of matcher.py:52-70; image b owns columns col_offsets[b] .. col_offsets[b+1]-1 (int32 [B+1]).
+ * query_of_target [layers][sum_targets] int32 receives the query matched to every target (targets <= Q, <= 64). */
+int gwd_lsap(const float *cost, const int32_t *col_offsets, int32_t *query_of_target, int32_t layers, int32_t B,
+             int32_t Q, int32_t sum_targets, int32_t max_targets, void *stream);
+
 /* Pixel-major resampling ([B][H][W][C]).  mode 0 = bilinear align_corners=True (PSP branches of
  * src/models/points/points_sample.py:114-121, CertainSample :293), mode 1 = legacy nearest
  * floor(dst*in/out) (src/models/multiscale_transformerr.py:1193,1230,1240,1267).  The backward kernels are

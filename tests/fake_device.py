@@ -287,3 +287,14 @@ class FakeDevice:
     def certain_sample(self, small, large, coords, edges, sample_num):
         e = [float(v) for v in edges.tolist()]
         coords.copy_(_certain_sample_reference(small, large, e[1:-1], sample_num, e[0]))
+
+    def lsap(self, cost, col_offsets, out, max_targets):
+        from scipy.optimize import linear_sum_assignment
+        L_, B, Q, sumT = cost.shape
+        off = col_offsets.tolist()
+        for l in range(L_):
+            for b in range(B):
+                c = cost[l, b, :, off[b]:off[b + 1]].double().cpu().numpy()
+                qi, ti = linear_sum_assignment(c)
+                for q, t in zip(qi, ti):
+                    out[l, off[b] + t] = int(q)

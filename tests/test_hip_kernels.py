@@ -317,3 +317,26 @@ def test_token_attention(dev, e, nwin, dtype):
     dev.tokattn_backward(Q, KV[:, :, 0], KV[:, :, 1], go.cuda(), gq, gkv[:, :, 0], gkv[:, :, 1], scale)
     torch.cuda.synchronize()
     assert rel(o, o_r) < TOL[dtype] and rel(gq, gq_r) < TOL[dtype] and rel(gkv, gkv_r) < TOL[dtype]
+
+
+@pytest.mark.parametrize("layers,B,Q,sizes", [(6, 8, 100, [7] * 8), (2, 3, 100, [1, 12, 5]), (1, 2, 37, [37, 20]), (3, 2, 1000, [30, 64])])
+def test_device_lsap_matches_scipy(dev, layers, B, Q, sizes):
+    from scipy.optimize import linear_sum_assignment
+    g = torch.Generator().manual_seed(11)
+    sumT = sum(sizes)
+    cost = torch.rand(layers, B, Q, sumT, generator=g) * 5 - 1
+    cost[0, 0] = (cost[0, 0] * 4).round() / 4 + torch.rand(Q, sumT, generator=g) * 1e-4      # near-degenerate block
+    off = [0]
+    for s in sizes:
+        off.append(off[-1] + s)
+    out = torch.full((layers, sumT), -1, dtype=torch.int32, device="cuda")
+    dev.lsap(cost.cuda(), torch.tensor(off, dtype=torch.int32, device="cuda"), out, max(sizes))
+    torch.cuda.synchronize()
+    out = out.cpu()
+    for l in range(layers):
+        for b in range(B):
+            c = cost[l, b, :, off[b]:off[b + 1]].double().numpy()
+            qi, ti = linear_sum_assignment(c)
+            want = torch.empty(sizes[b], dtype=torch.int32)
+            want[torch.as_tensor(ti)] = torch.as_tensor(qi, dtype=torch.int32)
+            assert torch.equal(out[l, off[b]:off[b + 1]], want), (l, b)

@@ -71,3 +71,19 @@ def test_matcher_prefetch_equals_per_layer_matching(fake):
         want = matcher(lay, b["targets"])
         for (gi, gj), (wi, wj) in zip(got, want):
             assert torch.equal(gi, wi) and torch.equal(gj, wj)
+
+
+def test_sync_free_criterion_equals_reference_criterion(fake):
+    """SetCriterion.forward_packed (device LSAP, static shapes, graph-capturable) == SetCriterion.forward."""
+    from gw_depth_amd.criteria import pack_targets
+    from gw_depth_amd.model import NestedTensor
+    cfg, model, crits = build()
+    b = synth_batch(2, 96, 128, seed=33, n_lines=[5, 2])
+    model.train()
+    with torch.no_grad():
+        out = model(NestedTensor(b["images"], b["pad_mask"]))
+        want = crits[0](out, b["targets"])
+        got = crits[0].forward_packed(out, pack_targets(b["targets"], "cpu"))
+    assert set(want) == set(got)
+    for k in want:
+        assert abs(float(want[k]) - float(got[k])) <= 1e-5 * max(1.0, abs(float(want[k]))), k
