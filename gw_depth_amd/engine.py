@@ -38,10 +38,14 @@ class TrainStep:
         self.compute_dtype = compute_dtype
         model.compute_dtype = compute_dtype
         self.check_finite = check_finite
+        self.device_matcher = True        # gwd_lsap + sync-free criterion (taps / teacher-forced tests use the host matcher)
+        self._pack_cache = {}
         self.use_graph = bool(graph)      # capture zero_grad+forward+losses+backward of a batch signature in one HIP graph
         self._graphs = {}
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (data_parallel and dist.is_available() and dist.is_initialized()) else 1
+        # the line-loss normaliser is the GLOBAL target count / world whenever a process group exists (glassrgbd.py:323-326)
+        self.norm_world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.step_count = 0
 
         named = dict(model.named_parameters())
@@ -152,10 +156,28 @@ class TrainStep:
             w.wait()
         self._pending = None
 
+    def _packed(self, targets):
+        """Static-shape device form of the targets for the sync-free criterion; the index scaffolding is cached per
+        tuple of target counts, only the line coordinates / labels are gathered each step (two small device ops)."""
+        sizes = tuple(int(len(t["labels"])) for t in targets)
+        if sum(sizes) == 0 or max(sizes) > 64:
+            return None                                # device LSAP limits; fall back to the host matcher
+        ent = self._pack_cache.get(sizes)
+        if ent is None:
+            ent = self._pack_cache[sizes] = pack_targets(targets, self.flat_p.device)
+        p = dict(ent)
+        p["lines"] = torch.cat([t["lines"] for t in targets]).float()
+        p["labels"] = torch.cat([t["labels"] for t in targets])
+        if self.norm_world > 1:                         # global target count (glassrgbd.py:323-326), stays on the device
+            n = ent["num_items"].clone()
+            dist.all_reduce(n, group=self.pg)
+            p["num_items"] = n
+        return p
+
     # ------------------------------------------------------------------ losses (engine_glassrgbd.py:62-115)
     def losses(self, out, depth_gt, seg_gt, targets, packed=None):
         cfg = self.cfg
-        terms = self.criterion.forward_packed(out, packed, self.world) if packed is not None else self.criterion(out, targets)
+        terms = self.criterion.forward_packed(out, packed, self.norm_world) if packed is not None else self.criterion(out, targets)
         wd = self.criterion.weight_dict
         total = sum(terms[k] * wd[k] for k in terms if k in wd)
         names = ["1/16", "1/8", "1/4", "1"]
@@ -192,9 +214,10 @@ class TrainStep:
     def forward_backward(self, batch, taps=None):
         """Forward, losses, backward and (N > 1) the bucketed gradient all-reduce; leaves SUMMED grads in flat_g."""
         self.model.train()
-        match = (self.criterion.matcher, batch["targets"]) if hasattr(self.criterion.matcher, "prefetch") else None
+        packed = self._packed(batch["targets"]) if self.device_matcher else None
+        match = (self.criterion.matcher, batch["targets"]) if (packed is None and hasattr(self.criterion.matcher, "prefetch")) else None
         out = self.model(NestedTensor(batch["images"], batch["pad_mask"]), taps=taps, match=match)
-        total, terms = self.losses(out, batch["depth"], batch["seg"], batch["targets"])
+        total, terms = self.losses(out, batch["depth"], batch["seg"], batch["targets"], packed=packed)
         self.zero_grad()
         self._begin_backward()
         total.backward()
@@ -246,7 +269,7 @@ class TrainStep:
         st["packed"]["labels"].copy_(torch.cat([t["labels"] for t in batch["targets"]]), non_blocking=True)
         n = st["packed"]["num_items"]
         n.fill_(float(lines.shape[0]))
-        if self.world > 1:                          # global target count, outside the captured region
+        if self.norm_world > 1:                     # global target count, outside the captured region
             dist.all_reduce(n, group=self.pg)
         ent["graph"].replay()
         if self.world > 1:                          # gradients: bucketed all-reduce after the replay (no overlap in graph mode)

@@ -101,6 +101,7 @@ def check_train_step(case, golden_dir, device, tol, grad_tol):
     step = TrainStep(model, crits, cfg, compute_dtype=torch.float32)
     tf = TeacherForcedMatcher(step.criterion.matcher, g)
     step.criterion.matcher = tf
+    step.device_matcher = False       # teacher-forced reference assignments go through the host matcher interface
     before = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
     # Index ops amplify 1e-6 float noise into different gathers when scores tie (SURVEY.md §7 "index-op
     # chaos"): the sampled points are teacher-forced to the reference's so that everything downstream sees

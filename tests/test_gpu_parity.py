@@ -90,3 +90,23 @@ def test_hip_graph_step_equals_eager_step():
         assert abs(t0[k] - t1[k]) <= 2e-5 * max(1.0, abs(t0[k])), k
     assert rel(d1, d0) < 1e-5
     assert rel(g1, g0) < 1e-3 and rel(p1, p0) < 1e-6
+
+
+def test_device_matcher_step_equals_host_matcher_step():
+    """Default eager step (device LSAP, no host sync in the criterion) == the same step with the host matcher."""
+    from gw_depth_amd.engine import TrainStep
+    from gw_depth_amd.synth import synth_batch
+    b = to_device(synth_batch(2, 96, 128, seed=43, n_lines=[6, 3]), "cuda")
+    res = []
+    for dev_match in (False, True):
+        cfg, model, crits = build(device="cuda")
+        step = TrainStep(model, crits, cfg, compute_dtype=torch.float32)
+        step.device_matcher = dev_match
+        out, total, terms = step(b)
+        torch.cuda.synchronize()
+        res.append((float(total), {k: float(v) for k, v in terms.items()}, step.flat_p.clone()))
+    (l0, t0, p0), (l1, t1, p1) = res
+    assert abs(l0 - l1) <= 2e-5 * abs(l0)
+    for k in t0:
+        assert abs(t0[k] - t1[k]) <= 2e-5 * max(1.0, abs(t0[k])), k
+    assert rel(p1, p0) < 1e-6
