@@ -741,6 +741,195 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const gwd_conv_desc d,
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// weight gradient, LDS-DMA pipeline (bf16, Cin % 8 == 0, Cout % 8 == 0)
+// ----------------------------------------------------------------------------------------------
+// Same math as igemm_wgrad_kernel; the dY tile [32 pixels][BNW channels] and the im2col tile [32 pixels][BKW] go
+// HBM -> LDS by global_load_lds_dwordx4 through a ring of STAGES buffers.  An LDS image is a linear array of 16-byte
+// chunks (row-major, unpadded: a DMA wave instruction writes 64 consecutive chunks), every lane derives the
+// (row, chunk) it fetches from its linear chunk index.  The transposed reads (ds_read_b64_tr_b16) touch 4 consecutive
+// rows per 16-lane group: rows of 320 B (BNW = 160) are 16 words apart mod 64 and need nothing, rows of 256/512 B
+// (128 B) alias and get an XOR of the chunk index with row bits, applied to the SOURCE address and to the read.
+// Wave grid WN x WK over the [BNW x BKW] output tile; BNW = 160 serves the 160/320-channel pyramids exactly.
+template <int ROWB> __device__ __forceinline__ int wg_swz(int row) {
+    if constexpr ((ROWB / 4) % 64 == 0) return (row & 3) << 2;
+    else if constexpr ((ROWB / 4) % 64 == 32) return ((row >> 1) & 1) << 2;
+    else return 0;
+}
+
+template <int BNW, int BKW, int WN, int WK, int STAGES>
+__global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(const gwd_conv_desc d, float *__restrict__ dw, int m_per_block) {
+    typedef __bf16 T;
+    constexpr int RM = 32;
+    constexpr int TN = BNW / WN / 32, TK = BKW / WK / 32;
+    constexpr int YB = BNW * 2, XB = BKW * 2;                  // row bytes
+    constexpr int YC = BNW / 8, XC = BKW / 8;                  // 16-byte chunks per row
+    constexpr int YI = RM * YC / 64, XI = RM * XC / 64;        // DMA wave-instructions per tile
+    constexpr int TI = YI + XI;
+    constexpr int IT = (TI + 3) / 4, FULL = TI % 4;            // wave w issues instructions w, w+4, ...; waves < FULL issue IT
+    constexpr int STAGE_BYTES = RM * (YB + XB);
+    static_assert(WN * WK == 4 && (RM * YC) % 64 == 0 && (RM * XC) % 64 == 0, "tile");
+    __shared__ __attribute__((aligned(1024))) char smem[STAGES * STAGE_BYTES];
+
+    const int M = d.B * d.Ho * d.Wo, N = d.Cout, K = d.KH * d.KW * d.Cin;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave / WK, wk = wave % WK;
+    const int kb0 = blockIdx.x * BKW, n0 = blockIdx.y * BNW;
+    const int m_begin = blockIdx.z * m_per_block;
+    const int m_end = min(M, m_begin + m_per_block);
+    const T *gy = (const T *)d.y;
+    const T *x = (const T *)d.x;
+    const char *zero = (const char *)d.zero_page;
+    const int my_loads = (FULL == 0 || wave < FULL) ? IT : IT - 1;
+    const int HoWo = d.Ho * d.Wo;
+
+    // ---- per-lane DMA assignments: instruction j = wave + 4*i of the combined (Y then X) list
+    bool is_y[IT], col_ok[IT];
+    int row[IT], x_kh[IT], x_kw[IT], x_c[IT], x_b[IT], x_oh[IT], x_ow[IT];
+    const T *y_src[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int j = wave + 4 * i;
+        is_y[i] = j < YI;
+        y_src[i] = gy;
+        x_kh[i] = x_kw[i] = x_c[i] = x_b[i] = x_oh[i] = x_ow[i] = 0;
+        if (is_y[i]) {
+            const int q = j * 64 + lane;
+            row[i] = q / YC;
+            const int c = (q - row[i] * YC) ^ wg_swz<YB>(row[i]);
+            col_ok[i] = n0 + c * 8 < N;
+            y_src[i] = gy + (size_t)(m_begin + row[i]) * N + n0 + c * 8;
+        } else {
+            const int q = (j - YI) * 64 + lane;
+            row[i] = q / XC;
+            const int c = (q - row[i] * XC) ^ wg_swz<XB>(row[i]);
+            const int k0 = kb0 + c * 8;
+            col_ok[i] = (j < TI) && k0 < K;
+            const int kk = col_ok[i] ? k0 : 0;
+            const int tap = kk / d.Cin;
+            x_c[i] = kk - tap * d.Cin;
+            x_kh[i] = tap / d.KW;
+            x_kw[i] = tap - x_kh[i] * d.KW;
+            const int m = m_begin + row[i];
+            x_b[i] = m / HoWo;
+            const int rem = m - x_b[i] * HoWo;
+            x_oh[i] = rem / d.Wo;
+            x_ow[i] = rem - x_oh[i] * d.Wo;
+        }
+    }
+
+    f32x16 acc[TN][TK];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int steps = (m_end - m_begin + RM - 1) / RM;
+    int issued = 0;
+    auto issue = [&](int stage) {
+        char *sb = smem + stage * STAGE_BYTES;
+        const int mbase = m_begin + issued * RM;
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            if (i >= my_loads) continue;                          // wave-uniform
+            const int j = wave + 4 * i;
+            const bool rok = col_ok[i] && (mbase + row[i]) < m_end;
+            const char *src = zero;
+            if (is_y[i]) {                                        // wave-uniform (an instruction is all-Y or all-X)
+                if (rok) src = (const char *)(y_src[i] + (size_t)issued * RM * N);
+            } else {
+                int ih, iw;
+                if (rok && src_pixel(d, x_oh[i], x_ow[i], x_kh[i], x_kw[i], ih, iw))
+                    src = (const char *)(x + ((size_t)(x_b[i] * d.Hi + ih) * d.Wi + iw) * d.Cin + x_c[i]);
+                if (HoWo == 1) {
+                    x_b[i] += RM;
+                } else {
+                    x_ow[i] += RM;
+                    while (x_ow[i] >= d.Wo) {
+                        x_ow[i] -= d.Wo;
+                        if (++x_oh[i] == d.Ho) {
+                            x_oh[i] = 0;
+                            ++x_b[i];
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(sb + j * 1024), 16, 0, 0);
+        }
+        ++issued;
+    };
+
+    const int g = lane >> 4, t = lane & 15;
+    auto compute = [&](int stage) {
+        const char *Yb = smem + stage * STAGE_BYTES;
+        const char *Xb = Yb + RM * YB;                            // == Yb + YI * 1024
+#pragma unroll
+        for (int ks = 0; ks < RM / 16; ++ks) {
+            bf16x8 af[TN], bfr[TK];
+            const int r0 = ks * 16 + 8 * (g >> 1) + (t >> 2);           // rows r0 (lo) and r0 + 4 (hi)
+            const int cw = 16 * (g & 1) + 4 * (t & 3);                    // column inside the 32-wide tile
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int col = wn * (BNW / WN) + i * 32 + cw;
+                const char *plo = Yb + r0 * YB + (((col >> 3) ^ wg_swz<YB>(r0)) << 4) + ((col & 7) << 1);
+                const char *phi = Yb + (r0 + 4) * YB + (((col >> 3) ^ wg_swz<YB>(r0 + 4)) << 4) + ((col & 7) << 1);
+                union { s16x4 h[2]; bf16x8 v; } u;
+                u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)plo);
+                u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)phi);
+                af[i] = u.v;
+            }
+#pragma unroll
+            for (int j = 0; j < TK; ++j) {
+                const int col = wk * (BKW / WK) + j * 32 + cw;
+                const char *plo = Xb + r0 * XB + (((col >> 3) ^ wg_swz<XB>(r0)) << 4) + ((col & 7) << 1);
+                const char *phi = Xb + (r0 + 4) * XB + (((col >> 3) ^ wg_swz<XB>(r0 + 4)) << 4) + ((col & 7) << 1);
+                union { s16x4 h[2]; bf16x8 v; } u;
+                u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)plo);
+                u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)phi);
+                bfr[j] = u.v;
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TK; ++j) acc[i][j] = mma(af[i], bfr[j], acc[i][j]);
+        }
+    };
+
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < steps) issue(s);
+    for (int s = 0; s < steps; ++s) {
+        if (s + STAGES - 2 < steps) {
+            if (my_loads == IT)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IT * (STAGES - 2)) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((IT - 1) * (STAGES - 2)) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (s + STAGES - 1 < steps) issue((s + STAGES - 1) % STAGES);
+        compute(s % STAGES);
+    }
+
+    const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TK; ++j) {
+        const int kcol = kb0 + wk * (BKW / WK) + j * 32 + fr;
+        if (kcol >= K) continue;
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * (BNW / WN) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (n < N) unsafeAtomicAdd(dw + (size_t)n * K + kcol, acc[i][j][r]);
+            }
+    }
+}
+
 template <typename T>
 __global__ void weight_prep_kernel(const float *__restrict__ w, const float *__restrict__ rs, T *__restrict__ wf,
                                    T *__restrict__ wd, int N, int taps, int C) {
@@ -828,21 +1017,63 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
     return 0;
 }
 
+static int wgrad_target_blocks() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GWD_WGRAD_BLOCKS");
+        v = e ? atoi(e) : 768;       // 256 CUs x 3 resident workgroups (48 KiB LDS): whole rounds
+    }
+    return v;
+}
+static int wgrad_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GWD_WGRAD_VARIANT");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
+static void wgrad_split(int M, int tiles, int rm, int &splits, int &m_per_block) {
+    // enough M-splits to put ~4 workgroups on every CU, at least 8 reduction steps per workgroup
+    splits = (wgrad_target_blocks() + tiles - 1) / tiles;
+    const int max_splits = (M + 8 * rm - 1) / (8 * rm);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    m_per_block = (M + splits - 1) / splits;
+    m_per_block = ((m_per_block + rm - 1) / rm) * rm;
+    splits = (M + m_per_block - 1) / m_per_block;
+}
+
 template <typename T>
 int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s) {
     constexpr int RM = Cfg<T>::BK;
     const int M = d->B * d->Ho * d->Wo, N = d->Cout, K = d->KH * d->KW * d->Cin;
+    int splits, m_per_block;
+    if constexpr (sizeof(T) == 2) {
+        if (dma_enabled() && d->zero_page && (d->Cin % 8) == 0 && (N % 8) == 0) {
+#define WG_LAUNCH(BN_, BK_, WN_, WK_, ST_)                                                                   \
+    {                                                                                                        \
+        const int tiles = ((N + BN_ - 1) / BN_) * ((K + BK_ - 1) / BK_);                                     \
+        wgrad_split(M, tiles, 32, splits, m_per_block);                                                      \
+        dim3 grid((K + BK_ - 1) / BK_, (N + BN_ - 1) / BN_, splits);                                         \
+        if (grid.y > 65535 || grid.z > 65535) return -8;                                                     \
+        igemm_wgrad_dma_kernel<BN_, BK_, WN_, WK_, ST_><<<grid, 256, 0, s>>>(*d, dw, m_per_block);           \
+    }
+            const int var = wgrad_variant();
+            if (N % 160 == 0 && K >= 256 && var == 1) WG_LAUNCH(160, 256, 1, 4, 3)
+            else if (N % 160 == 0 && K >= 128 && var != 3) WG_LAUNCH(160, 128, 1, 4, 3)
+            else if (N > 64 && K >= 256 && var == 1) WG_LAUNCH(128, 256, 2, 2, 3)
+            else if (N > 64 && K > 64) WG_LAUNCH(128, 128, 2, 2, 3)
+            else WG_LAUNCH(64, 64, 2, 2, 4)
+#undef WG_LAUNCH
+            GWD_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     const bool big = (N > 64 && K > 64);
     const int bn = big ? 128 : 64, bk = big ? 128 : 64;
-    const int tiles = ((N + bn - 1) / bn) * ((K + bk - 1) / bk);
-    // enough M-splits to put ~4 blocks on every CU, at least 8 reduction steps per block
-    int splits = (1024 + tiles - 1) / tiles;
-    const int max_splits = (M + 8 * RM - 1) / (8 * RM);
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    int m_per_block = (M + splits - 1) / splits;
-    m_per_block = ((m_per_block + RM - 1) / RM) * RM;
-    splits = (M + m_per_block - 1) / m_per_block;
+    wgrad_split(M, ((N + bn - 1) / bn) * ((K + bk - 1) / bk), RM, splits, m_per_block);
     dim3 grid((K + bk - 1) / bk, (N + bn - 1) / bn, splits);
     if (grid.y > 65535 || grid.z > 65535) return -8;
     if (big)

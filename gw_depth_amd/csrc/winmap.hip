@@ -1,0 +1,55 @@
+// Window partition / reverse for the Swin-style stages as ONE index-remapping copy each way:
+//   gather : (B, H, W, C) token map -> (B * nWin, 49, C) windows, including zero padding to a multiple of 7 and the
+//            cyclic shift (F.pad + torch.roll + view/permute/contiguous of multiscale_transformerr.py:667-676,705-707)
+//   scatter: the inverse (window_reverse + un-shift + crop, :730-747).
+// Each is the other's backward.  16-byte channel vectors; one thread per (window token, channel vector).
+#include "common.h"
+
+namespace {
+
+template <bool GATHER>
+__global__ void winmap_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int B, int H, int W, int CV, int shift) {
+    const int Hp = (H + 6) / 7 * 7, Wp = (W + 6) / 7 * 7, nwx = Wp / 7, nwy = Hp / 7;
+    const int64_t total = (int64_t)B * Hp * Wp * CV;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        int64_t r = i / CV;                           // window-major token index
+        const int t = (int)(r % 49);
+        r /= 49;
+        const int wx = (int)(r % nwx);
+        r /= nwx;
+        const int wy = (int)(r % nwy);
+        const int b = (int)(r / nwy);
+        int py = wy * 7 + t / 7 + shift, px = wx * 7 + t % 7 + shift;      // position in the padded, un-shifted map
+        if (py >= Hp) py -= Hp;
+        if (px >= Wp) px -= Wp;
+        const bool inside = py < H && px < W;
+        const int64_t map_idx = (((int64_t)b * H + py) * W + px) * CV + cv;
+        if (GATHER) {
+            dst[i] = inside ? src[map_idx] : make_uint4(0u, 0u, 0u, 0u);
+        } else if (inside) {
+            dst[map_idx] = src[i];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int gwd_window_map(const void *src, void *dst, int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift,
+                              int32_t gather, int32_t dtype, void *stream) {
+    if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || C <= 0 || shift < 0 || shift >= 7) return -1;
+    const int esz = dtype == GWD_BF16 ? 2 : (dtype == GWD_F32 ? 4 : 0);
+    if (!esz) return -2;
+    if ((C * esz) % 16) return -4;
+    const int CV = C * esz / 16;
+    const int Hp = (H + 6) / 7 * 7, Wp = (W + 6) / 7 * 7;
+    const int64_t total = (int64_t)B * Hp * Wp * CV;
+    int64_t nb = (total + 255) / 256;
+    const int grid = (int)(nb > 8192 ? 8192 : nb);
+    if (gather)
+        winmap_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>((const uint4 *)src, (uint4 *)dst, B, H, W, CV, shift);
+    else
+        winmap_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>((const uint4 *)src, (uint4 *)dst, B, H, W, CV, shift);
+    GWD_CHECK_LAUNCH();
+    return 0;
+}

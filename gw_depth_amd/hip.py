@@ -24,7 +24,7 @@ ENTRY_POINTS = [
     "gwd_softmax_backward", "gwd_silog_sums", "gwd_silog_backward", "gwd_seg_ce_sum", "gwd_seg_ce_backward",
     "gwd_sqnorm", "gwd_adamw_step", "gwd_resample_forward", "gwd_resample_backward", "gwd_avgpool_forward",
     "gwd_avgpool_backward", "gwd_winattn_forward", "gwd_winattn_backward", "gwd_tokattn_forward",
-    "gwd_tokattn_backward", "gwd_certain_sample", "gwd_lsap",
+    "gwd_tokattn_backward", "gwd_certain_sample", "gwd_lsap", "gwd_window_map",
 ]
 
 
@@ -121,6 +121,7 @@ class HipLibrary:
         L.gwd_tokattn_backward.argtypes = [sp] * 7 + [i64, i32, i32, f32, i32, vp]
         L.gwd_certain_sample.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp]
         L.gwd_lsap.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
+        L.gwd_window_map.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_sqnorm.argtypes = [vp, vp, i64, vp]
         L.gwd_adamw_step.argtypes = [vp, vp, vp, vp, vp, vp, i64] + [f32] * 9 + [vp]
 
@@ -266,6 +267,10 @@ class HipLibrary:
         L_, B, Q, sumT = cost.shape
         self._check(self.lib.gwd_lsap(_ptr(cost), _ptr(col_offsets), _ptr(out), L_, B, Q, sumT, max_targets,
                                       self._stream(cost, col_offsets, out)), "gwd_lsap")
+
+    def window_map(self, src, dst, B, H, W, C, shift, gather):
+        self._check(self.lib.gwd_window_map(_ptr(src), _ptr(dst), B, H, W, C, shift, int(gather), dtype_code(src),
+                                            self._stream(src, dst)), "gwd_window_map")
 
     def sqnorm(self, g, sq, n):
         self._check(self.lib.gwd_sqnorm(_ptr(g), _ptr(sq), n, self._stream(g, sq)), "gwd_sqnorm")

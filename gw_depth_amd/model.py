@@ -447,9 +447,11 @@ class SwinBlock(nn.Module):
     def forward(self, x, H, W, ref_coors=None, ref_pos=None, dtok=None, stok=None):
         B, L, C = x.shape
         shift = self.shift
-        sx, Hp, Wp = pad_roll(self.norm1(x).view(B, H, W, C), H, W, shift)
+        xn = self.norm1(x).view(B, H, W, C)
+        Hp, Wp = (H + WS - 1) // WS * WS, (W + WS - 1) // WS * WS
         mask = shift_regions(Hp, Wp, x.device) if shift else None
         if dtok is None:
+            sx, _, _ = pad_roll(xn, H, W, shift)
             if shift:                                                             # :678-686
                 rc = torch.stack([ref_coors[..., 0] - (shift / (Wp - 1)) * 2,
                                   ref_coors[..., 1] - (shift / (Hp - 1)) * 2], dim=-1)
@@ -463,18 +465,19 @@ class SwinBlock(nn.Module):
             aw = self.attn(window_partition(sx), x_ref, mask)
         else:
             tC = dtok.shape[-1]
-            dn, _, _ = pad_roll(self.norm_depth1(dtok).view(B, H, W, tC), H, W, shift)
-            sn, _, _ = pad_roll(self.norm_seg1(stok).view(B, H, W, tC), H, W, shift)
-            aw, dw, sw = self.attn(window_partition(sx), window_partition(dn), window_partition(sn), mask)
+            dn = ops.window_gather(self.norm_depth1(dtok).view(B, H, W, tC), shift)
+            sn = ops.window_gather(self.norm_seg1(stok).view(B, H, W, tC), shift)
+            aw, dw, sw = self.attn(ops.window_gather(xn, shift), dn, sn, mask)
+            x = x + ops.window_scatter(aw, B, H, W, shift).view(B, H * W, C)
+            x = x + self.mlp(self.norm2(x))
+            d = dtok + ops.window_scatter(dw, B, H, W, shift).view(B, H * W, tC)
+            d = d + self.mlp_depth(self.norm_depth2(d))
+            s = stok + ops.window_scatter(sw, B, H, W, shift).view(B, H * W, tC)
+            s = s + self.mlp_seg(self.norm_seg2(s))
+            return x, d, s
         x = x + unroll_crop(aw, H, W, Hp, Wp, shift).reshape(B, H * W, C)
         x = x + self.mlp(self.norm2(x))
-        if dtok is None:
-            return x, None, None
-        d = dtok + unroll_crop(dw, H, W, Hp, Wp, shift).reshape(B, H * W, tC)
-        d = d + self.mlp_depth(self.norm_depth2(d))
-        s = stok + unroll_crop(sw, H, W, Hp, Wp, shift).reshape(B, H * W, tC)
-        s = s + self.mlp_seg(self.norm_seg2(s))
-        return x, d, s
+        return x, None, None
 
 
 class BasicLayer(nn.Module):

@@ -445,3 +445,50 @@ class _TokAttnFn(torch.autograd.Function):
 def token_attention(q, k, v, scale):
     """Class-token attention: q (W,49,H,4), k/v (W,49,H,e) -> (W,49,4H); softmax over the e feature channels."""
     return _TokAttnFn.apply(q, k, v, float(scale))
+
+
+class _WindowGatherFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, shift):
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        Hp, Wp = (H + 6) // 7 * 7, (W + 6) // 7 * 7
+        out = torch.empty((B * (Hp // 7) * (Wp // 7), 49, C), dtype=x.dtype, device=x.device)
+        _lib().window_map(x, out, B, H, W, C, shift, True)
+        ctx.cfg = (B, H, W, C, shift)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H, W, C, shift = ctx.cfg
+        gx = torch.empty((B, H, W, C), dtype=g.dtype, device=g.device)
+        _lib().window_map(g.contiguous(), gx, B, H, W, C, shift, False)
+        return gx, None
+
+
+class _WindowScatterFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, win, B, H, W, shift):
+        win = win.contiguous()
+        C = win.shape[-1]
+        out = torch.empty((B, H, W, C), dtype=win.dtype, device=win.device)
+        _lib().window_map(win, out, B, H, W, C, shift, False)
+        ctx.cfg = (B, H, W, C, shift, tuple(win.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H, W, C, shift, shape = ctx.cfg
+        gw = torch.empty(shape, dtype=g.dtype, device=g.device)
+        _lib().window_map(g.contiguous(), gw, B, H, W, C, shift, True)
+        return gw, None, None, None, None
+
+
+def window_gather(x, shift):
+    """(B,H,W,C) -> (B*nWin, 49, C): zero-pad to multiples of 7, cyclic shift by -shift, 7x7 window partition."""
+    return _WindowGatherFn.apply(x, int(shift))
+
+
+def window_scatter(win, B, H, W, shift):
+    """Inverse of window_gather (window reverse, un-shift, crop) -> (B,H,W,C)."""
+    return _WindowScatterFn.apply(win, int(B), int(H), int(W), int(shift))

@@ -161,6 +161,12 @@ int gwd_certain_sample(const float *pred_small, const float *pred_large, float *
 int gwd_lsap(const float *cost, const int32_t *col_offsets, int32_t *query_of_target, int32_t layers, int32_t B,
              int32_t Q, int32_t sum_targets, int32_t max_targets, void *stream);
 
+/* Window partition (gather != 0) / reverse (gather == 0) of a (B,H,W,C) token map into (B*nWin,49,C) 7x7 windows
+ * with zero padding to multiples of 7 and cyclic shift `shift` (src/models/multiscale_transformerr.py:667-676,
+ * 705-707 / 730-747).  C * sizeof(dtype) must be a multiple of 16.                                            */
+int gwd_window_map(const void *src, void *dst, int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift,
+                   int32_t gather, int32_t dtype, void *stream);
+
 /* Pixel-major resampling ([B][H][W][C]).  mode 0 = bilinear align_corners=True (PSP branches of
  * src/models/points/points_sample.py:114-121, CertainSample :293), mode 1 = legacy nearest
  * floor(dst*in/out) (src/models/multiscale_transformerr.py:1193,1230,1240,1267).  The backward kernels are

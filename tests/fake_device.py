@@ -298,3 +298,17 @@ class FakeDevice:
                 qi, ti = linear_sum_assignment(c)
                 for q, t in zip(qi, ti):
                     out[l, off[b] + t] = int(q)
+
+    def window_map(self, src, dst, B, H, W, C, shift, gather):
+        Hp, Wp = (H + 6) // 7 * 7, (W + 6) // 7 * 7
+        if gather:
+            x = F.pad(src.reshape(B, H, W, C), (0, 0, 0, Wp - W, 0, Hp - H))
+            if shift:
+                x = torch.roll(x, shifts=(-shift, -shift), dims=(1, 2))
+            x = x.view(B, Hp // 7, 7, Wp // 7, 7, C).permute(0, 1, 3, 2, 4, 5)
+            dst.copy_(x.reshape(dst.shape))
+        else:
+            x = src.reshape(B, Hp // 7, Wp // 7, 7, 7, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
+            if shift:
+                x = torch.roll(x, shifts=(shift, shift), dims=(1, 2))
+            dst.copy_(x[:, :H, :W].reshape(dst.shape))

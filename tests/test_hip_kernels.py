@@ -340,3 +340,30 @@ def test_device_lsap_matches_scipy(dev, layers, B, Q, sizes):
             want = torch.empty(sizes[b], dtype=torch.int32)
             want[torch.as_tensor(ti)] = torch.as_tensor(qi, dtype=torch.int32)
             assert torch.equal(out[l, off[b]:off[b + 1]], want), (l, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 30, 40, 32, 0), (2, 30, 40, 32, 3), (1, 14, 21, 8, 3), (2, 15, 20, 128, 3), (3, 12, 16, 4, 0)])
+def test_window_map(dev, shape, dtype):
+    """Index remapping copy: bit-exact in both directions, padded slots zero, and scatter(gather(x)) == x."""
+    B, H, W, C, shift = shape
+    if C * (2 if dtype == torch.bfloat16 else 4) % 16:
+        pytest.skip("channel vector not 16-byte")
+    fake = FakeDevice()
+    Hp, Wp = (H + 6) // 7 * 7, (W + 6) // 7 * 7
+    nwin = B * (Hp // 7) * (Wp // 7)
+    x = rnd(B, H, W, C, dtype=dtype, seed=3)
+    win_r = torch.empty(nwin, 49, C, dtype=dtype)
+    fake.window_map(x, win_r, B, H, W, C, shift, True)
+    win = torch.full((nwin, 49, C), 7.0, dtype=dtype).cuda()
+    dev.window_map(x.cuda(), win, B, H, W, C, shift, True)
+    assert torch.equal(win.cpu(), win_r)
+    g = rnd(nwin, 49, C, dtype=dtype, seed=4)
+    back_r = torch.empty(B, H, W, C, dtype=dtype)
+    fake.window_map(g, back_r, B, H, W, C, shift, False)
+    back = torch.empty(B, H, W, C, dtype=dtype).cuda()
+    dev.window_map(g.cuda(), back, B, H, W, C, shift, False)
+    assert torch.equal(back.cpu(), back_r)
+    rt = torch.empty(B, H, W, C, dtype=dtype).cuda()
+    dev.window_map(win, rt, B, H, W, C, shift, False)
+    assert torch.equal(rt.cpu(), x)
