@@ -33,8 +33,8 @@ def parse():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="EXPERIMENTAL: replay zero_grad+forward+losses+backward from one HIP graph (see DESIGN.md §7)")
+    ap.add_argument("--no-graph", dest="graph", action="store_false",
+                    help="launch every kernel eagerly instead of replaying zero_grad+forward+losses+backward from one HIP graph")
     ap.add_argument("--cpu-baseline-budget-s", type=float, default=25.0)
     ap.add_argument("--kernel-timing", action="store_true", default=True)
     return ap.parse_args()
@@ -131,6 +131,7 @@ def main():
                    "global_batch": a.batch * world, "parallelism": "dp%d" % world,
                    "step_gflop_per_image": STEP_GFLOP_PER_IMAGE,
                    "whole_step_mfma_frac": round(ips / world * STEP_GFLOP_PER_IMAGE / 1000.0 / PEAK_MFMA_BF16_TFLOPS, 5),
+                   "launch": "hipgraph" if a.graph and all(e["graph"] is not None for e in step._graphs.values()) else "eager",
                    "final_loss": round(float(total), 4)},
         "roofline": roofline,
     }

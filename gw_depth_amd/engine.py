@@ -13,6 +13,7 @@ optimizer / DDP setup of /root/reference/src/main_glassrgbd.py:46-67, re-laid fo
   stay zero — no find_unused_parameters graph walk, no buffer broadcasts.
 """
 import math
+import warnings
 
 import torch
 import torch.distributed as dist
@@ -42,6 +43,7 @@ class TrainStep:
         self._pack_cache = {}
         self.use_graph = bool(graph)      # capture zero_grad+forward+losses+backward of a batch signature in one HIP graph
         self._graphs = {}
+        self._gstream = None
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (data_parallel and dist.is_available() and dist.is_initialized()) else 1
         # the line-loss normaliser is the GLOBAL target count / world whenever a process group exists (glassrgbd.py:323-326)
@@ -235,6 +237,23 @@ class TrainStep:
         total.backward()
         return out, total.detach(), {k: v.detach() for k, v in terms.items()}
 
+    def _graph_stream(self):
+        """The one non-default stream every graph-mode forward/backward of this TrainStep runs on.  autograd binds
+        each parameter's AccumulateGrad node to the stream it was created under and keeps it as long as any autograd
+        graph referencing it is alive; if such a node predates the capture on another stream, its in-place gradient
+        accumulation is captured on a forked branch whose input buffers the allocator recycles without ordering."""
+        if self._gstream is None:
+            self._gstream = torch.cuda.Stream()
+        return self._gstream
+
+    def _count_memsets(self, st):
+        """Run one sync-free pass under the profiler and count the hipMemsetAsync runtime calls it makes."""
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            self._sync_free_fb(st)
+            torch.cuda.synchronize()
+        return sum(1 for e in prof.events() if e.name == "hipMemsetAsync")
+
     def _graph_entry(self, batch):
         sizes = tuple(int(len(t["labels"])) for t in batch["targets"])
         key = (tuple(batch["images"].shape), sizes)
@@ -244,23 +263,43 @@ class TrainStep:
         dev = self.flat_p.device
         st = {k: batch[k].clone() for k in ("images", "pad_mask", "depth", "seg")}
         st["packed"] = pack_targets(batch["targets"], dev)
-        side = torch.cuda.Stream()
+        side = self._graph_stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):              # warm-up off the capture stream (allocator, caches, autotuned state)
-            for _ in range(2):
-                self._sync_free_fb(st)
+        with torch.cuda.stream(side), warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            self._sync_free_fb(st)                     # allocator / lazily built caches / AccumulateGrad nodes
+            memsets = self._count_memsets(st)          # second warm-up pass, audited
         torch.cuda.current_stream().wait_stream(side)
+        reason = None
+        if any("AccumulateGrad node's stream does not match" in str(w.message) for w in caught):
+            reason = ("an autograd graph built on another stream is still alive (e.g. the outputs of an eager step): its "
+                      "AccumulateGrad nodes would be captured on a forked stream")
+        elif memsets:
+            reason = ("%d hipMemsetAsync call(s) in the step (ATen multi-block reductions zero their semaphores that way); "
+                      "memset nodes do not replay correctly in HIP graphs on this ROCm" % memsets)
+        if reason is not None:
+            warnings.warn("gw_depth_amd: HIP-graph capture refused for batch signature %r, running eager: %s" % (key, reason))
+            ent = self._graphs[key] = {"graph": None, "reason": reason}
+            return ent
         g = torch.cuda.CUDAGraph()
-        # capture on the SAME stream the warm-up ran on: autograd's AccumulateGrad nodes (created lazily in the first
-        # backward) are bound to the stream they were created under; a different capture stream would run the in-place
-        # gradient accumulation of the non-kernel-accumulated parameters outside the captured order.
         with torch.cuda.graph(g, stream=side):
             res = self._sync_free_fb(st)
         ent = self._graphs[key] = {"graph": g, "static": st, "result": res}
         return ent
 
+    def _on_graph_stream(self, batch, taps):
+        """Eager forward/backward of a graph-mode TrainStep: same stream as the captures (see _graph_stream)."""
+        side = self._graph_stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            res = self.forward_backward(batch, taps)
+        torch.cuda.current_stream().wait_stream(side)
+        return res
+
     def _graph_step(self, batch):
         ent = self._graph_entry(batch)
+        if ent["graph"] is None:
+            return self._on_graph_stream(batch, None)
         st = ent["static"]
         for k in ("images", "pad_mask", "depth", "seg"):
             st[k].copy_(batch[k], non_blocking=True)
@@ -280,8 +319,8 @@ class TrainStep:
 
     def __call__(self, batch, taps=None):
         """batch: dict(images (B,3,H,W), pad_mask (B,H,W) bool, depth (B,1,H,W), seg (B,1,H,W) i64, targets)."""
-        if self.use_graph and taps is None and batch["images"].is_cuda:
-            out, total, terms = self._graph_step(batch)
+        if self.use_graph and batch["images"].is_cuda:
+            out, total, terms = self._graph_step(batch) if taps is None else self._on_graph_stream(batch, taps)
         else:
             out, total, terms = self.forward_backward(batch, taps)
         self.optimizer_step()

@@ -25,6 +25,7 @@ ENTRY_POINTS = [
     "gwd_sqnorm", "gwd_adamw_step", "gwd_resample_forward", "gwd_resample_backward", "gwd_avgpool_forward",
     "gwd_avgpool_backward", "gwd_winattn_forward", "gwd_winattn_backward", "gwd_tokattn_forward",
     "gwd_tokattn_backward", "gwd_certain_sample", "gwd_lsap", "gwd_window_map",
+    "gwd_inorm_gelu_forward", "gwd_inorm_gelu_backward",
 ]
 
 
@@ -121,6 +122,8 @@ class HipLibrary:
         L.gwd_tokattn_backward.argtypes = [sp] * 7 + [i64, i32, i32, f32, i32, vp]
         L.gwd_certain_sample.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp]
         L.gwd_lsap.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
+        L.gwd_inorm_gelu_forward.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, ctypes.c_float, i32, vp]
+        L.gwd_inorm_gelu_backward.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp]
         L.gwd_window_map.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_sqnorm.argtypes = [vp, vp, i64, vp]
         L.gwd_adamw_step.argtypes = [vp, vp, vp, vp, vp, vp, i64] + [f32] * 9 + [vp]
@@ -267,6 +270,14 @@ class HipLibrary:
         L_, B, Q, sumT = cost.shape
         self._check(self.lib.gwd_lsap(_ptr(cost), _ptr(col_offsets), _ptr(out), L_, B, Q, sumT, max_targets,
                                       self._stream(cost, col_offsets, out)), "gwd_lsap")
+
+    def inorm_gelu_forward(self, a, u, y, part, stat, B, L, C, S, eps):
+        self._check(self.lib.gwd_inorm_gelu_forward(_ptr(a), _ptr(u), _ptr(y), _ptr(part), _ptr(stat), B, L, C, S, eps,
+                                                    dtype_code(u), self._stream(a, u, y)), "gwd_inorm_gelu_forward")
+
+    def inorm_gelu_backward(self, gy, u, stat, part, du, B, L, C, S):
+        self._check(self.lib.gwd_inorm_gelu_backward(_ptr(gy), _ptr(u), _ptr(stat), _ptr(part), _ptr(du), B, L, C, S,
+                                                     dtype_code(u), self._stream(gy, u, du)), "gwd_inorm_gelu_backward")
 
     def window_map(self, src, dst, B, H, W, C, shift, gather):
         self._check(self.lib.gwd_window_map(_ptr(src), _ptr(dst), B, H, W, C, shift, int(gather), dtype_code(src),

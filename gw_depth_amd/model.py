@@ -371,10 +371,7 @@ class WindowAttention(WindowAttnBase):
         ra = torch.einsum("bwhnd,bhrd->bwnrh", qs, ref_k).reshape(rB, nwin * N, nrf, HEADS)  # pixel-major (B, nWin*N, nrf, heads)
         for _ in range(3):                                                        # :299-302
             upd = ops.conv2d(ra.contiguous(), self.ref_attn_diffusion.weight, self.ref_attn_diffusion.bias, pad=1)
-            uf = upd.float()
-            mu = uf.mean(dim=(1, 2), keepdim=True)
-            var = uf.var(dim=(1, 2), keepdim=True, unbiased=False)
-            ra = ra + F.gelu((uf - mu) * torch.rsqrt(var + 1e-5)).to(ra.dtype)
+            ra = ops.inorm_gelu_residual(ra, upd, 1e-5)
         ra = ra.reshape(rB, nwin, N, nrf, HEADS).permute(0, 1, 4, 2, 3)          # (rB, nwin, nH, N, nrf)
         att = ops.softmax_lastdim(ra)
         q_new = torch.einsum("bwhnr,bhrd->bwnhd", att, ref_v).reshape(B_, N, HEADS, hd)      # second *scale: in-kernel
@@ -572,8 +569,9 @@ class PointBasedPred(nn.Module):
         rg = torch.bmm(xg, refer.flatten(2).to(xg.dtype)) * (self.dim ** -2)            # (B, HW, S) = pixel-major map
         # NB: when H or W < 16 the pyramid zero-pads its map and the reference keeps the padded size (:94-125)
         att = ops.softmax_lastdim(self.pyramid(rg.view(B, H, W, -1)))
-        pred = (att.float() * anchor.view(B, 1, 1, -1)).sum(dim=-1, keepdim=True)
-        return pred.permute(0, 3, 1, 2)                                                   # (B,1,H',W') fp32
+        Ho, Wo, R = att.shape[1], att.shape[2], att.shape[3]
+        pred = torch.bmm(att.float().view(B, Ho * Wo, R), anchor.view(B, R, 1))         # sum_r att * anchor depth
+        return pred.view(B, 1, Ho, Wo)                                                  # (B,1,H',W') fp32
 
 
 @torch.no_grad()
@@ -661,8 +659,8 @@ class ReferTransformer(nn.Module):
             return proj(up) + proj_bb(feat).flatten(1, 2), Hn, Wn
 
         x1, H1, W1 = stage(x, H, W, feats[2], self.proj_class1, self.proj_backbn1)
-        dtok = self.depth_token.to(dt).expand(B, H1 * W1, -1)
-        stok = self.seg_token.to(dt).expand(B, H1 * W1, -1)
+        dtok = ops.broadcast_rows(self.depth_token, B, H1 * W1, dt)
+        stok = ops.broadcast_rows(self.seg_token, B, H1 * W1, dt)
         x1, dtok, stok = self.class_transformer1(x1, H1, W1, dtok=dtok, stok=stok)
         depth1 = sig_head(torch.cat([x1, dtok], dim=-1), self.depth_pred16).float().view(B, 1, H1, W1)
         md = cfg.min_depth_eval / cfg.max_depth_eval

@@ -492,3 +492,57 @@ def window_gather(x, shift):
 def window_scatter(win, B, H, W, shift):
     """Inverse of window_gather (window reverse, un-shift, crop) -> (B,H,W,C)."""
     return _WindowScatterFn.apply(win, int(B), int(H), int(W), int(shift))
+
+
+class _InormGeluFn(torch.autograd.Function):
+    SLICES = 32
+
+    @staticmethod
+    def forward(ctx, a, u, eps):
+        a, u = a.contiguous(), u.contiguous()
+        B, C = u.shape[0], u.shape[-1]
+        L = u.numel() // (B * C)
+        S = _InormGeluFn.SLICES
+        y = torch.empty_like(u)
+        part = torch.empty((B, S, C, 2), dtype=torch.float32, device=u.device)
+        stat = torch.empty((B, C, 2), dtype=torch.float32, device=u.device)
+        _lib().inorm_gelu_forward(a, u, y, part, stat, B, L, C, S, float(eps))
+        ctx.save_for_backward(u, stat)
+        ctx.cfg = (B, L, C, S)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        u, stat = ctx.saved_tensors
+        B, L, C, S = ctx.cfg
+        gy = gy.contiguous()
+        du = torch.empty_like(u)
+        part = torch.empty((B, S, C, 2), dtype=torch.float32, device=u.device)
+        _lib().inorm_gelu_backward(gy, u, stat, part, du, B, L, C, S)
+        return gy, du, None
+
+
+def inorm_gelu_residual(a, u, eps=1e-5):
+    """a + gelu(instance_norm(u)): statistics over every dim but the first (image) and last (channel)."""
+    return _InormGeluFn.apply(a, u, eps)
+
+
+class _BroadcastRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, row, B, L, dtype):
+        ctx.src = (row.shape, row.dtype)
+        return row.reshape(1, 1, -1).to(dtype).expand(B, L, -1).contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, dtype = ctx.src
+        g = g.contiguous()
+        C = g.shape[-1]
+        out = torch.zeros(C, dtype=torch.float32, device=g.device)
+        _lib().colsum(g, out, g.numel() // C, C)
+        return out.to(dtype).reshape(shape), None, None, None
+
+
+def broadcast_rows(row, B, L, dtype):
+    """(.., C) parameter row -> materialised (B, L, C); the gradient is one column-sum kernel."""
+    return _BroadcastRowsFn.apply(row, int(B), int(L), dtype)

@@ -161,6 +161,16 @@ int gwd_certain_sample(const float *pred_small, const float *pred_large, float *
 int gwd_lsap(const float *cost, const int32_t *col_offsets, int32_t *query_of_target, int32_t layers, int32_t B,
              int32_t Q, int32_t sum_targets, int32_t max_targets, void *stream);
 
+/* y = a + gelu((u - mean_bc(u)) * rsqrt(var_bc(u) + eps)), statistics over the L positions of image b for channel c;
+ * a, u, y are (B, L, C), channel innermost (src/models/multiscale_transformerr.py:299-302: conv -> instance
+ * normalisation -> GELU -> residual of the reference-point attention logits).  part: fp32 scratch [B][S][C][2]
+ * (S slices per image, caller-chosen, fully overwritten); stat: fp32 [B][C][2] = (mean, rstd) saved for backward.
+ * backward: du from gy (the gradient w.r.t. a is gy itself).  C * sizeof(dtype) / 16 must be a power of two.     */
+int gwd_inorm_gelu_forward(const void *a, const void *u, void *y, float *part, float *stat, int64_t B, int64_t L, int32_t C,
+                           int32_t S, float eps, int32_t dtype, void *stream);
+int gwd_inorm_gelu_backward(const void *gy, const void *u, const float *stat, float *part, void *du, int64_t B, int64_t L,
+                            int32_t C, int32_t S, int32_t dtype, void *stream);
+
 /* Window partition (gather != 0) / reverse (gather == 0) of a (B,H,W,C) token map into (B*nWin,49,C) 7x7 windows
  * with zero padding to multiples of 7 and cyclic shift `shift` (src/models/multiscale_transformerr.py:667-676,
  * 705-707 / 730-747).  C * sizeof(dtype) must be a multiple of 16.                                            */

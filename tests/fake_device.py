@@ -312,3 +312,19 @@ class FakeDevice:
             if shift:
                 x = torch.roll(x, shifts=(shift, shift), dims=(1, 2))
             dst.copy_(x[:, :H, :W].reshape(dst.shape))
+
+    def inorm_gelu_forward(self, a, u, y, part, stat, B, L, C, S, eps):
+        uf = u.reshape(B, L, C).float()
+        mu = uf.mean(dim=1, keepdim=True)
+        var = uf.var(dim=1, keepdim=True, unbiased=False)
+        rstd = torch.rsqrt(var + eps)
+        y.copy_((a.reshape(B, L, C).float() + F.gelu((uf - mu) * rstd)).reshape(y.shape))
+        stat.copy_(torch.stack([mu.reshape(B, C), rstd.reshape(B, C)], dim=-1).reshape(stat.shape))
+
+    def inorm_gelu_backward(self, gy, u, stat, part, du, B, L, C, S):
+        st = stat.reshape(B, 1, C, 2)
+        n = (u.reshape(B, L, C).float() - st[..., 0]) * st[..., 1]
+        cdf = 0.5 * (1 + torch.erf(n * 0.7071067811865476))
+        pdf = 0.3989422804014327 * torch.exp(-0.5 * n * n)
+        gn = gy.reshape(B, L, C).float() * (cdf + n * pdf)
+        du.copy_((st[..., 1] * (gn - gn.mean(dim=1, keepdim=True) - n * (gn * n).mean(dim=1, keepdim=True))).reshape(du.shape))

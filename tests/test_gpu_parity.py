@@ -67,11 +67,11 @@ def test_index_ops_bit_exact_on_identical_operands():
     assert torch.equal(torch.topk(logits[:, :, 0].cuda(), 20, dim=-1)[1].cpu(), torch.topk(logits[:, :, 0], 20, dim=-1)[1])
 
 
-@pytest.mark.skip(reason="HIP-graph replay of the full step is experimental: intermittent non-finite replays at 480x640 "
-                         "under investigation (DESIGN.md §7); the sync-free pieces it relies on are tested individually")
 def test_hip_graph_step_equals_eager_step():
     """The captured step (zero_grad + forward + losses + backward in one HIP graph, device LSAP / CertainSample, no host
-    sync) must reproduce the eager step: same loss terms, same flat gradient, same parameters after AdamW."""
+    sync) must reproduce the eager step: same loss terms, same flat gradient, same parameters after AdamW.  Step 1 is
+    compared tightly; steps 2-3 (replays on memory the previous replay left behind) loosely, because AdamW's first
+    updates are ~lr*sign(g) and amplify atomic-order noise in near-zero gradients."""
     from gw_depth_amd.engine import TrainStep
     from gw_depth_amd.synth import synth_batch
     b = to_device(synth_batch(2, 96, 128, seed=41, n_lines=[4, 6]), "cuda")
@@ -79,17 +79,22 @@ def test_hip_graph_step_equals_eager_step():
     for graph in (False, True):
         cfg, model, crits = build(device="cuda")
         step = TrainStep(model, crits, cfg, compute_dtype=torch.float32, graph=graph)
-        for _ in range(2):
+        snaps = []
+        for _ in range(3):
             out, total, terms = step(b)
-        torch.cuda.synchronize()
-        res.append((float(total), {k: float(v) for k, v in terms.items()}, step.flat_g.clone(), step.flat_p.clone(),
-                    out["pred_depth"][-1].clone()))
-    (l0, t0, g0, p0, d0), (l1, t1, g1, p1, d1) = res
-    assert abs(l0 - l1) <= 2e-5 * abs(l0)
-    for k in t0:
-        assert abs(t0[k] - t1[k]) <= 2e-5 * max(1.0, abs(t0[k])), k
-    assert rel(d1, d0) < 1e-5
-    assert rel(g1, g0) < 1e-3 and rel(p1, p0) < 1e-6
+            torch.cuda.synchronize()
+            snaps.append((float(total), {k: float(v) for k, v in terms.items()}, step.flat_g.clone(), step.flat_p.clone(),
+                          out["pred_depth"][-1].clone()))
+        if graph:
+            assert all(e["graph"] is not None for e in step._graphs.values()), "capture was refused"
+        res.append(snaps)
+    for i, tol in ((0, 2e-5), (2, 1e-3)):
+        (l0, t0, g0, p0, d0), (l1, t1, g1, p1, d1) = res[0][i], res[1][i]
+        assert abs(l0 - l1) <= tol * abs(l0), i
+        for k in t0:
+            assert abs(t0[k] - t1[k]) <= tol * max(1.0, abs(t0[k])), (i, k)
+        assert rel(d1, d0) < tol
+        assert rel(g1, g0) < 50 * tol and rel(p1, p0) < 1e-5
 
 
 def test_device_matcher_step_equals_host_matcher_step():

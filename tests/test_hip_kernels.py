@@ -367,3 +367,27 @@ def test_window_map(dev, shape, dtype):
     rt = torch.empty(B, H, W, C, dtype=dtype).cuda()
     dev.window_map(win, rt, B, H, W, C, shift, False)
     assert torch.equal(rt.cpu(), x)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(8, 17640, 16, 32), (2, 441, 16, 32), (3, 100, 16, 7), (2, 50, 32, 64), (1, 5, 8, 4)])
+def test_inorm_gelu(dev, shape, dtype):
+    B, L, C, S = shape
+    if (C * (2 if dtype == torch.bfloat16 else 4)) % 16:
+        pytest.skip("channel vector not 16-byte")
+    fake = FakeDevice()
+    a, u = rnd(B, L, C, dtype=dtype, seed=5), (rnd(B, L, C, dtype=dtype, seed=6) * 0.7 + 1.5).to(dtype)
+    gy = rnd(B, L, C, dtype=dtype, seed=7)
+    y_r, du_r = torch.empty(B, L, C), torch.empty(B, L, C)
+    stat_r = torch.empty(B, C, 2)
+    fake.inorm_gelu_forward(a, u, y_r, None, stat_r, B, L, C, S, 1e-5)
+    fake.inorm_gelu_backward(gy, u, stat_r, None, du_r, B, L, C, S)
+    y, du = torch.empty(B, L, C, dtype=dtype).cuda(), torch.empty(B, L, C, dtype=dtype).cuda()
+    part = torch.full((B, S, C, 2), float("nan")).cuda()
+    stat = torch.full((B, C, 2), float("nan")).cuda()
+    dev.inorm_gelu_forward(a.cuda(), u.cuda(), y, part, stat, B, L, C, S, 1e-5)
+    assert rel(stat, stat_r) < 2e-5
+    part.fill_(float("nan"))
+    dev.inorm_gelu_backward(gy.cuda(), u.cuda(), stat, part, du, B, L, C, S)
+    torch.cuda.synchronize()
+    assert rel(y, y_r) < TOL[dtype] and rel(du, du_r) < TOL[dtype]
