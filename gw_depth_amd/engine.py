@@ -281,9 +281,19 @@ class TrainStep:
             warnings.warn("gw_depth_amd: HIP-graph capture refused for batch signature %r, running eager: %s" % (key, reason))
             ent = self._graphs[key] = {"graph": None, "reason": reason}
             return ent
+        if self.norm_world > 1:                     # communicator set-up (allocations, helper threads) finishes before capture
+            dist.all_reduce(torch.zeros(1, device=dev), group=self.pg)
+            torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=side):
-            res = self._sync_free_fb(st)
+        # thread_local: RCCL's watchdog / proxy threads may touch the runtime while this thread captures
+        try:
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                res = self._sync_free_fb(st)
+        except RuntimeError as e:                   # capture invalidated: keep training, eagerly, and say so
+            torch.cuda.synchronize()
+            warnings.warn("gw_depth_amd: HIP-graph capture failed for batch signature %r, running eager: %s" % (key, e))
+            ent = self._graphs[key] = {"graph": None, "reason": str(e)}
+            return ent
         ent = self._graphs[key] = {"graph": g, "static": st, "result": res}
         return ent
 
