@@ -332,6 +332,15 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const gwd_conv_desc d) {
 // Out-of-image taps / rows are fetched from a caller-provided zero page, which keeps every lane active.
 // GM: 0 = plain conv gather, 1 = transposed gather with stride 1 (data gradient of a stride-1 layer), 2 = any
 // (decided at run time): the two hot cases get a straight-line address path.
+// Workgroups are dispatched round-robin over the 8 XCDs (each with a private L2): remap the hardware workgroup id so
+// that every XCD works on one CONTIGUOUS band of the logical tile order; tiles that re-read the same operand bytes
+// (filter-tap halos of neighbouring pixel strips, the column tiles of one row tile, the tiles of one reduction split)
+// are then neighbours in one L2 instead of eight HBM readers.
+__device__ __forceinline__ int xcd_band(int id, int total) {
+    const int xcd = id & 7, idx = id >> 3, per = total >> 3, rem = total & 7;
+    return xcd * per + (xcd < rem ? xcd : rem) + idx;
+}
+
 template <int BM, int BN, int WM, int WN, int STAGES, int GM>
 __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_desc d) {
     typedef __bf16 T;
@@ -351,7 +360,9 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
     const int M = d.B * d.Ho * d.Wo, N = d.Cout, K = d.KH * d.KW * d.Cin;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int n_tiles = (N + BN - 1) / BN;
+    const int tile = xcd_band(blockIdx.x, ((M + BM - 1) / BM) * n_tiles);      // column tiles of a row tile are adjacent
+    const int m0 = (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;
     const T *x = (const T *)d.x;
     const T *wgt = (const T *)d.w;
     const char *zero = (const char *)d.zero_page;
@@ -408,7 +419,11 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int KT = K / BK;
-    int u_kh = 0, u_kw = 0, u_c0 = 0, u_kt = 0;          // filter tap of the next tile to issue (workgroup-uniform)
+    // reduction order: 64-channel group (one 128-byte line per pixel) outermost, then the filter taps, then the two
+    // 32-channel halves of the group - a pixel's line is re-read for the next tap / half one or two tiles later, while
+    // it is still in L2 (tap-outermost order has a reuse distance of Cin/32 tiles x every resident workgroup).
+    int u_kh = 0, u_kw = 0, u_cb = 0, u_sub = 0, u_c0 = 0;  // workgroup-uniform state of the next tile to issue
+    int u_grp = d.Cin >= 64 ? 2 : 1;                     // 32-channel tiles in the current group
     auto issue = [&](int stage) {
         char *sb = smem + stage * STAGE_BYTES;
 #pragma unroll
@@ -446,20 +461,23 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             if (i < my_b_loads) {                                 // wave-uniform
-                const char *src = b_ok[i] ? b_src[i] + (size_t)u_kt * (BK * 2) : zero;
+                const char *src = b_ok[i] ? b_src[i] + (size_t)((u_kh * d.KW + u_kw) * d.Cin + u_c0) * 2 : zero;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(sb + BM * 64 + (wave + i * NW) * 1024), 16, 0, 0);
             }
         }
-        ++u_kt;
-        u_c0 += BK;
-        if (u_c0 >= d.Cin) {
-            u_c0 = 0;
+        if (++u_sub == u_grp) {
+            u_sub = 0;
             if (++u_kw == d.KW) {
                 u_kw = 0;
-                ++u_kh;
+                if (++u_kh == d.KH) {
+                    u_kh = 0;
+                    u_cb += 64;
+                    u_grp = d.Cin - u_cb >= 64 ? 2 : 1;
+                }
             }
         }
+        u_c0 = u_cb + u_sub * BK;
     };
     const int fr = lane & 31, fh = lane >> 5;
     auto compute = [&](int stage) {
@@ -774,8 +792,12 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(const gwd_conv_des
     const int M = d.B * d.Ho * d.Wo, N = d.Cout, K = d.KH * d.KW * d.Cin;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WK, wk = wave % WK;
-    const int kb0 = blockIdx.x * BKW, n0 = blockIdx.y * BNW;
-    const int m_begin = blockIdx.z * m_per_block;
+    // one XCD owns a contiguous run of (split, tile) pairs: all tiles of a reduction split re-read the same pixels
+    const int k_tiles = (K + BKW - 1) / BKW, tiles = k_tiles * ((N + BNW - 1) / BNW);
+    const int band_id = xcd_band(blockIdx.x, gridDim.x);
+    const int tile = band_id % tiles;
+    const int kb0 = (tile % k_tiles) * BKW, n0 = (tile / k_tiles) * BNW;
+    const int m_begin = (band_id / tiles) * m_per_block;
     const int m_end = min(M, m_begin + m_per_block);
     const T *gy = (const T *)d.y;
     const T *x = (const T *)d.x;
@@ -991,13 +1013,13 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
             const bool big = big_tiles_enabled() && M >= 256 * 512;      // >= 2 workgroups per CU with 256-row tiles
             const unsigned gm2 = (M + 255) / 256;
             if (N % 160 == 0) {
-                if (big) { DMA_LAUNCH(256, 160, 8, 1, 3, dim3(gm2, N / 160)) } else { DMA_LAUNCH(128, 160, 4, 1, 3, dim3(gm, N / 160)) }
+                if (big) { DMA_LAUNCH(256, 160, 8, 1, 3, dim3(gm2 * (N / 160))) } else { DMA_LAUNCH(128, 160, 4, 1, 3, dim3(gm * (N / 160))) }
             } else if (N > 64) {
-                if (big) { DMA_LAUNCH(256, 128, 4, 2, 3, dim3(gm2, (N + 127) / 128)) } else { DMA_LAUNCH(128, 128, 2, 2, 3, dim3(gm, (N + 127) / 128)) }
+                if (big) { DMA_LAUNCH(256, 128, 4, 2, 3, dim3(gm2 * ((N + 127) / 128))) } else { DMA_LAUNCH(128, 128, 2, 2, 3, dim3(gm * ((N + 127) / 128))) }
             } else if (N > 32) {
-                DMA_LAUNCH(128, 64, 2, 2, 4, dim3(gm, 1))
+                DMA_LAUNCH(128, 64, 2, 2, 4, dim3(gm))
             } else {
-                DMA_LAUNCH(128, 32, 4, 1, 4, dim3(gm, 1))
+                DMA_LAUNCH(128, 32, 4, 1, 4, dim3(gm))
             }
 #undef DMA_LAUNCH
             GWD_CHECK_LAUNCH();
@@ -1056,8 +1078,7 @@ int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s) {
     {                                                                                                        \
         const int tiles = ((N + BN_ - 1) / BN_) * ((K + BK_ - 1) / BK_);                                     \
         wgrad_split(M, tiles, 32, splits, m_per_block);                                                      \
-        dim3 grid((K + BK_ - 1) / BK_, (N + BN_ - 1) / BN_, splits);                                         \
-        if (grid.y > 65535 || grid.z > 65535) return -8;                                                     \
+        dim3 grid((unsigned)tiles * splits);                                                                 \
         igemm_wgrad_dma_kernel<BN_, BK_, WN_, WK_, ST_><<<grid, 256, 0, s>>>(*d, dw, m_per_block);           \
     }
             const int var = wgrad_variant();

@@ -15,6 +15,10 @@ SHAPES = [  # B, H, W, Cin, Cout, K
 ]
 
 
+if os.environ.get("SHAPES"):
+    SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["SHAPES"].split(";")]
+
+
 def timeit(fn, n=20):
     for _ in range(3):
         fn()
