@@ -47,11 +47,26 @@ __device__ __forceinline__ bool src_pixel(const gwd_conv_desc &d, int oh, int ow
 // One 16-byte vector of the im2col row of output pixel (b,oh,ow) starting at flattened k0.
 template <typename T>
 __device__ __forceinline__ uint4 gather_vec(const gwd_conv_desc &d, bool row_ok, int b, int oh, int ow, int k0, int K,
-                                            bool fast) {
+                                            bool fast, bool half) {
     constexpr int VEC = Cfg<T>::VEC;
     uint4 r = make_uint4(0u, 0u, 0u, 0u);
     if (!row_ok || k0 >= K) return r;
     const T *x = (const T *)d.x;
+    if (half) {                 // Cin % (VEC/2) == 0 (e.g. the 60 / 300 channel pyramids): two 8-byte pieces, one tap each
+        uint2 h[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int k = k0 + e * (VEC / 2);
+            if (k < K) {
+                const int tap = k / d.Cin, c = k - tap * d.Cin;
+                const int kh = tap / d.KW, kw = tap - kh * d.KW;
+                int ih, iw;
+                if (src_pixel(d, oh, ow, kh, kw, ih, iw))
+                    h[e] = *(const uint2 *)(x + ((size_t)(b * d.Hi + ih) * d.Wi + iw) * d.Cin + c);
+            }
+        }
+        return make_uint4(h[0].x, h[0].y, h[1].x, h[1].y);
+    }
     if (fast) {
         const int tap = k0 / d.Cin, c = k0 - tap * d.Cin;
         const int kh = tap / d.KW, kw = tap - kh * d.KW;
@@ -79,12 +94,17 @@ __device__ __forceinline__ uint4 gather_vec(const gwd_conv_desc &d, bool row_ok,
 
 // 16 bytes of row `n` of a row-major [rows][K] matrix starting at column k0 (zero outside).
 template <typename T>
-__device__ __forceinline__ uint4 row_vec(const T *base, int n, int N, int k0, int K, bool fast) {
+__device__ __forceinline__ uint4 row_vec(const T *base, int n, int N, int k0, int K, bool fast, bool half = false) {
     constexpr int VEC = Cfg<T>::VEC;
     uint4 r = make_uint4(0u, 0u, 0u, 0u);
     if (n >= N || k0 >= K) return r;
     const T *p = base + (size_t)n * K + k0;
     if (fast) return *(const uint4 *)p;
+    if (half) {                 // K % (VEC/2) == 0: the row is 8-byte aligned, the tile's last vector may be half full
+        const uint2 lo = *(const uint2 *)p;
+        const uint2 hi = (k0 + VEC / 2 < K) ? *(const uint2 *)(p + VEC / 2) : make_uint2(0u, 0u);
+        return make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
     T tmp[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) tmp[e] = (k0 + e < K) ? p[e] : from_f32<T>(0.f);
@@ -123,6 +143,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const gwd_conv_desc d) {
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const bool fastA = (d.Cin % VEC) == 0, fastB = (K % VEC) == 0;
+    const bool halfA = !fastA && (d.Cin % (VEC / 2)) == 0, halfB = !fastB && (K % (VEC / 2)) == 0;
     // When Cin is a multiple of BK every K tile lies inside ONE filter tap: (kh, kw, c0) are then
     // workgroup-uniform (scalar registers, advanced incrementally) and the per-thread gather costs a
     // bounds test and one multiply-add chain instead of two integer divisions per 16-byte vector.
@@ -176,12 +197,12 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const gwd_conv_desc d) {
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < A_IT; ++i) ra[i] = gather_vec<T>(d, a_ok[i], a_b[i], a_oh[i], a_ow[i], k0, K, fastA);
+            for (int i = 0; i < A_IT; ++i) ra[i] = gather_vec<T>(d, a_ok[i], a_b[i], a_oh[i], a_ow[i], k0, K, fastA, halfA);
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int row = lr + i * ROWS_PER_PASS;
-            rb[i] = (row < BN) ? row_vec<T>((const T *)d.w, n0 + row, N, k0, K, fastB) : make_uint4(0u, 0u, 0u, 0u);
+            rb[i] = (row < BN) ? row_vec<T>((const T *)d.w, n0 + row, N, k0, K, fastB, halfB) : make_uint4(0u, 0u, 0u, 0u);
         }
     };
     auto store_tiles = [&](int buf) {
@@ -602,6 +623,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const gwd_conv_desc d,
     const int m_begin = blockIdx.z * m_per_block;
     const int m_end = min(M, m_begin + m_per_block);
     const bool fastA = (d.Cin % VEC) == 0, fastY = (N % VEC) == 0;
+    const bool halfA = !fastA && (d.Cin % (VEC / 2)) == 0, halfY = !fastY && (N % (VEC / 2)) == 0;
     const T *gy = (const T *)d.y;
 
     f32x16 acc[TN][TK];
@@ -639,7 +661,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const gwd_conv_desc d,
         for (int i = 0; i < Y_IT; ++i) {
             const int idx = tid + i * 256, row = idx / YV, v = idx % YV;
             const int m = mbase + row;
-            ry[i] = (m < m_end) ? row_vec<T>(gy, m, M, n0 + v * VEC, N, fastY) : make_uint4(0u, 0u, 0u, 0u);
+            ry[i] = (m < m_end) ? row_vec<T>(gy, m, M, n0 + v * VEC, N, fastY, halfY) : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int i = 0; i < X_IT; ++i) {
@@ -652,7 +674,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const gwd_conv_desc d,
                     r = *(const uint4 *)((const T *)d.x + ((size_t)(x_b[i] * d.Hi + ih) * d.Wi + iw) * d.Cin + x_c[i]);
                 rx[i] = r;
             } else {
-                rx[i] = gather_vec<T>(d, ok, x_b[i], x_oh[i], x_ow[i], kb0 + v * VEC, K, false);
+                rx[i] = gather_vec<T>(d, ok, x_b[i], x_oh[i], x_ow[i], kb0 + v * VEC, K, false, halfA);
             }
             // advance this row's output pixel by RM for the next step
             if (HoWo == 1) {
@@ -966,6 +988,31 @@ __global__ void weight_prep_kernel(const float *__restrict__ w, const float *__r
     }
 }
 
+// Every registered weight in ONE launch: block b belongs to the job whose [block0, next block0) range holds it
+// (binary search over the table, workgroup-uniform) and converts 1024 consecutive elements of that weight.
+__global__ __launch_bounds__(256) void weight_prep_batch_kernel(const gwd_prep_job *__restrict__ jobs, int n_jobs) {
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const gwd_prep_job j = jobs[lo];
+    const size_t total = (size_t)j.N * j.taps * j.C;
+    const size_t base = (size_t)((int)blockIdx.x - j.block0) * 1024;
+    __bf16 *wf = (__bf16 *)j.w_fwd, *wd = (__bf16 *)j.w_dgrad;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const size_t i = base + e * 256 + threadIdx.x;
+        if (i >= total) break;
+        const int c = (int)(i % j.C);
+        const size_t r = i / j.C;
+        const int tap = (int)(r % j.taps), n = (int)(r / j.taps);
+        const float v = j.row_scale ? j.w[i] * j.row_scale[n] : j.w[i];
+        if (wf) wf[i] = (__bf16)v;
+        if (wd) wd[((size_t)c * j.taps + tap) * j.N + n] = (__bf16)v;
+    }
+}
+
 int check_desc(const gwd_conv_desc *d) {
     if (!d || !d->x || !d->y) return -1;
     if (d->dtype != GWD_F32 && d->dtype != GWD_BF16) return -2;
@@ -1135,6 +1182,13 @@ extern "C" int gwd_weight_prep(const float *w, const float *row_scale, void *w_f
         weight_prep_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>(w, row_scale, (float *)w_fwd, (float *)w_dgrad, N, taps, C);
     else
         return -2;
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gwd_weight_prep_batch(const gwd_prep_job *jobs, int32_t n_jobs, int32_t total_blocks, void *stream) {
+    if (!jobs || n_jobs <= 0 || total_blocks <= 0) return -1;
+    weight_prep_batch_kernel<<<total_blocks, 256, 0, (hipStream_t)stream>>>(jobs, n_jobs);
     GWD_CHECK_LAUNCH();
     return 0;
 }

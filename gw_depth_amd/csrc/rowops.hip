@@ -219,13 +219,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ g, fl
 // normalises 64/LPR rows at once (C = 64 bf16 -> 8 rows per wave, one 1 KiB coalesced load per instruction).
 // ---------------------------------------------------------------------------------------------------------
 template <typename T> struct VecOf { static constexpr int N = 16 / sizeof(T); };
+// VB = bytes per lane access: 16, or 8 for channel counts that are only a multiple of half a vector (60, 120, 300)
+template <int VB> struct Raw;
+template <> struct Raw<16> { uint4 v; };
+template <> struct Raw<8> { uint2 v; };
 
-template <typename T, int LPR, int NCH>
+template <typename T, int LPR, int NCH, int VB>
 __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T *__restrict__ x, const float *__restrict__ gamma,
                                                                 const float *__restrict__ beta, T *__restrict__ y,
                                                                 float *__restrict__ mean, float *__restrict__ rstd,
                                                                 int64_t rows, int C, int gelu) {
-    constexpr int VEC = VecOf<T>::N, RPW = 64 / LPR;
+    constexpr int VEC = VB / (int)sizeof(T), RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, sub = lane % LPR, rsel = lane / LPR;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
     float g[NCH][VEC], b[NCH][VEC];
@@ -247,8 +251,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T *__restr
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            uint4 raw = make_uint4(0u, 0u, 0u, 0u);
-            if (okr && okc[c]) raw = *(const uint4 *)(x + r * C + (sub + c * LPR) * VEC);
+            Raw<VB> raw = {};
+            if (okr && okc[c]) raw = *(const Raw<VB> *)(x + r * C + (sub + c * LPR) * VEC);
             const T *pv = (const T *)&raw;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
@@ -277,25 +281,25 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T *__restr
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             if (!(okr && okc[c])) continue;
-            T outv[VEC];
+            alignas(16) T outv[VEC];
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 float o = (v[c][e] - mu) * rs * g[c][e] + b[c][e];
                 if (gelu) o = gelu_f(o);
                 outv[e] = from_f32<T>(o);
             }
-            *(uint4 *)(y + r * C + (sub + c * LPR) * VEC) = *(const uint4 *)outv;
+            *(Raw<VB> *)(y + r * C + (sub + c * LPR) * VEC) = *(const Raw<VB> *)outv;
         }
     }
 }
 
-template <typename T, int LPR, int NCH>
+template <typename T, int LPR, int NCH, int VB>
 __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T *__restrict__ gy, const T *__restrict__ x,
                                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                 const float *__restrict__ mean, const float *__restrict__ rstd,
                                                                 T *__restrict__ gx, float *__restrict__ dgamma,
                                                                 float *__restrict__ dbeta, int64_t rows, int C, int gelu) {
-    constexpr int VEC = VecOf<T>::N, RPW = 64 / LPR;
+    constexpr int VEC = VB / (int)sizeof(T), RPW = 64 / LPR;
     __shared__ float red[2][4][LPR * NCH * VEC];      // [gamma|beta][wave][channel slot]
     const int lane = threadIdx.x & 63, sub = lane % LPR, rsel = lane / LPR, wv = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nw = (int64_t)gridDim.x * 4;
@@ -320,11 +324,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T *__restr
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            uint4 rx = make_uint4(0u, 0u, 0u, 0u), rg = make_uint4(0u, 0u, 0u, 0u);
+            Raw<VB> rx = {}, rg = {};
             const bool ok = okr && okc[c];
             if (ok) {
-                rx = *(const uint4 *)(x + r * C + (sub + c * LPR) * VEC);
-                rg = *(const uint4 *)(gy + r * C + (sub + c * LPR) * VEC);
+                rx = *(const Raw<VB> *)(x + r * C + (sub + c * LPR) * VEC);
+                rg = *(const Raw<VB> *)(gy + r * C + (sub + c * LPR) * VEC);
             }
             const T *px = (const T *)&rx;
             const T *pg = (const T *)&rg;
@@ -350,10 +354,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T *__restr
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             if (!(okr && okc[c])) continue;
-            T outv[VEC];
+            alignas(16) T outv[VEC];
 #pragma unroll
             for (int e = 0; e < VEC; ++e) outv[e] = from_f32<T>(rs * (gw[c][e] - s1 - xh[c][e] * s2));
-            *(uint4 *)(gx + r * C + (sub + c * LPR) * VEC) = *(const uint4 *)outv;
+            *(Raw<VB> *)(gx + r * C + (sub + c * LPR) * VEC) = *(const Raw<VB> *)outv;
         }
     }
     if (dgamma) {
@@ -415,15 +419,15 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T *__restrict__ g
     }
 }
 
-template <typename T>
+template <typename T, int VB>
 int launch_ln_fwd_vec(const T *x, const float *ga, const float *be, T *y, float *mean, float *rstd, int64_t rows, int C, int gelu,
                       hipStream_t s) {
-    constexpr int VEC = VecOf<T>::N;
+    constexpr int VEC = VB / (int)sizeof(T);
     const int need = C / VEC;
 #define LN_FWD(LPR, NCH)                                                                                            \
     {                                                                                                               \
         const int64_t wv = (rows + (64 / LPR) - 1) / (64 / LPR);                                                    \
-        layernorm_fwd_vec_kernel<T, LPR, NCH><<<row_grid(wv, 4), 256, 0, s>>>(x, ga, be, y, mean, rstd, rows, C, gelu); \
+        layernorm_fwd_vec_kernel<T, LPR, NCH, VB><<<row_grid(wv, 4), 256, 0, s>>>(x, ga, be, y, mean, rstd, rows, C, gelu); \
         return 0;                                                                                                   \
     }
     if (need <= 8) LN_FWD(8, 1)
@@ -435,17 +439,17 @@ int launch_ln_fwd_vec(const T *x, const float *ga, const float *be, T *y, float 
     return -5;
 }
 
-template <typename T>
+template <typename T, int VB>
 int launch_ln_bwd_vec(const T *gy, const T *x, const float *ga, const float *be, const float *mean, const float *rstd, T *gx,
                       float *dg, float *db, int64_t rows, int C, int gelu, hipStream_t s) {
-    constexpr int VEC = VecOf<T>::N;
+    constexpr int VEC = VB / (int)sizeof(T);
     const int need = C / VEC;
 #define LN_BWD(LPR, NCH)                                                                                            \
     {                                                                                                               \
         const int64_t wv = (rows + (64 / LPR) - 1) / (64 / LPR);                                                    \
         int grid = row_grid(wv, 4);                                                                                 \
         if (grid > 768) grid = 768;                                                                                 \
-        layernorm_bwd_vec_kernel<T, LPR, NCH><<<grid, 256, 0, s>>>(gy, x, ga, be, mean, rstd, gx, dg, db, rows, C, gelu); \
+        layernorm_bwd_vec_kernel<T, LPR, NCH, VB><<<grid, 256, 0, s>>>(gy, x, ga, be, mean, rstd, gx, dg, db, rows, C, gelu); \
         return 0;                                                                                                   \
     }
     if (need <= 8) LN_BWD(8, 1)
@@ -470,11 +474,12 @@ extern "C" int gwd_layernorm_forward(const void *x, const float *gamma, const fl
     if ((gamma == nullptr) != (beta == nullptr)) return -1;
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GWD_BF16 && C % 8 == 0) {
-        int rc = launch_ln_fwd_vec<__bf16>((const __bf16 *)x, gamma, beta, (__bf16 *)y, mean, rstd, rows, C, gelu, s);
-        if (rc == 0) { GWD_CHECK_LAUNCH(); return 0; }
-    } else if (dtype == GWD_F32 && C % 4 == 0) {
-        int rc = launch_ln_fwd_vec<float>((const float *)x, gamma, beta, (float *)y, mean, rstd, rows, C, gelu, s);
+    {
+        int rc = -5;
+        if (dtype == GWD_BF16 && C % 8 == 0) rc = launch_ln_fwd_vec<__bf16, 16>((const __bf16 *)x, gamma, beta, (__bf16 *)y, mean, rstd, rows, C, gelu, s);
+        else if (dtype == GWD_BF16 && C % 4 == 0) rc = launch_ln_fwd_vec<__bf16, 8>((const __bf16 *)x, gamma, beta, (__bf16 *)y, mean, rstd, rows, C, gelu, s);
+        else if (dtype == GWD_F32 && C % 4 == 0) rc = launch_ln_fwd_vec<float, 16>((const float *)x, gamma, beta, (float *)y, mean, rstd, rows, C, gelu, s);
+        else if (dtype == GWD_F32 && C % 2 == 0) rc = launch_ln_fwd_vec<float, 8>((const float *)x, gamma, beta, (float *)y, mean, rstd, rows, C, gelu, s);
         if (rc == 0) { GWD_CHECK_LAUNCH(); return 0; }
     }
     const int grid = row_grid(rows, 4);
@@ -492,11 +497,12 @@ extern "C" int gwd_layernorm_backward(const void *gy, const void *x, const float
     if ((dgamma == nullptr) != (dbeta == nullptr)) return -1;
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GWD_BF16 && C % 8 == 0) {
-        int rc = launch_ln_bwd_vec<__bf16>((const __bf16 *)gy, (const __bf16 *)x, gamma, beta, mean, rstd, (__bf16 *)gx, dgamma, dbeta, rows, C, gelu, s);
-        if (rc == 0) { GWD_CHECK_LAUNCH(); return 0; }
-    } else if (dtype == GWD_F32 && C % 4 == 0) {
-        int rc = launch_ln_bwd_vec<float>((const float *)gy, (const float *)x, gamma, beta, mean, rstd, (float *)gx, dgamma, dbeta, rows, C, gelu, s);
+    {
+        int rc = -5;
+        if (dtype == GWD_BF16 && C % 8 == 0) rc = launch_ln_bwd_vec<__bf16, 16>((const __bf16 *)gy, (const __bf16 *)x, gamma, beta, mean, rstd, (__bf16 *)gx, dgamma, dbeta, rows, C, gelu, s);
+        else if (dtype == GWD_BF16 && C % 4 == 0) rc = launch_ln_bwd_vec<__bf16, 8>((const __bf16 *)gy, (const __bf16 *)x, gamma, beta, mean, rstd, (__bf16 *)gx, dgamma, dbeta, rows, C, gelu, s);
+        else if (dtype == GWD_F32 && C % 4 == 0) rc = launch_ln_bwd_vec<float, 16>((const float *)gy, (const float *)x, gamma, beta, mean, rstd, (float *)gx, dgamma, dbeta, rows, C, gelu, s);
+        else if (dtype == GWD_F32 && C % 2 == 0) rc = launch_ln_bwd_vec<float, 8>((const float *)gy, (const float *)x, gamma, beta, mean, rstd, (float *)gx, dgamma, dbeta, rows, C, gelu, s);
         if (rc == 0) { GWD_CHECK_LAUNCH(); return 0; }
     }
     int grid = row_grid(rows, 4);

@@ -18,7 +18,7 @@ import warnings
 import torch
 import torch.distributed as dist
 
-from . import hip
+from . import hip, ops
 from .criteria import pack_targets
 from .model import NestedTensor
 
@@ -44,6 +44,7 @@ class TrainStep:
         self.use_graph = bool(graph)      # capture zero_grad+forward+losses+backward of a batch signature in one HIP graph
         self._graphs = {}
         self._gstream = None
+        self.weights = ops.WeightCache()
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (data_parallel and dist.is_available() and dist.is_initialized()) else 1
         # the line-loss normaliser is the GLOBAL target count / world whenever a process group exists (glassrgbd.py:323-326)
@@ -218,12 +219,19 @@ class TrainStep:
         self.model.train()
         packed = self._packed(batch["targets"]) if self.device_matcher else None
         match = (self.criterion.matcher, batch["targets"]) if (packed is None and hasattr(self.criterion.matcher, "prefetch")) else None
-        out = self.model(NestedTensor(batch["images"], batch["pad_mask"]), taps=taps, match=match)
-        total, terms = self.losses(out, batch["depth"], batch["seg"], batch["targets"], packed=packed)
-        self.zero_grad()
-        self._begin_backward()
-        total.backward()
-        self._finish_backward()
+        weights = self.weights if (self.compute_dtype == torch.bfloat16 and batch["images"].is_cuda) else None
+        if weights is not None:
+            weights.begin_pass()
+        try:
+            out = self.model(NestedTensor(batch["images"], batch["pad_mask"]), taps=taps, match=match)
+            total, terms = self.losses(out, batch["depth"], batch["seg"], batch["targets"], packed=packed)
+            self.zero_grad()
+            self._begin_backward()
+            total.backward()
+            self._finish_backward()
+        finally:
+            if weights is not None:
+                weights.end_pass()
         return out, total, terms
 
     # ------------------------------------------------------------------ HIP-graph path (no host sync inside)
@@ -231,10 +239,17 @@ class TrainStep:
         """zero_grad + forward + 17 losses + backward on the static tensors `st`; contains no host round trip
         (device LSAP, device CertainSample, fused losses), hence capturable."""
         self.model.train()
-        out = self.model(NestedTensor(st["images"], st["pad_mask"]), taps=st.get("taps"))
-        total, terms = self.losses(out, st["depth"], st["seg"], None, packed=st["packed"])
-        self.flat_g.zero_()
-        total.backward()
+        weights = self.weights if (self.compute_dtype == torch.bfloat16 and st["images"].is_cuda) else None
+        if weights is not None:
+            weights.begin_pass()                       # every transposed / BN-folded bf16 weight copy, one launch
+        try:
+            out = self.model(NestedTensor(st["images"], st["pad_mask"]), taps=st.get("taps"))
+            total, terms = self.losses(out, st["depth"], st["seg"], None, packed=st["packed"])
+            self.flat_g.zero_()
+            total.backward()
+        finally:
+            if weights is not None:
+                weights.end_pass()
         return out, total.detach(), {k: v.detach() for k, v in terms.items()}
 
     def _graph_stream(self):

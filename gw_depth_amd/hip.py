@@ -25,7 +25,7 @@ ENTRY_POINTS = [
     "gwd_sqnorm", "gwd_adamw_step", "gwd_resample_forward", "gwd_resample_backward", "gwd_avgpool_forward",
     "gwd_avgpool_backward", "gwd_winattn_forward", "gwd_winattn_backward", "gwd_tokattn_forward",
     "gwd_tokattn_backward", "gwd_certain_sample", "gwd_lsap", "gwd_window_map",
-    "gwd_inorm_gelu_forward", "gwd_inorm_gelu_backward",
+    "gwd_inorm_gelu_forward", "gwd_inorm_gelu_backward", "gwd_weight_prep_batch",
 ]
 
 
@@ -40,6 +40,12 @@ class ConvDesc(ctypes.Structure):
                [(n, ctypes.c_int32) for n in ("B", "Hi", "Wi", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad",
                                               "gather", "Hv", "Wv", "act")] + \
                [("act_scale", ctypes.c_float), ("dtype", ctypes.c_int32)]
+
+
+class PrepJob(ctypes.Structure):
+    """gwd_prep_job (include/gwdepth.h)."""
+    _fields_ = [("w", ctypes.c_void_p), ("row_scale", ctypes.c_void_p), ("w_fwd", ctypes.c_void_p), ("w_dgrad", ctypes.c_void_p),
+                ("N", ctypes.c_int32), ("taps", ctypes.c_int32), ("C", ctypes.c_int32), ("block0", ctypes.c_int32)]
 
 
 class Strided(ctypes.Structure):
@@ -124,6 +130,7 @@ class HipLibrary:
         L.gwd_lsap.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
         L.gwd_inorm_gelu_forward.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, ctypes.c_float, i32, vp]
         L.gwd_inorm_gelu_backward.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp]
+        L.gwd_weight_prep_batch.argtypes = [vp, i32, i32, vp]
         L.gwd_window_map.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_sqnorm.argtypes = [vp, vp, i64, vp]
         L.gwd_adamw_step.argtypes = [vp, vp, vp, vp, vp, vp, i64] + [f32] * 9 + [vp]
@@ -278,6 +285,10 @@ class HipLibrary:
     def inorm_gelu_backward(self, gy, u, stat, part, du, B, L, C, S):
         self._check(self.lib.gwd_inorm_gelu_backward(_ptr(gy), _ptr(u), _ptr(stat), _ptr(part), _ptr(du), B, L, C, S,
                                                      dtype_code(u), self._stream(gy, u, du)), "gwd_inorm_gelu_backward")
+
+    def weight_prep_batch(self, table, n_jobs, total_blocks):
+        """table: device uint8 tensor holding n_jobs packed gwd_prep_job records (see PrepJob)."""
+        self._check(self.lib.gwd_weight_prep_batch(_ptr(table), n_jobs, total_blocks, self._stream(table)), "gwd_weight_prep_batch")
 
     def window_map(self, src, dst, B, H, W, C, shift, gather):
         self._check(self.lib.gwd_window_map(_ptr(src), _ptr(dst), B, H, W, C, shift, int(gather), dtype_code(src),

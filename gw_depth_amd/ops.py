@@ -19,6 +19,85 @@ def _lib():
     return hip.library()
 
 
+class WeightCache:
+    """bf16 kernel-side copies of the conv / linear weights (row-scaled forward copy for folded FrozenBN, transposed
+    copy for the data gradient), refreshed by ONE gwd_weight_prep_batch launch per train step instead of one small
+    launch per layer.  engine.TrainStep owns one and brackets each forward/backward with begin_pass() / end_pass();
+    outside such a pass (plain ops calls, fp32 runs) every copy is made on the fly as before.  A weight first seen inside a pass is
+    prepared on the fly and joins the table for the next pass."""
+
+    def __init__(self):
+        self.jobs = {}           # key -> dict(w, rs, fwd, t)
+        self.table = None
+        self.n_jobs = self.blocks = 0
+        self.dirty = False
+        self.active = False
+        self._retired = []
+
+    @staticmethod
+    def _key(w, rs):
+        return (w.data_ptr(), tuple(w.shape), 0 if rs is None else rs.data_ptr())
+
+    def get(self, w, rs, kind):
+        """kind 'fwd' | 't' -> cached tensor, or None when the cache is not in a pass / not applicable."""
+        if not self.active or not w.is_cuda or w.dtype != torch.float32:
+            return None
+        job = self.jobs.get(self._key(w, rs))
+        if job is not None and job[kind] is not None:
+            return job[kind]        # refreshed by this pass's batch launch, or made earlier in this very pass
+        return self._add(w, rs, kind)
+
+    def _add(self, w, rs, kind):
+        key = self._key(w, rs)
+        job = self.jobs.get(key)
+        if job is None:
+            job = self.jobs[key] = {"w": w.detach(), "rs": rs, "fwd": None, "t": None}
+        N, C = w.shape[0], w.shape[-1]
+        taps = w.numel() // (N * C)
+        if kind == "fwd":
+            out = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
+            _lib().weight_prep(w.detach(), rs, out, None, N, taps, C, hip.BF16)
+        else:
+            out = torch.empty((C,) + tuple(w.shape[1:-1]) + (N,), dtype=torch.bfloat16, device=w.device)
+            _lib().weight_prep(w.detach(), rs, None, out, N, taps, C, hip.BF16)
+        job[kind] = out
+        self.dirty = True
+        return out
+
+    def begin_pass(self):
+        if self.dirty and self.jobs:
+            recs = (hip.PrepJob * len(self.jobs))()
+            b0 = 0
+            for i, job in enumerate(self.jobs.values()):
+                w = job["w"]
+                N, C = w.shape[0], w.shape[-1]
+                r = recs[i]
+                r.w, r.row_scale = w.data_ptr(), (0 if job["rs"] is None else job["rs"].data_ptr())
+                r.w_fwd = 0 if job["fwd"] is None else job["fwd"].data_ptr()
+                r.w_dgrad = 0 if job["t"] is None else job["t"].data_ptr()
+                r.N, r.taps, r.C, r.block0 = N, w.numel() // (N * C), C, b0
+                b0 += (w.numel() + 1023) // 1024
+            raw = torch.frombuffer(bytearray(bytes(recs)), dtype=torch.uint8)
+            dev = next(iter(self.jobs.values()))["w"].device
+            self._retired.append(self.table)      # a captured HIP graph may still launch with the old table
+            self.table = raw.to(dev)
+            self.n_jobs, self.blocks = len(self.jobs), b0
+            self.dirty = False
+        if self.table is not None:
+            _lib().weight_prep_batch(self.table, self.n_jobs, self.blocks)
+        self.active = True
+        global _ACTIVE_WEIGHTS
+        _ACTIVE_WEIGHTS = self
+
+    def end_pass(self):
+        global _ACTIVE_WEIGHTS
+        self.active = False
+        _ACTIVE_WEIGHTS = None
+
+
+_ACTIVE_WEIGHTS = None
+
+
 def _weight_for(w, row_scale, dtype, shadow=None):
     """Kernel-ready forward weights in the activation dtype (fp32 master -> as is)."""
     if row_scale is None:
@@ -26,6 +105,10 @@ def _weight_for(w, row_scale, dtype, shadow=None):
             return w.detach()
         if shadow is not None and shadow.dtype == dtype:
             return shadow
+    if dtype == torch.bfloat16 and _ACTIVE_WEIGHTS is not None:
+        cached = _ACTIVE_WEIGHTS.get(w, row_scale, "fwd")
+        if cached is not None:
+            return cached
     out = torch.empty(w.shape, dtype=dtype, device=w.device)
     N, C = w.shape[0], w.shape[-1]
     _lib().weight_prep(w.detach(), row_scale, out, None, N, w.numel() // (N * C), C, hip.F32 if dtype == torch.float32 else hip.BF16)
@@ -34,6 +117,10 @@ def _weight_for(w, row_scale, dtype, shadow=None):
 
 def _weight_transposed(w, row_scale, dtype):
     """[Cin][taps][Cout] copy for the data gradient."""
+    if dtype == torch.bfloat16 and _ACTIVE_WEIGHTS is not None:
+        cached = _ACTIVE_WEIGHTS.get(w, row_scale, "t")
+        if cached is not None:
+            return cached
     N, C = w.shape[0], w.shape[-1]
     taps = w.numel() // (N * C)
     out = torch.empty((C,) + tuple(w.shape[1:-1]) + (N,), dtype=dtype, device=w.device)

@@ -161,6 +161,19 @@ int gwd_certain_sample(const float *pred_small, const float *pred_large, float *
 int gwd_lsap(const float *cost, const int32_t *col_offsets, int32_t *query_of_target, int32_t layers, int32_t B,
              int32_t Q, int32_t sum_targets, int32_t max_targets, void *stream);
 
+/* gwd_weight_prep for many weights in one launch (bf16 outputs).  `jobs` is a DEVICE array; job i owns the blocks
+ * [block0_i, block0_{i+1}) of the launch, 1024 elements each, block0_0 = 0, total_blocks = sum of ceil(N*taps*C/1024).
+ * w_fwd / w_dgrad may be NULL per job.                                                                          */
+typedef struct gwd_prep_job {
+    const float *w;          /* fp32 master weight (N, taps, C)                         */
+    const float *row_scale;  /* optional per-output-row scale (folded FrozenBN), or NULL */
+    void *w_fwd;             /* bf16 (N, taps, C) or NULL                                */
+    void *w_dgrad;           /* bf16 (C, taps, N) or NULL                                */
+    int32_t N, taps, C;
+    int32_t block0;
+} gwd_prep_job;
+int gwd_weight_prep_batch(const gwd_prep_job *jobs, int32_t n_jobs, int32_t total_blocks, void *stream);
+
 /* y = a + gelu((u - mean_bc(u)) * rsqrt(var_bc(u) + eps)), statistics over the L positions of image b for channel c;
  * a, u, y are (B, L, C), channel innermost (src/models/multiscale_transformerr.py:299-302: conv -> instance
  * normalisation -> GELU -> residual of the reference-point attention logits).  part: fp32 scratch [B][S][C][2]

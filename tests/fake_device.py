@@ -328,3 +328,6 @@ class FakeDevice:
         pdf = 0.3989422804014327 * torch.exp(-0.5 * n * n)
         gn = gy.reshape(B, L, C).float() * (cdf + n * pdf)
         du.copy_((st[..., 1] * (gn - gn.mean(dim=1, keepdim=True) - n * (gn * n).mean(dim=1, keepdim=True))).reshape(du.shape))
+
+    def weight_prep_batch(self, table, n_jobs, total_blocks):
+        raise NotImplementedError("the CPU stand-in never activates the batched weight cache")

@@ -38,6 +38,8 @@ CONV_CASES = [
     ("7x7_s2_rgb", 2, 32, 40, 3, 64, 7, 2, 3, None, dict(shift=True, act=hip.ACT_RELU)),
     ("3x3_30_60_odd", 2, 12, 16, 30, 60, 3, 1, 1, None, dict()),
     ("3x3_300_120_odd", 1, 12, 16, 300, 120, 3, 1, 1, None, dict()),
+    ("3x3_60_60_half", 2, 13, 17, 60, 60, 3, 1, 1, None, dict()),
+    ("3x3_120_30_half", 1, 12, 16, 120, 30, 3, 1, 1, None, dict()),
     ("up2_64_64_elu", 2, 10, 12, 64, 64, 3, 1, 1, (20, 24), dict(act=hip.ACT_ELU)),
     ("up_size_64_32", 1, 9, 11, 64, 32, 3, 1, 1, (24, 32), dict(act=hip.ACT_ELU)),
     ("3x3_32_1_sig10", 2, 24, 32, 32, 1, 3, 1, 1, None, dict(act=hip.ACT_SIGMOID, act_scale=10.0)),
@@ -114,7 +116,8 @@ def test_conv_forward_dgrad_wgrad(dev, case, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("rows,C,gelu,affine", [(300, 256, False, True), (1000, 64, False, True), (77, 160, True, True),
-                                                (513, 30, True, True), (64, 512, False, True), (40, 320, False, False)])
+                                                (513, 30, True, True), (64, 512, False, True), (40, 320, False, False),
+                                                (777, 60, True, True), (130, 300, True, True), (65, 120, False, True), (33, 6, False, True)])
 def test_layernorm(dev, rows, C, gelu, affine, dtype):
     fake = FakeDevice()
     x = rnd(rows, C, dtype=dtype, seed=1, scale=2.0)
@@ -391,3 +394,34 @@ def test_inorm_gelu(dev, shape, dtype):
     dev.inorm_gelu_backward(gy.cuda(), u.cuda(), stat, part, du, B, L, C, S)
     torch.cuda.synchronize()
     assert rel(y, y_r) < TOL[dtype] and rel(du, du_r) < TOL[dtype]
+
+
+def test_weight_cache_batch_refresh(dev):
+    """One gwd_weight_prep_batch launch must reproduce the per-weight gwd_weight_prep copies after the masters change."""
+    from gw_depth_amd import ops
+    torch.manual_seed(3)
+    shapes = [(64, 3, 3, 32), (160, 3, 3, 160), (256, 1, 1, 64), (10, 1, 1, 7), (30, 3, 3, 60), (2048, 1, 1, 512)]
+    ws = [torch.randn(s, device="cuda") for s in shapes]
+    rss = [None, torch.rand(160, device="cuda") + 0.5, None, None, torch.rand(30, device="cuda") + 0.5, None]
+    cache = ops.WeightCache()
+    cache.begin_pass()
+    for w, rs in zip(ws, rss):
+        assert cache.get(w, rs, "t") is not None
+        if rs is not None:
+            assert cache.get(w, rs, "fwd") is not None
+    cache.end_pass()
+    assert cache.get(ws[0], None, "t") is None                 # inactive outside a pass
+    for w in ws:
+        w.mul_(1.5).add_(0.25)
+    cache.begin_pass()                                           # table upload + ONE launch
+    assert cache.n_jobs == len(ws)
+    for w, rs in zip(ws, rss):
+        N, C = w.shape[0], w.shape[-1]
+        taps = w.numel() // (N * C)
+        ref_t = torch.empty((C,) + tuple(w.shape[1:-1]) + (N,), dtype=torch.bfloat16, device="cuda")
+        ref_f = torch.empty(w.shape, dtype=torch.bfloat16, device="cuda")
+        dev.weight_prep(w, rs, ref_f, ref_t, N, taps, C, hip.BF16)
+        assert torch.equal(cache.get(w, rs, "t"), ref_t)
+        if rs is not None:
+            assert torch.equal(cache.get(w, rs, "fwd"), ref_f)
+    cache.end_pass()
