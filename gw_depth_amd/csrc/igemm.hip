@@ -1034,6 +1034,15 @@ static bool big_tiles_enabled() {
     return v == 1;
 }
 
+static int small_tile_threshold() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GWD_SMALL_TILES");
+        v = e ? atoi(e) : 320;
+    }
+    return v;
+}
+
 static bool dma_enabled() {
     static int v = -1;
     if (v < 0) {
@@ -1062,7 +1071,13 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
             if (N % 160 == 0) {
                 if (big) { DMA_LAUNCH(256, 160, 8, 1, 3, dim3(gm2 * (N / 160))) } else { DMA_LAUNCH(128, 160, 4, 1, 3, dim3(gm * (N / 160))) }
             } else if (N > 64) {
-                if (big) { DMA_LAUNCH(256, 128, 4, 2, 3, dim3(gm2 * ((N + 127) / 128))) } else { DMA_LAUNCH(128, 128, 2, 2, 3, dim3(gm * ((N + 127) / 128))) }
+                const unsigned t128 = gm * ((N + 127) / 128);
+                const int small_thr = small_tile_threshold();
+                if (big) { DMA_LAUNCH(256, 128, 4, 2, 3, dim3(gm2 * ((N + 127) / 128))) }
+                else if ((int)t128 < small_thr) {
+                    // fewer 128x128 tiles than CUs: quarter tiles put four times as many workgroups on the chip
+                    DMA_LAUNCH(64, 64, 2, 2, 4, dim3(((M + 63) / 64) * ((N + 63) / 64)))
+                } else { DMA_LAUNCH(128, 128, 2, 2, 3, dim3(t128)) }
             } else if (N > 32) {
                 DMA_LAUNCH(128, 64, 2, 2, 4, dim3(gm))
             } else {
