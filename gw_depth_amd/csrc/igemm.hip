@@ -797,7 +797,11 @@ template <int ROWB> __device__ __forceinline__ int wg_swz(int row) {
     else return 0;
 }
 
-template <int BNW, int BKW, int WN, int WK, int STAGES>
+// FAST: 0 = any gather (per-step coordinate walk and bounds tests with divergent lanes); 1 = stride-1 'same'
+// convolution (Ho == Hi, Wo == Wi >= 11): the source pixel of output pixel m under tap (kh, kw) is m + const, so a
+// lane's address advances by a constant per step and only the in-image test needs (oh, ow), kept by branch-free
+// conditional subtractions; 2 = 1x1 / stride 1 / no padding (every Linear): purely linear, always in range.
+template <int BNW, int BKW, int WN, int WK, int STAGES, int FAST>
 __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(const gwd_conv_desc d, float *__restrict__ dw, int m_per_block) {
     typedef __bf16 T;
     constexpr int RM = 32;
@@ -831,6 +835,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(const gwd_conv_des
     bool is_y[IT], col_ok[IT];
     int row[IT], x_kh[IT], x_kw[IT], x_c[IT], x_b[IT], x_oh[IT], x_ow[IT];
     const T *y_src[IT];
+    const T *x_lin[IT];          // FAST: address of the lane's 16 bytes for output pixel 0 (advanced by pixel index)
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
         const int j = wave + 4 * i;
@@ -860,6 +865,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(const gwd_conv_des
             x_oh[i] = rem / d.Wo;
             x_ow[i] = rem - x_oh[i] * d.Wo;
         }
+        x_lin[i] = x + ((ptrdiff_t)(x_kh[i] - d.pad) * d.Wi + (x_kw[i] - d.pad)) * d.Cin + x_c[i];
     }
 
     f32x16 acc[TN][TK];
@@ -883,6 +889,20 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(const gwd_conv_des
             const char *src = zero;
             if (is_y[i]) {                                        // wave-uniform (an instruction is all-Y or all-X)
                 if (rok) src = (const char *)(y_src[i] + (size_t)issued * RM * N);
+            } else if (FAST == 2) {
+                if (rok) src = (const char *)(x_lin[i] + (size_t)(mbase + row[i]) * d.Cin);
+            } else if (FAST == 1) {
+                const int ih = x_oh[i] + x_kh[i] - d.pad, iw = x_ow[i] + x_kw[i] - d.pad;
+                const bool ok = rok & ((unsigned)ih < (unsigned)d.Hi) & ((unsigned)iw < (unsigned)d.Wi);
+                if (ok) src = (const char *)(x_lin[i] + (ptrdiff_t)(mbase + row[i]) * d.Cin);
+                x_ow[i] += RM;                                    // (oh, ow) of the lane's next pixel, image index not needed
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    const bool wrap = x_ow[i] >= d.Wo;
+                    x_ow[i] -= wrap ? d.Wo : 0;
+                    x_oh[i] += wrap ? 1 : 0;
+                    x_oh[i] -= x_oh[i] >= d.Ho ? d.Ho : 0;
+                }
             } else {
                 int ih, iw;
                 if (rok && src_pixel(d, x_oh[i], x_ow[i], x_kh[i], x_kw[i], ih, iw))
@@ -1101,13 +1121,13 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
     return 0;
 }
 
-static int wgrad_target_blocks() {
+static int wgrad_target_blocks(int resident) {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("GWD_WGRAD_BLOCKS");
-        v = e ? atoi(e) : 768;       // 256 CUs x 3 resident workgroups (48 KiB LDS): whole rounds
+        v = e ? atoi(e) : 0;
     }
-    return v;
+    return v > 0 ? v : resident;     // default: exactly one full round of resident workgroups (no tail round)
 }
 static int wgrad_variant() {
     static int v = -1;
@@ -1118,9 +1138,10 @@ static int wgrad_variant() {
     return v;
 }
 
-static void wgrad_split(int M, int tiles, int rm, int &splits, int &m_per_block) {
-    // enough M-splits to put ~4 workgroups on every CU, at least 8 reduction steps per workgroup
-    splits = (wgrad_target_blocks() + tiles - 1) / tiles;
+static void wgrad_split(int M, int tiles, int rm, int &splits, int &m_per_block, int resident = 768) {
+    // M-splits so that tiles x splits fills the chip's resident workgroup slots once; >= 8 reduction steps each
+    splits = wgrad_target_blocks(resident) / tiles;
+    if (splits * tiles < wgrad_target_blocks(resident) * 3 / 4) ++splits;     // far below a full round: round up instead
     const int max_splits = (M + 8 * rm - 1) / (8 * rm);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -1139,11 +1160,19 @@ int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s) {
 #define WG_LAUNCH(BN_, BK_, WN_, WK_, ST_)                                                                   \
     {                                                                                                        \
         const int tiles = ((N + BN_ - 1) / BN_) * ((K + BK_ - 1) / BK_);                                     \
-        wgrad_split(M, tiles, 32, splits, m_per_block);                                                      \
+        const int lds = ST_ * 32 * (BN_ + BK_) * 2, per_cu = (160 * 1024) / lds;                             \
+        wgrad_split(M, tiles, 32, splits, m_per_block, 256 * (per_cu > 4 ? 4 : per_cu));                     \
         dim3 grid((unsigned)tiles * splits);                                                                 \
-        igemm_wgrad_dma_kernel<BN_, BK_, WN_, WK_, ST_><<<grid, 256, 0, s>>>(*d, dw, m_per_block);           \
+        if (fast == 2) igemm_wgrad_dma_kernel<BN_, BK_, WN_, WK_, ST_, 2><<<grid, 256, 0, s>>>(*d, dw, m_per_block);      \
+        else if (fast == 1) igemm_wgrad_dma_kernel<BN_, BK_, WN_, WK_, ST_, 1><<<grid, 256, 0, s>>>(*d, dw, m_per_block); \
+        else igemm_wgrad_dma_kernel<BN_, BK_, WN_, WK_, ST_, 0><<<grid, 256, 0, s>>>(*d, dw, m_per_block);   \
     }
             const int var = wgrad_variant();
+            int fast = 0;
+            if (d->gather == GWD_GATHER_CONV && d->stride == 1) {
+                if (d->KH == 1 && d->KW == 1 && d->pad == 0) fast = 2;
+                else if (d->Ho == d->Hi && d->Wo == d->Wi && d->Wo >= 11) fast = 1;
+            }
             if (N % 160 == 0 && K >= 256 && var == 1) WG_LAUNCH(160, 256, 1, 4, 3)
             else if (N % 160 == 0 && K >= 128 && var != 3) WG_LAUNCH(160, 128, 1, 4, 3)
             else if (N > 64 && K >= 256 && var == 1) WG_LAUNCH(128, 256, 2, 2, 3)
