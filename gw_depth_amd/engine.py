@@ -182,15 +182,24 @@ class TrainStep:
         cfg = self.cfg
         terms = self.criterion.forward_packed(out, packed, self.norm_world) if packed is not None else self.criterion(out, targets)
         wd = self.criterion.weight_dict
-        total = sum(terms[k] * wd[k] for k in terms if k in wd)
+        keys = [k for k in terms if k in wd]
+        parts, coef = [terms[k] for k in keys], [float(wd[k]) for k in keys]
         names = ["1/16", "1/8", "1/4", "1"]
         for i, pd in enumerate(out["pred_depth"]):
             ld = self.criterion_depth.fused(pd, depth_gt, cfg.depth_loss_weights[i])
             terms["loss_depth_" + names[i]] = ld
-            total = total + ld
+            parts.append(ld)
+            coef.append(1.0)
         ls = self.criterion_seg(out["pred_seg"], seg_gt.reshape(seg_gt.shape[0], *seg_gt.shape[-2:]), cfg.seg_loss_weight)
         terms["loss_seg"] = ls
-        return total + ls, terms
+        parts.append(ls)
+        coef.append(1.0)
+        # engine_glassrgbd.py:120-134: the weighted sum of the 17 terms, as one stack/multiply/sum instead of 34 scalar kernels
+        ck = (tuple(coef), parts[0].device)
+        if getattr(self, "_coef_key", None) != ck:
+            self._coef_key, self._coef = ck, torch.tensor(coef, dtype=torch.float32, device=parts[0].device)
+        total = (torch.stack([p.float().reshape(()) for p in parts]) * self._coef).sum()
+        return total, terms
 
     # ------------------------------------------------------------------ the step
     def zero_grad(self):

@@ -26,6 +26,7 @@ ENTRY_POINTS = [
     "gwd_avgpool_backward", "gwd_winattn_forward", "gwd_winattn_backward", "gwd_tokattn_forward",
     "gwd_tokattn_backward", "gwd_certain_sample", "gwd_lsap", "gwd_window_map",
     "gwd_inorm_gelu_forward", "gwd_inorm_gelu_backward", "gwd_weight_prep_batch",
+    "gwd_point_sample_forward", "gwd_point_sample_backward",
 ]
 
 
@@ -130,6 +131,8 @@ class HipLibrary:
         L.gwd_lsap.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
         L.gwd_inorm_gelu_forward.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, ctypes.c_float, i32, vp]
         L.gwd_inorm_gelu_backward.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp]
+        L.gwd_point_sample_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+        L.gwd_point_sample_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_weight_prep_batch.argtypes = [vp, i32, i32, vp]
         L.gwd_window_map.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_sqnorm.argtypes = [vp, vp, i64, vp]
@@ -285,6 +288,14 @@ class HipLibrary:
     def inorm_gelu_backward(self, gy, u, stat, part, du, B, L, C, S):
         self._check(self.lib.gwd_inorm_gelu_backward(_ptr(gy), _ptr(u), _ptr(stat), _ptr(part), _ptr(du), B, L, C, S,
                                                      dtype_code(u), self._stream(gy, u, du)), "gwd_inorm_gelu_backward")
+
+    def point_sample_forward(self, fmap, coords, out, B, H, W, C, S, mode):
+        self._check(self.lib.gwd_point_sample_forward(_ptr(fmap), _ptr(coords), _ptr(out), B, H, W, C, S, mode, dtype_code(fmap),
+                                                      self._stream(fmap, out)), "gwd_point_sample_forward")
+
+    def point_sample_backward(self, gout, coords, gmap, B, H, W, C, S, mode):
+        self._check(self.lib.gwd_point_sample_backward(_ptr(gout), _ptr(coords), _ptr(gmap), B, H, W, C, S, mode, dtype_code(gmap),
+                                                       self._stream(gout, gmap)), "gwd_point_sample_backward")
 
     def weight_prep_batch(self, table, n_jobs, total_blocks):
         """table: device uint8 tensor holding n_jobs packed gwd_prep_job records (see PrepJob)."""

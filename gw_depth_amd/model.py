@@ -181,12 +181,12 @@ class MultiheadAttention(nn.Module):
         H, hd = self.heads, E // self.heads
         W, b = self.in_proj_weight, self.in_proj_bias
         if query is key:
-            qk = ops.linear(query, W[: 2 * E], b[: 2 * E])
+            qk = ops.linear(query, W, b, rows=(0, 2 * E))
             q, k = qk[..., :E], qk[..., E:]
         else:
-            q = ops.linear(query, W[:E], b[:E])
-            k = ops.linear(key, W[E: 2 * E], b[E: 2 * E])
-        v = ops.linear(value, W[2 * E:], b[2 * E:])
+            q = ops.linear(query, W, b, rows=(0, E))
+            k = ops.linear(key, W, b, rows=(E, 2 * E))
+        v = ops.linear(value, W, b, rows=(2 * E, 3 * E))
         q = (q * (float(hd) ** -0.5)).reshape(B, L, H, hd).transpose(1, 2)
         k = k.reshape(B, S, H, hd).transpose(1, 2)
         v = v.reshape(B, S, H, hd).transpose(1, 2)
@@ -456,9 +456,7 @@ class SwinBlock(nn.Module):
                 rpos = torch.roll(ref_pos, shifts=(-shift, -shift), dims=(1, 2))
             else:
                 rc, rpos = ref_coors, ref_pos
-            x_ref = F.grid_sample(to_nchw(sx).float(), rc, mode="nearest", align_corners=False)
-            x_ref = x_ref + F.grid_sample(to_nchw(rpos), rc, mode="nearest", align_corners=False)
-            x_ref = x_ref.reshape(B, C, -1).permute(0, 2, 1).to(x.dtype)
+            x_ref = (ops.point_sample(sx, rc, nearest=True) + ops.point_sample(rpos, rc, nearest=True)).to(x.dtype)   # (B, S, C)
             aw = self.attn(window_partition(sx), x_ref, mask)
         else:
             tC = dtok.shape[-1]
@@ -562,11 +560,10 @@ class PointBasedPred(nn.Module):
         B = x.shape[0]
         xg_xr = self.refer_proj(self.pre_proj(torch.cat([x, dtok], dim=-1)))
         xg, xr = xg_xr[..., : self.dim], xg_xr[..., self.dim:]
-        xr_map = to_nchw(xr.reshape(B, H, W, self.dim))
-        refer = F.grid_sample(xr_map.float(), coords, align_corners=False) + \
-            F.grid_sample(to_nchw(pos), coords, align_corners=False)                     # (B, dim, S, 1)
-        anchor = F.grid_sample(pre_depth.float(), coords, align_corners=False)          # (B, 1, S, 1)
-        rg = torch.bmm(xg, refer.flatten(2).to(xg.dtype)) * (self.dim ** -2)            # (B, HW, S) = pixel-major map
+        refer = ops.point_sample(xr.reshape(B, H, W, self.dim), coords) + ops.point_sample(pos, coords)   # (B, S, dim) fp32
+        hp, wp = pre_depth.shape[-2:]
+        anchor = ops.point_sample(pre_depth.float().reshape(B, hp, wp, 1), coords)       # (B, S, 1)
+        rg = torch.bmm(xg, refer.transpose(1, 2).to(xg.dtype)) * (self.dim ** -2)       # (B, HW, S) = pixel-major map
         # NB: when H or W < 16 the pyramid zero-pads its map and the reference keeps the padded size (:94-125)
         att = ops.softmax_lastdim(self.pyramid(rg.view(B, H, W, -1)))
         Ho, Wo, R = att.shape[1], att.shape[2], att.shape[3]

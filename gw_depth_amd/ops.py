@@ -241,17 +241,31 @@ def conv2d(x, w, bias=None, *, stride=1, pad=0, act=ACT_NONE, act_scale=1.0, res
                          getattr(w, "_gwd_bf16", None), sinks if (sinks[0] or sinks[1]) else None)
 
 
-def linear(x, w, bias=None, act=ACT_NONE):
-    """x (..., K) @ w(N, K)^T + bias, optional fused activation; same kernel as conv2d (1x1, one pixel per row)."""
+def linear(x, w, bias=None, act=ACT_NONE, rows=None):
+    """x (..., K) @ w(N, K)^T + bias, optional fused activation; same kernel as conv2d (1x1, one pixel per row).
+    rows=(r0, r1): use only that row range of a packed parameter (the q/k/v blocks of an attention in-projection);
+    the gradient then goes straight into that slice of the parameter's flat gradient instead of through a
+    zero-filled full-size SliceBackward temporary."""
     K = x.shape[-1]
     lead = x.shape[:-1]
     x2 = x.reshape(-1, 1, 1, K)
     shadow = getattr(w, "_gwd_bf16", None)
-    sinks = (_sink(w, (w.shape[0], 1, 1, K)), _sink(bias) if bias is not None else None)
-    y = _ConvFn.apply(x2, w.view(w.shape[0], 1, 1, K), bias, None, None, None, 1, 0, act, 1.0, None,
-                      None if shadow is None else shadow.view(w.shape[0], 1, 1, K),
+    ws, bs = _sink(w), (_sink(bias) if bias is not None else None)
+    if rows is not None:
+        r0, r1 = rows
+        if ws is not None:
+            ws = (ws[0][r0:r1], ws[1])
+        if bs is not None:
+            bs = (bs[0][r0:r1], bs[1])
+        shadow = None if shadow is None else shadow[r0:r1]
+        w = w[r0:r1]
+        bias = None if bias is None else bias[r0:r1]
+    n = w.shape[0]
+    sinks = (None if ws is None else (ws[0].view(n, 1, 1, K), ws[1]), bs)
+    y = _ConvFn.apply(x2, w.view(n, 1, 1, K), bias, None, None, None, 1, 0, act, 1.0, None,
+                      None if shadow is None else shadow.view(n, 1, 1, K),
                       sinks if (sinks[0] or sinks[1]) else None)
-    return y.view(*lead, w.shape[0])
+    return y.view(*lead, n)
 
 
 class _LayerNormFn(torch.autograd.Function):
@@ -633,3 +647,31 @@ class _BroadcastRowsFn(torch.autograd.Function):
 def broadcast_rows(row, B, L, dtype):
     """(.., C) parameter row -> materialised (B, L, C); the gradient is one column-sum kernel."""
     return _BroadcastRowsFn.apply(row, int(B), int(L), dtype)
+
+
+class _PointSampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fmap, coords, mode):
+        fmap = fmap.contiguous()
+        B, H, W, C = fmap.shape
+        coords = coords.detach().reshape(B, -1, 2).float().contiguous()
+        S = coords.shape[1]
+        out = torch.empty((B, S, C), dtype=torch.float32, device=fmap.device)
+        _lib().point_sample_forward(fmap, coords, out, B, H, W, C, S, mode)
+        ctx.save_for_backward(coords)
+        ctx.cfg = (B, H, W, C, S, mode, fmap.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (coords,) = ctx.saved_tensors
+        B, H, W, C, S, mode, dtype = ctx.cfg
+        gmap = torch.zeros((B, H, W, C), dtype=dtype, device=gout.device)
+        _lib().point_sample_backward(gout.float().contiguous(), coords, gmap, B, H, W, C, S, mode)
+        return gmap, None, None
+
+
+def point_sample(fmap, coords, nearest=False):
+    """F.grid_sample(map, coords (B,S,1,2) or (B,S,2), align_corners=False, zeros padding) on a pixel-major map
+    (B,H,W,C) -> fp32 (B,S,C); gradient to the map only."""
+    return _PointSampleFn.apply(fmap, coords, 1 if nearest else 0)

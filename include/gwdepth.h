@@ -161,6 +161,15 @@ int gwd_certain_sample(const float *pred_small, const float *pred_large, float *
 int gwd_lsap(const float *cost, const int32_t *col_offsets, int32_t *query_of_target, int32_t layers, int32_t B,
              int32_t Q, int32_t sum_targets, int32_t max_targets, void *stream);
 
+/* grid_sample (align_corners=False, zero padding) of a pixel-major map (B,H,W,C) at S points per image: coords fp32
+ * (B,S,2) = normalised (x, y); mode 0 bilinear, 1 nearest; out fp32 (B,S,C) (src/models/points_sample.py:262-268,
+ * multiscale_transformerr.py:688-691).  backward adds the scatter of gout into gmap (map dtype, pre-zeroed by the
+ * caller); no gradient w.r.t. coords.                                                                          */
+int gwd_point_sample_forward(const void *map, const float *coords, float *out, int32_t B, int32_t H, int32_t W, int32_t C,
+                             int32_t S, int32_t mode, int32_t dtype, void *stream);
+int gwd_point_sample_backward(const float *gout, const float *coords, void *gmap, int32_t B, int32_t H, int32_t W, int32_t C,
+                              int32_t S, int32_t mode, int32_t dtype, void *stream);
+
 /* gwd_weight_prep for many weights in one launch (bf16 outputs).  `jobs` is a DEVICE array; job i owns the blocks
  * [block0_i, block0_{i+1}) of the launch, 1024 elements each, block0_0 = 0, total_blocks = sum of ceil(N*taps*C/1024).
  * w_fwd / w_dgrad may be NULL per job.                                                                          */

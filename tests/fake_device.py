@@ -331,3 +331,15 @@ class FakeDevice:
 
     def weight_prep_batch(self, table, n_jobs, total_blocks):
         raise NotImplementedError("the CPU stand-in never activates the batched weight cache")
+
+    def point_sample_forward(self, fmap, coords, out, B, H, W, C, S, mode):
+        r = F.grid_sample(fmap.reshape(B, H, W, C).permute(0, 3, 1, 2).float(), coords.reshape(B, S, 1, 2),
+                          mode="nearest" if mode == 1 else "bilinear", align_corners=False)
+        out.copy_(r.reshape(B, C, S).permute(0, 2, 1).reshape(out.shape))
+
+    def point_sample_backward(self, gout, coords, gmap, B, H, W, C, S, mode):
+        with torch.enable_grad():
+            x = torch.zeros(B, C, H, W, requires_grad=True)
+            r = F.grid_sample(x, coords.reshape(B, S, 1, 2), mode="nearest" if mode == 1 else "bilinear", align_corners=False)
+            r.backward(gout.reshape(B, S, C).permute(0, 2, 1).reshape(B, C, S, 1))
+        gmap.add_(x.grad.permute(0, 2, 3, 1).reshape(gmap.shape).to(gmap.dtype))

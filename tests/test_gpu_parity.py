@@ -94,7 +94,7 @@ def test_hip_graph_step_equals_eager_step():
         for k in t0:
             assert abs(t0[k] - t1[k]) <= tol * max(1.0, abs(t0[k])), (i, k)
         assert rel(d1, d0) < tol
-        assert rel(g1, g0) < 50 * tol and rel(p1, p0) < 1e-5
+        assert rel(g1, g0) < 50 * tol and rel(p1, p0) < 1e-4       # AdamW: lr * sign(noise-level gradient)
 
 
 def test_device_matcher_step_equals_host_matcher_step():

@@ -425,3 +425,28 @@ def test_weight_cache_batch_refresh(dev):
         if rs is not None:
             assert torch.equal(cache.get(w, rs, "fwd"), ref_f)
     cache.end_pass()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("nearest", [False, True])
+@pytest.mark.parametrize("shape", [(2, 21, 21, 64, 40), (3, 15, 20, 7, 5), (2, 60, 80, 128, 30), (1, 12, 16, 1, 9)])
+def test_point_sample(dev, shape, nearest, dtype):
+    """grid_sample at points (incl. out-of-image and duplicate points) on a pixel-major map; fp32 output."""
+    B, H, W, C, S = shape
+    fake = FakeDevice()
+    fmap = rnd(B, H, W, C, dtype=dtype, seed=8)
+    g = torch.Generator().manual_seed(S + H)
+    coords = torch.rand(B, S, 2, generator=g) * 2.4 - 1.2
+    coords[:, 1] = coords[:, 0]                                   # a duplicate point: colliding scatter in the backward
+    mode = 1 if nearest else 0
+    out_r = torch.empty(B, S, C)
+    fake.point_sample_forward(fmap, coords, out_r, B, H, W, C, S, mode)
+    out = torch.empty(B, S, C).cuda()
+    dev.point_sample_forward(fmap.cuda(), coords.cuda(), out, B, H, W, C, S, mode)
+    assert rel(out, out_r) < 1e-6
+    gout = rnd(B, S, C, seed=9)
+    gm_r = torch.zeros(B, H, W, C, dtype=dtype)
+    fake.point_sample_backward(gout, coords, gm_r, B, H, W, C, S, mode)
+    gm = torch.zeros(B, H, W, C, dtype=dtype).cuda()
+    dev.point_sample_backward(gout.cuda(), coords.cuda(), gm, B, H, W, C, S, mode)
+    assert rel(gm, gm_r) < TOL[dtype]
