@@ -515,7 +515,27 @@ def window_attention_packed(qkv, bias, region, windows_per_image, scale):
     return _WinAttnPackedFn.apply(qkv, bias, region, int(windows_per_image), float(scale))
 
 
+_REGION_MASKS = {}
+
+
+def _window_attention_matmul(q, k, v, bias, region, windows_per_image, scale):
+    """head_dim 32 (the 72-window 1/32 stage): 49x49x32 batched GEMMs are MFMA-sized and the lane-per-row kernel
+    spills at this width, so scores / PV go through the batched-GEMM library and the softmax through gwd_softmax."""
+    W, N, H, D = q.shape
+    s = torch.matmul((q * scale).permute(0, 2, 1, 3), k.permute(0, 2, 3, 1)) + bias.to(q.dtype)      # (W, H, N, N)
+    if region is not None:
+        key = (region.data_ptr(), tuple(region.shape), q.dtype)
+        m = _REGION_MASKS.get(key)
+        if m is None:
+            m = _REGION_MASKS[key] = ((region[:, :, None] != region[:, None, :]).to(q.dtype) * -100.0).unsqueeze(1)   # (wpi,1,N,N)
+        s = (s.view(W // windows_per_image, windows_per_image, H, N, N) + m).view(W, H, N, N)
+    p = softmax_lastdim(s)
+    return torch.matmul(p, v.permute(0, 2, 1, 3)).permute(0, 2, 1, 3).reshape(W, N, H * D)
+
+
 def window_attention(q, k, v, bias, region, windows_per_image, scale):
+    if q.shape[-1] >= 32 and q.is_cuda:
+        return _window_attention_matmul(q, k, v, bias, region, int(windows_per_image), float(scale))
     return _WinAttnFn.apply(q, k, v, bias, region, int(windows_per_image), float(scale))
 
 
