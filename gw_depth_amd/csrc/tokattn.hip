@@ -15,19 +15,56 @@ struct Op {
     long ws, ts, hs;
 };
 
-template <typename T, int E>
+// 4 consecutive elements per access (8 bytes of bf16, 16 of fp32) when the host has checked pointers and strides;
+// element-wise otherwise.  The rows are 24-96 bytes at a token stride of hundreds of bytes, so each lane touches its
+// own cache line: one wide access per line instead of one per element.
+template <typename T> struct Quad;
+template <> struct Quad<float> { typedef float4 type; };
+template <> struct Quad<__bf16> { typedef uint2 type; };
+
+template <typename T, int N, bool VEC>
+__device__ __forceinline__ void load_n(const T *p, bool live, float (&dst)[N]) {
+    if constexpr (VEC) {
+#pragma unroll
+        for (int c = 0; c < N; c += 4) {
+            typename Quad<T>::type raw = {};
+            if (live) raw = *(const typename Quad<T>::type *)(p + c);
+            const T *e = (const T *)&raw;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[c + j] = to_f32(e[j]);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < N; ++c) dst[c] = live ? to_f32(p[c]) : 0.f;
+    }
+}
+
+template <typename T, int N, bool VEC>
+__device__ __forceinline__ void store_n(T *p, const float (&src)[N]) {
+    if constexpr (VEC) {
+#pragma unroll
+        for (int c = 0; c < N; c += 4) {
+            typename Quad<T>::type raw;
+            T *e = (T *)&raw;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = from_f32<T>(src[c + j]);
+            *(typename Quad<T>::type *)(p + c) = raw;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < N; ++c) p[c] = from_f32<T>(src[c]);
+    }
+}
+
+template <typename T, int E, bool VEC>
 __device__ __forceinline__ void load_rows(const Op &q, const Op &k, const Op &v, long w, int h, int n, bool live, float (&qr)[R],
                                           float (&kr)[E], float (&vr)[E]) {
     const T *qp = (const T *)q.p + w * q.ws + n * q.ts + h * q.hs;
     const T *kp = (const T *)k.p + w * k.ws + n * k.ts + h * k.hs;
     const T *vp = (const T *)v.p + w * v.ws + n * v.ts + h * v.hs;
-#pragma unroll
-    for (int r = 0; r < R; ++r) qr[r] = live ? to_f32(qp[r]) : 0.f;
-#pragma unroll
-    for (int c = 0; c < E; ++c) {
-        kr[c] = live ? to_f32(kp[c]) : 0.f;
-        vr[c] = live ? to_f32(vp[c]) : 0.f;
-    }
+    load_n<T, R, VEC>(qp, live, qr);
+    load_n<T, E, VEC>(kp, live, kr);
+    load_n<T, E, VEC>(vp, live, vr);
 }
 
 template <int E>
@@ -52,7 +89,7 @@ __device__ __forceinline__ void scores_softmax(const float (&qr)[R], const float
     }
 }
 
-template <typename T, int E>
+template <typename T, int E, bool VEC>
 __global__ __launch_bounds__(256) void tokattn_fwd_kernel(Op q, Op k, Op v, Op o, long n_problems, int heads, float scale) {
     const int lane = threadIdx.x & 63;
     const bool live = lane < NT;
@@ -61,22 +98,24 @@ __global__ __launch_bounds__(256) void tokattn_fwd_kernel(Op q, Op k, Op v, Op o
         const long w = pb / heads;
         const int h = (int)(pb - w * heads);
         float qr[R], kr[E], vr[E], a[R][E];
-        load_rows<T, E>(q, k, v, w, h, n, live, qr, kr, vr);
+        load_rows<T, E, VEC>(q, k, v, w, h, n, live, qr, kr, vr);
         scores_softmax<E>(qr, kr, scale, a);
         if (live) {
             T *op = (T *)o.p + w * o.ws + n * o.ts + h * o.hs;
+            float ov[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 float acc = 0.f;
 #pragma unroll
                 for (int c = 0; c < E; ++c) acc += a[r][c] * vr[c];
-                op[r] = from_f32<T>(acc);
+                ov[r] = acc;
             }
+            store_n<T, R, VEC>(op, ov);
         }
     }
 }
 
-template <typename T, int E>
+template <typename T, int E, bool VEC>
 __global__ __launch_bounds__(256) void tokattn_bwd_kernel(Op q, Op k, Op v, Op go, Op gq, Op gk, Op gv, long n_problems, int heads,
                                                           float scale) {
     const int lane = threadIdx.x & 63;
@@ -86,12 +125,8 @@ __global__ __launch_bounds__(256) void tokattn_bwd_kernel(Op q, Op k, Op v, Op g
         const long w = pb / heads;
         const int h = (int)(pb - w * heads);
         float qr[R], kr[E], vr[E], a[R][E], dor[R];
-        load_rows<T, E>(q, k, v, w, h, n, live, qr, kr, vr);
-        {
-            const T *gp = (const T *)go.p + w * go.ws + n * go.ts + h * go.hs;
-#pragma unroll
-            for (int r = 0; r < R; ++r) dor[r] = live ? to_f32(gp[r]) : 0.f;
-        }
+        load_rows<T, E, VEC>(q, k, v, w, h, n, live, qr, kr, vr);
+        load_n<T, R, VEC>((const T *)go.p + w * go.ws + n * go.ts + h * go.hs, live, dor);
         scores_softmax<E>(qr, kr, scale, a);
         float dv[E], dk[E], dq[R];
 #pragma unroll
@@ -119,13 +154,9 @@ __global__ __launch_bounds__(256) void tokattn_bwd_kernel(Op q, Op k, Op v, Op g
             T *qp = (T *)gq.p + w * gq.ws + n * gq.ts + h * gq.hs;
             T *kp = (T *)gk.p + w * gk.ws + n * gk.ts + h * gk.hs;
             T *vp = (T *)gv.p + w * gv.ws + n * gv.ts + h * gv.hs;
-#pragma unroll
-            for (int r = 0; r < R; ++r) qp[r] = from_f32<T>(dq[r]);
-#pragma unroll
-            for (int c = 0; c < E; ++c) {
-                kp[c] = from_f32<T>(dk[c]);
-                vp[c] = from_f32<T>(dv[c]);
-            }
+            store_n<T, R, VEC>(qp, dq);
+            store_n<T, E, VEC>(kp, dk);
+            store_n<T, E, VEC>(vp, dv);
         }
     }
 }
@@ -136,11 +167,17 @@ template <typename T, int E>
 int run(bool bwd, const gwd_strided *const *s, long n_problems, int heads, float scale, hipStream_t st) {
     long bx = (n_problems + 3) / 4;
     if (bx > 4096) bx = 4096;
-    if (!bwd)
-        tokattn_fwd_kernel<T, E><<<(unsigned)bx, 256, 0, st>>>(mk(s[0]), mk(s[1]), mk(s[2]), mk(s[3]), n_problems, heads, scale);
-    else
-        tokattn_bwd_kernel<T, E><<<(unsigned)bx, 256, 0, st>>>(mk(s[0]), mk(s[1]), mk(s[2]), mk(s[3]), mk(s[4]), mk(s[5]), mk(s[6]),
-                                                             n_problems, heads, scale);
+    // wide accesses need every operand's base and strides to be multiples of 4 elements
+    bool vec = true;
+    for (int i = 0; i < (bwd ? 7 : 4); ++i)
+        vec = vec && ((uintptr_t)s[i]->p % (4 * sizeof(T)) == 0) && s[i]->ws % 4 == 0 && s[i]->ts % 4 == 0 && s[i]->hs % 4 == 0;
+    if (!bwd) {
+        if (vec) tokattn_fwd_kernel<T, E, true><<<(unsigned)bx, 256, 0, st>>>(mk(s[0]), mk(s[1]), mk(s[2]), mk(s[3]), n_problems, heads, scale);
+        else tokattn_fwd_kernel<T, E, false><<<(unsigned)bx, 256, 0, st>>>(mk(s[0]), mk(s[1]), mk(s[2]), mk(s[3]), n_problems, heads, scale);
+    } else {
+        if (vec) tokattn_bwd_kernel<T, E, true><<<(unsigned)bx, 256, 0, st>>>(mk(s[0]), mk(s[1]), mk(s[2]), mk(s[3]), mk(s[4]), mk(s[5]), mk(s[6]), n_problems, heads, scale);
+        else tokattn_bwd_kernel<T, E, false><<<(unsigned)bx, 256, 0, st>>>(mk(s[0]), mk(s[1]), mk(s[2]), mk(s[3]), mk(s[4]), mk(s[5]), mk(s[6]), n_problems, heads, scale);
+    }
     GWD_CHECK_LAUNCH();
     return 0;
 }

@@ -15,6 +15,7 @@
 namespace {
 
 constexpr int NT = 49;   // tokens per window
+constexpr int NB = 2404; // floats reserved for one 49x49 bias copy in LDS (padded so the tiles behind it stay 16-byte aligned)
 
 struct Operand {
     const void *p;
@@ -25,37 +26,78 @@ struct OperandW {
     long ws, ts, hs;
 };
 
-template <typename T, int HD>
+template <typename T> struct Quad;
+template <> struct Quad<float> { typedef float4 type; };
+template <> struct Quad<__bf16> { typedef uint2 type; };
+
+// VEC: every operand's base and strides are multiples of 4 elements (checked on the host) -> 4 elements per access
+template <typename T, int HD, bool VEC>
 __device__ __forceinline__ void load_tile(float *dst, const Operand &op, long w, int h, int lane) {
     const T *base = (const T *)op.p + w * op.ws + h * op.hs;
-    for (int e = lane; e < NT * HD; e += 64) {
-        const int t = e / HD, d = e - t * HD;
-        dst[e] = to_f32(base[t * op.ts + d]);
+    if constexpr (VEC) {
+        for (int e = lane * 4; e < NT * HD; e += 256) {
+            const int t = e / HD, d = e - t * HD;
+            const typename Quad<T>::type raw = *(const typename Quad<T>::type *)(base + t * op.ts + d);
+            const T *v = (const T *)&raw;
+            *(float4 *)(dst + e) = make_float4(to_f32(v[0]), to_f32(v[1]), to_f32(v[2]), to_f32(v[3]));
+        }
+    } else {
+        for (int e = lane; e < NT * HD; e += 64) {
+            const int t = e / HD, d = e - t * HD;
+            dst[e] = to_f32(base[t * op.ts + d]);
+        }
     }
 }
 
-template <typename T, int HD>
+template <typename T, int HD, bool VEC>
+__device__ __forceinline__ void store_row(T *p, const float (&v)[HD], float mul) {
+    if constexpr (VEC) {
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) {
+            typename Quad<T>::type raw;
+            T *e = (T *)&raw;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = from_f32<T>(v[d + j] * mul);
+            *(typename Quad<T>::type *)(p + d) = raw;
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < HD; ++d) p[d] = from_f32<T>(v[d] * mul);
+    }
+}
+
+template <typename T, int HD, bool VEC>
 __global__ __launch_bounds__(256) void winattn_fwd_kernel(Operand q, Operand k, Operand v, OperandW o,
                                                           const float *__restrict__ bias, const int *__restrict__ region,
                                                           long n_windows, int windows_per_image, float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *bias_s = smem;                                  // [49*49]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = blockIdx.y;
-    float *ks = smem + NT * NT + wave * (2 * NT * HD + 64);
+    float *ks = smem + NB + wave * (2 * NT * HD + 64);
     float *vs = ks + NT * HD;
     int *reg_s = (int *)(vs + NT * HD);
     for (int e = threadIdx.x; e < NT * NT; e += blockDim.x) bias_s[e] = bias[(long)h * NT * NT + e];
     __syncthreads();
     const int i = lane < NT ? lane : NT - 1;               // idle lanes shadow the last row (keeps loops uniform)
     for (long w = (long)blockIdx.x * 4 + wave; w < n_windows; w += (long)gridDim.x * 4) {
-        load_tile<T, HD>(ks, k, w, h, lane);
-        load_tile<T, HD>(vs, v, w, h, lane);
+        load_tile<T, HD, VEC>(ks, k, w, h, lane);
+        load_tile<T, HD, VEC>(vs, v, w, h, lane);
         if (region) reg_s[lane] = lane < NT ? region[(w % windows_per_image) * NT + lane] : 0;
         float qr[HD];
         {
             const T *qp = (const T *)q.p + w * q.ws + i * q.ts + h * q.hs;
+            if constexpr (VEC) {
 #pragma unroll
-            for (int d = 0; d < HD; ++d) qr[d] = to_f32(qp[d]) * scale;
+                for (int d = 0; d < HD; d += 4) {
+                    const typename Quad<T>::type raw = *(const typename Quad<T>::type *)(qp + d);
+                    const T *v4 = (const T *)&raw;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) qr[d + j] = to_f32(v4[j]) * scale;
+                }
+            } else {
+#pragma unroll
+                for (int d = 0; d < HD; ++d) qr[d] = to_f32(qp[d]) * scale;
+            }
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes are visible to itself
@@ -87,23 +129,22 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(Operand q, Operand k, 
             for (int d = 0; d < HD; ++d) acc[d] += s[j] * vs[j * HD + d];
         if (lane < NT) {
             T *op = (T *)o.p + w * o.ws + i * o.ts + h * o.hs;
-#pragma unroll
-            for (int d = 0; d < HD; ++d) op[d] = from_f32<T>(acc[d] * inv);
+            store_row<T, HD, VEC>(op, acc, inv);
         }
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-template <typename T, int HD>
+template <typename T, int HD, bool VEC>
 __global__ __launch_bounds__(256) void winattn_bwd_kernel(Operand q, Operand k, Operand v, Operand go, OperandW gq,
                                                           OperandW gk, OperandW gv, const float *__restrict__ bias,
                                                           float *__restrict__ dbias, const int *__restrict__ region,
                                                           long n_windows, int windows_per_image, float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *bias_s = smem;                                  // [49*49]
-    float *dbias_s = smem + NT * NT;                       // [49*49]
+    float *dbias_s = smem + NB;                            // [49*49]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = blockIdx.y;
-    float *qs = smem + 2 * NT * NT + wave * (4 * NT * HD + 4 * 64);
+    float *qs = smem + 2 * NB + wave * (4 * NT * HD + 4 * 64);
     float *ks = qs + NT * HD, *vs = ks + NT * HD, *os = vs + NT * HD;
     float *m_s = os + NT * HD, *l_s = m_s + 64, *dl_s = l_s + 64;
     int *reg_s = (int *)(dl_s + 64);
@@ -119,10 +160,10 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(Operand q, Operand k, 
     for (int j = 0; j < NT; ++j) db[j] = 0.f;
 
     for (long w = (long)blockIdx.x * 4 + wave; w < n_windows; w += (long)gridDim.x * 4) {
-        load_tile<T, HD>(qs, q, w, h, lane);
-        load_tile<T, HD>(ks, k, w, h, lane);
-        load_tile<T, HD>(vs, v, w, h, lane);
-        load_tile<T, HD>(os, go, w, h, lane);
+        load_tile<T, HD, VEC>(qs, q, w, h, lane);
+        load_tile<T, HD, VEC>(ks, k, w, h, lane);
+        load_tile<T, HD, VEC>(vs, v, w, h, lane);
+        load_tile<T, HD, VEC>(os, go, w, h, lane);
         if (region) reg_s[lane] = lane < NT ? region[(w % windows_per_image) * NT + lane] : 0;
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -179,8 +220,7 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(Operand q, Operand k, 
         }
         if (live) {
             T *gp = (T *)gq.p + w * gq.ws + i * gq.ts + h * gq.hs;
-#pragma unroll
-            for (int d = 0; d < HD; ++d) gp[d] = from_f32<T>(dq[d] * scale);
+            store_row<T, HD, VEC>(gp, dq, scale);
         }
         m_s[lane] = mx;
         l_s[lane] = inv;
@@ -217,11 +257,8 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(Operand q, Operand k, 
         if (live) {
             T *kp = (T *)gk.p + w * gk.ws + jj * gk.ts + h * gk.hs;
             T *vp = (T *)gv.p + w * gv.ws + jj * gv.ts + h * gv.hs;
-#pragma unroll
-            for (int d = 0; d < HD; ++d) {
-                kp[d] = from_f32<T>(dk[d] * scale);
-                vp[d] = from_f32<T>(dv[d]);
-            }
+            store_row<T, HD, VEC>(kp, dk, scale);
+            store_row<T, HD, VEC>(vp, dv, 1.0f);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -246,13 +283,21 @@ int launch(bool backward, const Args &a, const float *bias, float *dbias, const 
     long bx = (n_windows + 3) / 4;
     if (bx > 512) bx = 512;
     dim3 grid((unsigned)bx, heads);
+    auto al = [](const void *p, long ws, long ts, long hs) {
+        return (uintptr_t)p % (4 * sizeof(T)) == 0 && ws % 4 == 0 && ts % 4 == 0 && hs % 4 == 0;
+    };
+    bool vec = al(a.q.p, a.q.ws, a.q.ts, a.q.hs) && al(a.k.p, a.k.ws, a.k.ts, a.k.hs) && al(a.v.p, a.v.ws, a.v.ts, a.v.hs);
     if (!backward) {
-        const size_t lds = (NT * NT + 4 * (2 * NT * HD + 64)) * sizeof(float);
-        winattn_fwd_kernel<T, HD><<<grid, 256, lds, s>>>(a.q, a.k, a.v, a.o, bias, region, n_windows, windows_per_image, scale);
+        vec = vec && al(a.o.p, a.o.ws, a.o.ts, a.o.hs);
+        const size_t lds = (NB + 4 * (2 * NT * HD + 64)) * sizeof(float);
+        if (vec) winattn_fwd_kernel<T, HD, true><<<grid, 256, lds, s>>>(a.q, a.k, a.v, a.o, bias, region, n_windows, windows_per_image, scale);
+        else winattn_fwd_kernel<T, HD, false><<<grid, 256, lds, s>>>(a.q, a.k, a.v, a.o, bias, region, n_windows, windows_per_image, scale);
     } else {
-        const size_t lds = (2 * NT * NT + 4 * (4 * NT * HD + 4 * 64)) * sizeof(float);
-        winattn_bwd_kernel<T, HD><<<grid, 256, lds, s>>>(a.q, a.k, a.v, a.go, a.gq, a.gk, a.gv, bias, dbias, region, n_windows,
-                                                        windows_per_image, scale);
+        vec = vec && al(a.go.p, a.go.ws, a.go.ts, a.go.hs) && al(a.gq.p, a.gq.ws, a.gq.ts, a.gq.hs) &&
+              al(a.gk.p, a.gk.ws, a.gk.ts, a.gk.hs) && al(a.gv.p, a.gv.ws, a.gv.ts, a.gv.hs);
+        const size_t lds = (2 * NB + 4 * (4 * NT * HD + 4 * 64)) * sizeof(float);
+        if (vec) winattn_bwd_kernel<T, HD, true><<<grid, 256, lds, s>>>(a.q, a.k, a.v, a.go, a.gq, a.gk, a.gv, bias, dbias, region, n_windows, windows_per_image, scale);
+        else winattn_bwd_kernel<T, HD, false><<<grid, 256, lds, s>>>(a.q, a.k, a.v, a.go, a.gq, a.gk, a.gv, bias, dbias, region, n_windows, windows_per_image, scale);
     }
     GWD_CHECK_LAUNCH();
     return 0;
