@@ -419,6 +419,60 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T *__restrict__ g
     }
 }
 
+// Activation backward and the bias gradient in one pass: gx = act'(ref) * gy (16-byte vectors), and the column sums
+// of gx (= dBias of the layer) accumulated in registers, reduced through LDS, one atomic per channel per workgroup.
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const T *__restrict__ gy, const T *__restrict__ ref, T *__restrict__ gx,
+                                                             float *__restrict__ dbias, int64_t rows, int C, int act, float act_scale) {
+    constexpr int VEC = VecOf<T>::N;
+    __shared__ float red[256 * VEC];
+    const int vpr = C / VEC, rpb = 256 / vpr;
+    const int slot = threadIdx.x / vpr, v = threadIdx.x % vpr;
+    float s[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+    if (slot < rpb) {
+        for (int64_t r = (int64_t)blockIdx.x * rpb + slot; r < rows; r += (int64_t)gridDim.x * rpb) {
+            const int64_t o = r * C + v * VEC;
+            const uint4 rg = *(const uint4 *)(gy + o);
+            uint4 rr = make_uint4(0u, 0u, 0u, 0u);
+            if (ref) rr = *(const uint4 *)(ref + o);
+            const T *pg = (const T *)&rg;
+            const T *pr = (const T *)&rr;
+            alignas(16) T outv[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float g = to_f32(pg[e]);
+                const float rv = to_f32(pr[e]);
+                switch (act) {
+                    case GWD_ACT_RELU: g = rv > 0.f ? g : 0.f; break;
+                    case GWD_ACT_GELU: g *= gelu_grad_f(rv); break;
+                    case GWD_ACT_ELU: g *= (rv > 0.f ? 1.0f : rv / act_scale + 1.0f); break;
+                    case GWD_ACT_SIGMOID: {
+                        const float sg = rv / act_scale;
+                        g *= sg * (1.0f - sg);
+                        break;
+                    }
+                    default: break;
+                }
+                g *= act_scale;
+                outv[e] = from_f32<T>(g);
+                s[e] += to_f32(outv[e]);           // the sum of what the consumers of gx will read
+            }
+            *(uint4 *)(gx + o) = *(const uint4 *)outv;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) red[threadIdx.x * VEC + e] = s[e];
+    __syncthreads();
+    for (int t = threadIdx.x; t < vpr * VEC; t += 256) {
+        const int vv = t / VEC, e = t % VEC;
+        float a = 0.f;
+        for (int sl = 0; sl < rpb; ++sl) a += red[(sl * vpr + vv) * VEC + e];
+        unsafeAtomicAdd(dbias + t, a);
+    }
+}
+
 template <typename T, int VB>
 int launch_ln_fwd_vec(const T *x, const float *ga, const float *be, T *y, float *mean, float *rstd, int64_t rows, int C, int gelu,
                       hipStream_t s) {
@@ -574,6 +628,26 @@ extern "C" int gwd_colsum(const void *g, float *out, int64_t rows, int32_t C, in
     const int grid = (int)(b > 512 ? 512 : (b < 1 ? 1 : b));
     DISPATCH_T(dtype, (colsum_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)g, out, rows, C)),
                (colsum_kernel<float><<<grid, 256, 0, s>>>((const float *)g, out, rows, C)));
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gwd_act_backward_colsum(const void *gy, const void *ref, void *gx, float *dbias, int64_t rows, int32_t C,
+                                       int32_t act, float act_scale, int32_t dtype, void *stream) {
+    if (!gy || !gx || !dbias || rows < 0 || C <= 0) return -1;
+    if (act != GWD_ACT_NONE && !ref) return -1;
+    if (rows == 0) return 0;
+    const int vec = dtype == GWD_BF16 ? 8 : (dtype == GWD_F32 ? 4 : 0);
+    if (!vec) return -2;
+    if (C % vec != 0 || C / vec > 256) return -4;              // caller falls back to gwd_act_backward + gwd_colsum
+    hipStream_t s = (hipStream_t)stream;
+    const int rpb = 256 / (C / vec);
+    int64_t nb = (rows + (int64_t)rpb * 8 - 1) / ((int64_t)rpb * 8);
+    const int grid = (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
+    if (dtype == GWD_BF16)
+        act_bwd_colsum_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)gy, (const __bf16 *)ref, (__bf16 *)gx, dbias, rows, C, act, act_scale);
+    else
+        act_bwd_colsum_kernel<float><<<grid, 256, 0, s>>>((const float *)gy, (const float *)ref, (float *)gx, dbias, rows, C, act, act_scale);
     GWD_CHECK_LAUNCH();
     return 0;
 }

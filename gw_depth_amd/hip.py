@@ -26,7 +26,7 @@ ENTRY_POINTS = [
     "gwd_avgpool_backward", "gwd_winattn_forward", "gwd_winattn_backward", "gwd_tokattn_forward",
     "gwd_tokattn_backward", "gwd_certain_sample", "gwd_lsap", "gwd_window_map",
     "gwd_inorm_gelu_forward", "gwd_inorm_gelu_backward", "gwd_weight_prep_batch",
-    "gwd_point_sample_forward", "gwd_point_sample_backward",
+    "gwd_point_sample_forward", "gwd_point_sample_backward", "gwd_act_backward_colsum",
 ]
 
 
@@ -131,6 +131,7 @@ class HipLibrary:
         L.gwd_lsap.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
         L.gwd_inorm_gelu_forward.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, ctypes.c_float, i32, vp]
         L.gwd_inorm_gelu_backward.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp]
+        L.gwd_act_backward_colsum.argtypes = [vp, vp, vp, vp, i64, i32, i32, ctypes.c_float, i32, vp]
         L.gwd_point_sample_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_point_sample_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_weight_prep_batch.argtypes = [vp, i32, i32, vp]
@@ -185,6 +186,15 @@ class HipLibrary:
     def act_backward(self, gy, ref, gx, scale, rows, C, act, act_scale):
         self._check(self.lib.gwd_act_backward(_ptr(gy), _ptr(ref), _ptr(gx), _ptr(scale), rows, C, act, act_scale,
                                               dtype_code(gy), self._stream(gy, ref, gx)), "gwd_act_backward")
+
+    def act_backward_colsum(self, gy, ref, gx, dbias, rows, C, act, act_scale):
+        """Fused activation backward + bias gradient; False when the shape is not supported (use the two separate calls)."""
+        rc = self.lib.gwd_act_backward_colsum(_ptr(gy), _ptr(ref), _ptr(gx), _ptr(dbias), rows, C, act, act_scale,
+                                              dtype_code(gy), self._stream(gy, ref, gx))
+        if rc == -4:
+            return False
+        self._check(rc, "gwd_act_backward_colsum")
+        return True
 
     def colsum(self, g, out, rows, C):
         self._check(self.lib.gwd_colsum(_ptr(g), _ptr(out), rows, C, dtype_code(g), self._stream(g, out)), "gwd_colsum")

@@ -169,9 +169,17 @@ class _ConvFn(torch.autograd.Function):
         B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW = dims
         gy = gy.contiguous()
         rows = B * Ho * Wo
+        w_sink, b_sink = ctx.sinks if ctx.sinks is not None else (None, None)
+        bias_done = False
         if act != ACT_NONE or act_scale != 1.0:
             dv = torch.empty_like(gy)
-            lib.act_backward(gy, ref, dv, None, rows, Cout, act, act_scale)
+            if has_bias and ctx.needs_input_grad[2] and b_sink is not None:
+                # activation backward and the bias gradient (column sums of dv) in one pass, straight into the flat gradient
+                bias_done = lib.act_backward_colsum(gy, ref, dv, b_sink[0], rows, Cout, act, act_scale)
+                if bias_done and b_sink[1] is not None:
+                    b_sink[1]()
+            if not bias_done:
+                lib.act_backward(gy, ref, dv, None, rows, Cout, act, act_scale)
         else:
             dv = gy
         gx = gw = gb = None
@@ -186,7 +194,6 @@ class _ConvFn(torch.autograd.Function):
                 gx = torch.empty_like(x)
                 lib.conv_forward(dv, wt, gx, (B, Ho, Wo, Cout, Hi, Wi, Cin, KH, KW), stride=stride, pad=pad,
                                  gather=GATHER_TRANSPOSED)
-        w_sink, b_sink = ctx.sinks if ctx.sinks is not None else (None, None)
         if ctx.needs_input_grad[1]:
             if w_sink is not None and row_scale is None:
                 # the kernel ACCUMULATES (fp32 atomics): add straight into the flat gradient buffer, no temporary
@@ -198,7 +205,7 @@ class _ConvFn(torch.autograd.Function):
                 lib.conv_wgrad(x, dv, gw, dims, stride=stride, pad=pad, gather=gather, virt=vv)
                 if row_scale is not None:
                     gw.mul_(row_scale.view(-1, 1, 1, 1))
-        if has_bias and ctx.needs_input_grad[2]:
+        if has_bias and ctx.needs_input_grad[2] and not bias_done:
             if b_sink is not None:
                 lib.colsum(dv, b_sink[0], rows, Cout)
                 if b_sink[1] is not None:

@@ -82,6 +82,12 @@ int gwd_act_backward(const void *gy, const void *ref, void *gx, const float *sca
 
 /* out[c] += sum_rows g[row][c]  (bias / shift gradients; fp32 atomics, caller zeroes).           */
 int gwd_colsum(const void *g, float *out, int64_t rows, int32_t C, int32_t dtype, void *stream);
+/* gwd_act_backward and gwd_colsum of its result in one pass (activation backward of a biased layer: dBias is the column
+ * sum of gx).  dbias is ACCUMULATED into.  Returns -4 when C is not a multiple of 16 bytes / wider than 256 vectors:
+ * the caller then uses the two separate entry points.                                                            */
+int gwd_act_backward_colsum(const void *gy, const void *ref, void *gx, float *dbias, int64_t rows, int32_t C, int32_t act,
+                            float act_scale, int32_t dtype, void *stream);
+
 
 /* LayerNorm over the last dim (C <= 512), eps 1e-5, optional fused exact GELU on the output.
  * Replaces nn.LayerNorm (+ nn.GELU) call sites: src/models/points/points_sample.py:19-25,

@@ -343,3 +343,8 @@ class FakeDevice:
             r = F.grid_sample(x, coords.reshape(B, S, 1, 2), mode="nearest" if mode == 1 else "bilinear", align_corners=False)
             r.backward(gout.reshape(B, S, C).permute(0, 2, 1).reshape(B, C, S, 1))
         gmap.add_(x.grad.permute(0, 2, 3, 1).reshape(gmap.shape).to(gmap.dtype))
+
+    def act_backward_colsum(self, gy, ref, gx, dbias, rows, C, act, act_scale):
+        self.act_backward(gy, ref, gx, None, rows, C, act, act_scale)
+        dbias.add_(gx.reshape(rows, C).float().sum(0))
+        return True

@@ -450,3 +450,17 @@ def test_point_sample(dev, shape, nearest, dtype):
     gm = torch.zeros(B, H, W, C, dtype=dtype).cuda()
     dev.point_sample_backward(gout.cuda(), coords.cuda(), gm, B, H, W, C, S, mode)
     assert rel(gm, gm_r) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,C,act", [(1000, 64, hip.ACT_GELU), (77, 256, hip.ACT_RELU), (513, 32, hip.ACT_ELU), (40, 1024, hip.ACT_GELU)])
+def test_act_backward_colsum(dev, rows, C, act, dtype):
+    fake = FakeDevice()
+    gy, ref = rnd(rows, C, dtype=dtype, seed=11), rnd(rows, C, dtype=dtype, seed=12)
+    gx_r, db_r = torch.empty(rows, C, dtype=dtype), torch.full((C,), 0.5)
+    fake.act_backward_colsum(gy, ref, gx_r, db_r, rows, C, act, 1.0)
+    gx, db = torch.empty(rows, C, dtype=dtype).cuda(), torch.full((C,), 0.5).cuda()
+    assert dev.act_backward_colsum(gy.cuda(), ref.cuda(), gx, db, rows, C, act, 1.0)
+    assert rel(gx, gx_r) < TOL[dtype] and rel(db, db_r) < TOL[dtype]
+    assert dev.act_backward_colsum(gy.cuda()[:, :6].contiguous(), ref.cuda()[:, :6].contiguous(), gx[:, :6].contiguous(), db[:6].contiguous(),
+                                   rows, 6, act, 1.0) is False
