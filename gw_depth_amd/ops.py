@@ -76,7 +76,7 @@ class WeightCache:
                 r.w_fwd = 0 if job["fwd"] is None else job["fwd"].data_ptr()
                 r.w_dgrad = 0 if job["t"] is None else job["t"].data_ptr()
                 r.N, r.taps, r.C, r.block0 = N, w.numel() // (N * C), C, b0
-                b0 += (w.numel() + 1023) // 1024
+                b0 += (w.numel() // (N * C)) * ((N + 31) // 32) * ((C + 31) // 32)
             raw = torch.frombuffer(bytearray(bytes(recs)), dtype=torch.uint8)
             dev = next(iter(self.jobs.values()))["w"].device
             self._retired.append(self.table)      # a captured HIP graph may still launch with the old table

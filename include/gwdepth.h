@@ -177,7 +177,8 @@ int gwd_point_sample_backward(const float *gout, const float *coords, void *gmap
                               int32_t S, int32_t mode, int32_t dtype, void *stream);
 
 /* gwd_weight_prep for many weights in one launch (bf16 outputs).  `jobs` is a DEVICE array; job i owns the blocks
- * [block0_i, block0_{i+1}) of the launch, 1024 elements each, block0_0 = 0, total_blocks = sum of ceil(N*taps*C/1024).
+ * [block0_i, block0_{i+1}) of the launch, one 32(n) x 32(c) tile of one tap each: blocks_i = taps*ceil(N/32)*ceil(C/32),
+ * block0_0 = 0, total_blocks = sum of blocks_i.
  * w_fwd / w_dgrad may be NULL per job.                                                                          */
 typedef struct gwd_prep_job {
     const float *w;          /* fp32 master weight (N, taps, C)                         */
