@@ -293,16 +293,18 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T *__restr
     }
 }
 
-template <typename T, int LPR, int NCH, int VB>
-__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T *__restrict__ gy, const T *__restrict__ x,
+// NWV waves per workgroup: 4, or 16 for narrow rows - the affine-gradient reduction ends in one atomic per channel per
+// WORKGROUP, and with hundreds of small workgroups those serialise on the same few cache lines (10-18 us of a 25 us call)
+template <typename T, int LPR, int NCH, int VB, int NWV>
+__global__ __launch_bounds__(NWV * 64) void layernorm_bwd_vec_kernel(const T *__restrict__ gy, const T *__restrict__ x,
                                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                 const float *__restrict__ mean, const float *__restrict__ rstd,
                                                                 T *__restrict__ gx, float *__restrict__ dgamma,
                                                                 float *__restrict__ dbeta, int64_t rows, int C, int gelu) {
     constexpr int VEC = VB / (int)sizeof(T), RPW = 64 / LPR;
-    __shared__ float red[2][4][LPR * NCH * VEC];      // [gamma|beta][wave][channel slot]
+    __shared__ float red[2][NWV][LPR * NCH * VEC];    // [gamma|beta][wave][channel slot]
     const int lane = threadIdx.x & 63, sub = lane % LPR, rsel = lane / LPR, wv = threadIdx.x >> 6;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nw = (int64_t)gridDim.x * 4;
+    const int64_t wave = (int64_t)blockIdx.x * NWV + wv, nw = (int64_t)gridDim.x * NWV;
     float g[NCH][VEC], b[NCH][VEC], ag[NCH][VEC], ab[NCH][VEC];
     bool okc[NCH];
 #pragma unroll
@@ -377,13 +379,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T *__restr
                 }
             }
         __syncthreads();
-        for (int t = threadIdx.x; t < LPR * NCH * VEC; t += 256) {
+        for (int t = threadIdx.x; t < LPR * NCH * VEC; t += NWV * 64) {
             const int slot = t / VEC, e = t % VEC;
             const int c = slot / LPR, sb = slot % LPR;
             const int ch = (sb + c * LPR) * VEC + e;
             if (ch < C) {
-                unsafeAtomicAdd(dgamma + ch, red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t]);
-                unsafeAtomicAdd(dbeta + ch, red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t]);
+                float sg = 0.f, sb = 0.f;
+#pragma unroll
+                for (int w = 0; w < NWV; ++w) {
+                    sg += red[0][w][t];
+                    sb += red[1][w][t];
+                }
+                unsafeAtomicAdd(dgamma + ch, sg);
+                unsafeAtomicAdd(dbeta + ch, sb);
             }
         }
     }
@@ -501,9 +509,15 @@ int launch_ln_bwd_vec(const T *gy, const T *x, const float *ga, const float *be,
 #define LN_BWD(LPR, NCH)                                                                                            \
     {                                                                                                               \
         const int64_t wv = (rows + (64 / LPR) - 1) / (64 / LPR);                                                    \
+        if (LPR * NCH * VEC <= 512 && dg) {                     /* narrow rows: 16-wave workgroups, one per CU */   \
+            int grid = row_grid(wv, 16);                                                                            \
+            if (grid > 256) grid = 256;                                                                             \
+            layernorm_bwd_vec_kernel<T, LPR, NCH, VB, 16><<<grid, 1024, 0, s>>>(gy, x, ga, be, mean, rstd, gx, dg, db, rows, C, gelu); \
+            return 0;                                                                                               \
+        }                                                                                                           \
         int grid = row_grid(wv, 4);                                                                                 \
         if (grid > 768) grid = 768;                                                                                 \
-        layernorm_bwd_vec_kernel<T, LPR, NCH, VB><<<grid, 256, 0, s>>>(gy, x, ga, be, mean, rstd, gx, dg, db, rows, C, gelu); \
+        layernorm_bwd_vec_kernel<T, LPR, NCH, VB, 4><<<grid, 256, 0, s>>>(gy, x, ga, be, mean, rstd, gx, dg, db, rows, C, gelu); \
         return 0;                                                                                                   \
     }
     if (need <= 8) LN_BWD(8, 1)
