@@ -44,7 +44,7 @@ class TrainStep:
         self.use_graph = bool(graph)      # capture zero_grad+forward+losses+backward of a batch signature in one HIP graph
         self._graphs = {}
         self._gstream = None
-        self.weights = ops.WeightCache()
+        self.weights = None           # built after the parameters moved into the flat buffer
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (data_parallel and dist.is_available() and dist.is_initialized()) else 1
         # the line-loss normaliser is the GLOBAL target count / world whenever a process group exists (glassrgbd.py:323-326)
@@ -86,6 +86,9 @@ class TrainStep:
             self.params[n] = p
         if self.flat_p16 is not None:
             self.flat_p16.copy_(self.flat_p)
+        spans = [(self.flat_p.data_ptr(), self.flat_p.data_ptr() + self.flat_p.numel() * 4)]
+        spans += [(p.data_ptr(), p.data_ptr() + p.numel() * p.element_size()) for p in model.parameters() if not p.requires_grad]
+        self.weights = ops.WeightCache(spans)
 
         # ---- bucket plan: contiguous flat ranges of ~bucket_mb
         per = max(int(bucket_mb * (1 << 20) / 4), 1)

@@ -719,6 +719,18 @@ class DensePrediction(nn.Module):
         self.get_depth = Seq(_0=Conv(tdim // 2, 1, 3))
         self.get_seg = Conv(tdim // 2, 2, 3)
 
+    def fuse_padded(self, x):
+        """depth_token_fuse (129 -> 129 -> 64) with the odd 129-channel width zero-padded to 136: identical values (the
+        extra input channels are zero, the extra hidden units get zero weights and bias, GELU(0) = 0), but every row is
+        a whole number of 16-byte vectors, so the three GEMMs and the GELU leave the scalar odd-width paths."""
+        fc1, fc2 = self.depth_token_fuse.fc1, self.depth_token_fuse.fc2
+        pad = (-x.shape[-1]) % 8
+        if pad == 0 or not x.is_cuda:
+            return self.depth_token_fuse(x)
+        xp = F.pad(x, (0, pad))
+        h = ops.linear(xp, F.pad(fc1.weight, (0, pad, 0, pad)), F.pad(fc1.bias, (0, pad)), ACT_GELU)
+        return ops.linear(h, F.pad(fc2.weight, (0, pad)), fc2.bias)
+
     def branch(self, fuse_in, tag, fuse, size):
         B, H, W, _ = fuse_in.shape
         f = fuse(fuse_in)
@@ -730,7 +742,7 @@ class DensePrediction(nn.Module):
     def forward(self, feat, depth3, dtok, stok, size):
         B, H, W, _ = feat.shape
         d3 = depth3.view(B, H, W, 1).to(feat.dtype)
-        d = self.branch(torch.cat([feat, d3, dtok], dim=-1), "depth", self.depth_token_fuse, size)
+        d = self.branch(torch.cat([feat, d3, dtok], dim=-1), "depth", self.fuse_padded, size)
         depth = ops.conv2d(d, self.get_depth[0].weight, pad=1, act=ACT_SIGMOID, act_scale=float(self.max_depth))
         s = self.branch(torch.cat([feat, stok], dim=-1), "seg", self.seg_token_fuse, size)
         seg = ops.conv2d(s, self.get_seg.weight, pad=1)

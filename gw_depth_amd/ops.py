@@ -26,7 +26,10 @@ class WeightCache:
     outside such a pass (plain ops calls, fp32 runs) every copy is made on the fly as before.  A weight first seen inside a pass is
     prepared on the fly and joins the table for the next pass."""
 
-    def __init__(self):
+    def __init__(self, persistent=()):
+        # [start, end) address ranges of PARAMETER storage: only weights living there are cached - a temporary (e.g. a
+        # zero-padded copy of a parameter) has a new address every step and must be prepared on the fly
+        self.ranges = sorted((int(a), int(b)) for a, b in persistent)
         self.jobs = {}           # key -> dict(w, rs, fwd, t)
         self.table = None
         self.n_jobs = self.blocks = 0
@@ -41,6 +44,9 @@ class WeightCache:
     def get(self, w, rs, kind):
         """kind 'fwd' | 't' -> cached tensor, or None when the cache is not in a pass / not applicable."""
         if not self.active or not w.is_cuda or w.dtype != torch.float32:
+            return None
+        p = w.data_ptr()
+        if not any(a <= p < b for a, b in self.ranges):
             return None
         job = self.jobs.get(self._key(w, rs))
         if job is not None and job[kind] is not None:

@@ -403,12 +403,13 @@ def test_weight_cache_batch_refresh(dev):
     shapes = [(64, 3, 3, 32), (160, 3, 3, 160), (256, 1, 1, 64), (10, 1, 1, 7), (30, 3, 3, 60), (2048, 1, 1, 512)]
     ws = [torch.randn(s, device="cuda") for s in shapes]
     rss = [None, torch.rand(160, device="cuda") + 0.5, None, None, torch.rand(30, device="cuda") + 0.5, None]
-    cache = ops.WeightCache()
+    cache = ops.WeightCache([(w.data_ptr(), w.data_ptr() + w.numel() * 4) for w in ws])
     cache.begin_pass()
     for w, rs in zip(ws, rss):
         assert cache.get(w, rs, "t") is not None
         if rs is not None:
             assert cache.get(w, rs, "fwd") is not None
+    assert cache.get(torch.randn(8, 1, 1, 8, device="cuda"), None, "t") is None      # not parameter storage: never cached
     cache.end_pass()
     assert cache.get(ws[0], None, "t") is None                 # inactive outside a pass
     for w in ws:
