@@ -1212,11 +1212,19 @@ int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s) {
 
 }  // namespace
 
+// thinconv.hip: streaming kernels for the 1-2 channel heads; return 1 when they took the problem
+int gwd_thin_conv_forward(const gwd_conv_desc *d, hipStream_t s);
+int gwd_thin_conv_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s);
+
 extern "C" int gwd_conv_forward(const gwd_conv_desc *d, void *stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!d->w) return -1;
     if ((int64_t)d->B * d->Ho * d->Wo * d->Cout >= (1LL << 40)) return -7;
+    if (gwd_thin_conv_forward(d, (hipStream_t)stream)) {
+        GWD_CHECK_LAUNCH();
+        return 0;
+    }
     return d->dtype == GWD_BF16 ? launch_fwd<__bf16>(d, (hipStream_t)stream) : launch_fwd<float>(d, (hipStream_t)stream);
 }
 
@@ -1224,6 +1232,10 @@ extern "C" int gwd_conv_wgrad(const gwd_conv_desc *d, float *dw, void *stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!dw) return -1;
+    if (gwd_thin_conv_wgrad(d, dw, (hipStream_t)stream)) {
+        GWD_CHECK_LAUNCH();
+        return 0;
+    }
     return d->dtype == GWD_BF16 ? launch_wgrad<__bf16>(d, dw, (hipStream_t)stream)
                                 : launch_wgrad<float>(d, dw, (hipStream_t)stream);
 }

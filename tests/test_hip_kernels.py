@@ -44,6 +44,8 @@ CONV_CASES = [
     ("up_size_64_32", 1, 9, 11, 64, 32, 3, 1, 1, (24, 32), dict(act=hip.ACT_ELU)),
     ("3x3_32_1_sig10", 2, 24, 32, 32, 1, 3, 1, 1, None, dict(act=hip.ACT_SIGMOID, act_scale=10.0)),
     ("3x3_32_2", 2, 24, 32, 32, 2, 3, 1, 1, None, dict()),
+    ("3x3_32_2_ragged", 3, 37, 45, 32, 2, 3, 1, 1, None, dict(shift=True)),
+    ("3x3_32_1_ragged", 1, 50, 19, 32, 1, 3, 1, 1, None, dict(act=hip.ACT_SIGMOID, act_scale=10.0)),
     ("3x3_800_320", 1, 12, 16, 800, 320, 3, 1, 1, None, dict()),
     ("lin_300x256_768", 300, 1, 1, 256, 768, 1, 1, 0, None, dict(shift=True)),
     ("lin_800x2048_256", 800, 1, 1, 2048, 256, 1, 1, 0, None, dict(shift=True)),
