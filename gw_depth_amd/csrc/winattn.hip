@@ -280,7 +280,11 @@ struct Args {
 template <typename T, int HD>
 int launch(bool backward, const Args &a, const float *bias, float *dbias, const int *region, long n_windows,
            int windows_per_image, int heads, float scale, hipStream_t s) {
+    // a workgroup stages one head's bias (and, backward, flushes 2401 dBias atomics): give every wave ~8 windows so that
+    // cost is amortised, as long as that still leaves >= 4 workgroups per CU
     long bx = (n_windows + 3) / 4;
+    const long want = (n_windows + 31) / 32;
+    if (want * heads >= 1024) bx = want;
     if (bx > 512) bx = 512;
     dim3 grid((unsigned)bx, heads);
     auto al = [](const void *p, long ws, long ts, long hs) {
