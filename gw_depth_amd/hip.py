@@ -26,7 +26,7 @@ ENTRY_POINTS = [
     "gwd_avgpool_backward", "gwd_winattn_forward", "gwd_winattn_backward", "gwd_tokattn_forward",
     "gwd_tokattn_backward", "gwd_certain_sample", "gwd_lsap", "gwd_window_map",
     "gwd_inorm_gelu_forward", "gwd_inorm_gelu_backward", "gwd_weight_prep_batch",
-    "gwd_point_sample_forward", "gwd_point_sample_backward", "gwd_act_backward_colsum",
+    "gwd_point_sample_forward", "gwd_point_sample_backward", "gwd_act_backward_colsum", "gwd_resample_backward_sep",
 ]
 
 
@@ -131,6 +131,7 @@ class HipLibrary:
         L.gwd_lsap.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
         L.gwd_inorm_gelu_forward.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, ctypes.c_float, i32, vp]
         L.gwd_inorm_gelu_backward.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp]
+        L.gwd_resample_backward_sep.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_act_backward_colsum.argtypes = [vp, vp, vp, vp, i64, i32, i32, ctypes.c_float, i32, vp]
         L.gwd_point_sample_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_point_sample_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -241,6 +242,15 @@ class HipLibrary:
     def resample_backward(self, gy, gx, B, Hs, Ws, Ho, Wo, C, mode):
         self._check(self.lib.gwd_resample_backward(_ptr(gy), _ptr(gx), B, Hs, Ws, Ho, Wo, C, mode, dtype_code(gy),
                                                    self._stream(gy, gx)), "gwd_resample_backward")
+
+    def resample_backward_sep(self, gy, tmp, gx, B, Hs, Ws, Ho, Wo, C, mode):
+        """Separable backward through the fp32 scratch `tmp` (B,Ho,Ws,C); False when C is not vector-sized."""
+        rc = self.lib.gwd_resample_backward_sep(_ptr(gy), _ptr(tmp), _ptr(gx), B, Hs, Ws, Ho, Wo, C, mode, dtype_code(gy),
+                                                self._stream(gy, gx))
+        if rc == -4:
+            return False
+        self._check(rc, "gwd_resample_backward_sep")
+        return True
 
     def avgpool_forward(self, x, y, B, H, W, C, k):
         self._check(self.lib.gwd_avgpool_forward(_ptr(x), _ptr(y), B, H, W, C, k, dtype_code(x), self._stream(x, y)),

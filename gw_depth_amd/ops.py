@@ -432,7 +432,13 @@ class _ResampleFn(torch.autograd.Function):
         B, Hs, Ws, Ho, Wo, C, mode = ctx.cfg
         gy = gy.contiguous()
         gx = torch.empty((B, Hs, Ws, C), dtype=gy.dtype, device=gy.device)
-        _lib().resample_backward(gy, gx, B, Hs, Ws, Ho, Wo, C, mode)
+        lib = _lib()
+        done = False
+        if C % 4 == 0 and (Ho > Hs or Wo > Ws):
+            tmp = torch.empty((B, Ho, Ws, C), dtype=torch.float32, device=gy.device)      # x pass -> y pass scratch
+            done = lib.resample_backward_sep(gy, tmp, gx, B, Hs, Ws, Ho, Wo, C, mode)
+        if not done:
+            lib.resample_backward(gy, gx, B, Hs, Ws, Ho, Wo, C, mode)
         return gx, None, None
 
 

@@ -348,3 +348,7 @@ class FakeDevice:
         self.act_backward(gy, ref, gx, None, rows, C, act, act_scale)
         dbias.add_(gx.reshape(rows, C).float().sum(0))
         return True
+
+    def resample_backward_sep(self, gy, tmp, gx, B, Hs, Ws, Ho, Wo, C, mode):
+        self.resample_backward(gy, gx, B, Hs, Ws, Ho, Wo, C, mode)
+        return True

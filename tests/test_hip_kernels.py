@@ -237,7 +237,7 @@ def test_sqnorm_adamw(dev):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("mode", [hip.RESAMPLE_BILINEAR_AC, hip.RESAMPLE_NEAREST])
-@pytest.mark.parametrize("shape", [(2, 7, 10, 120, 160, 32), (2, 15, 20, 30, 40, 1), (1, 60, 80, 120, 160, 24),
+@pytest.mark.parametrize("shape", [(2, 7, 10, 120, 160, 32), (2, 15, 20, 30, 40, 1), (1, 60, 80, 120, 160, 24), (2, 7, 10, 60, 80, 60),
                                    (2, 1, 1, 16, 16, 60), (2, 6, 8, 12, 16, 64), (1, 9, 11, 24, 32, 8), (2, 30, 40, 30, 40, 16)])
 def test_resample(dev, shape, mode, dtype):
     fake = FakeDevice()
@@ -467,3 +467,23 @@ def test_act_backward_colsum(dev, rows, C, act, dtype):
     assert rel(gx, gx_r) < TOL[dtype] and rel(db, db_r) < TOL[dtype]
     assert dev.act_backward_colsum(gy.cuda()[:, :6].contiguous(), ref.cuda()[:, :6].contiguous(), gx[:, :6].contiguous(), db[:6].contiguous(),
                                    rows, 6, act, 1.0) is False
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", [hip.RESAMPLE_BILINEAR_AC, hip.RESAMPLE_NEAREST])
+@pytest.mark.parametrize("shape", [(2, 7, 10, 120, 160, 32), (2, 3, 5, 60, 80, 8), (1, 60, 80, 120, 160, 24), (2, 15, 20, 17, 33, 16), (1, 1, 1, 9, 7, 8),
+                                   (2, 3, 5, 60, 80, 60), (1, 4, 4, 9, 9, 6)])
+def test_resample_backward_separable(dev, shape, mode, dtype):
+    """Two-pass (x then y) backward == single-pass gather, through the fp32 scratch."""
+    B, Hs, Ws, Ho, Wo, C = shape
+    fake = FakeDevice()
+    gy = rnd(B, Ho, Wo, C, dtype=dtype, seed=21)
+    gx_r = torch.empty(B, Hs, Ws, C, dtype=dtype)
+    fake.resample_backward(gy, gx_r, B, Hs, Ws, Ho, Wo, C, mode)
+    gx = torch.full((B, Hs, Ws, C), float("nan"), dtype=dtype).cuda()
+    tmp = torch.full((B, Ho, Ws, C), float("nan")).cuda()
+    ok = dev.resample_backward_sep(gy.cuda(), tmp, gx, B, Hs, Ws, Ho, Wo, C, mode)
+    if C % 4:
+        assert ok is False
+        return
+    assert ok and rel(gx, gx_r) < TOL[dtype]
