@@ -239,6 +239,67 @@ __global__ void avgpool_bwd_kernel(const T *__restrict__ gy, T *__restrict__ gx,
     }
 }
 
+// vector forms of the k x k average pool (C a multiple of VB bytes)
+template <typename T, int VB>
+__global__ void avgpool_fwd_vec_kernel(const T *__restrict__ x, T *__restrict__ y, int B, int H, int W, int C, int k) {
+    constexpr int VEC = VB / (int)sizeof(T);
+    typedef typename RsRaw<VB>::type Raw;
+    const int Ho = H / k, Wo = W / k, CV = C / VEC;
+    const int64_t total = (int64_t)B * Ho * Wo * CV;
+    const float inv = 1.0f / (float)(k * k);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        int64_t r = i / CV;
+        const int ox = (int)(r % Wo);
+        r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        const T *xb = x + (((size_t)b * H + (size_t)oy * k) * W + (size_t)ox * k) * C + cv * VEC;
+        float s[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+        for (int dy = 0; dy < k; ++dy)
+            for (int dx = 0; dx < k; ++dx) {
+                const Raw raw = *(const Raw *)(xb + ((size_t)dy * W + dx) * C);
+                const T *p = (const T *)&raw;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) s[e] += to_f32(p[e]);
+            }
+        alignas(16) T out[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) out[e] = from_f32<T>(s[e] * inv);
+        *(Raw *)(y + i * VEC) = *(const Raw *)out;
+    }
+}
+
+template <typename T, int VB>
+__global__ void avgpool_bwd_vec_kernel(const T *__restrict__ gy, T *__restrict__ gx, int B, int H, int W, int C, int k) {
+    constexpr int VEC = VB / (int)sizeof(T);
+    typedef typename RsRaw<VB>::type Raw;
+    const int Ho = H / k, Wo = W / k, CV = C / VEC;
+    const int64_t total = (int64_t)B * H * W * CV;
+    const float inv = 1.0f / (float)(k * k);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        int64_t r = i / CV;
+        const int xx = (int)(r % W);
+        r /= W;
+        const int yy = (int)(r % H);
+        const int b = (int)(r / H);
+        const int oy = yy / k, ox = xx / k;
+        alignas(16) T out[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) out[e] = from_f32<T>(0.f);
+        if (oy < Ho && ox < Wo) {
+            const Raw raw = *(const Raw *)(gy + (((size_t)b * Ho + oy) * Wo + ox) * C + cv * VEC);
+            const T *p = (const T *)&raw;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) out[e] = from_f32<T>(to_f32(p[e]) * inv);
+        }
+        *(Raw *)(gx + i * VEC) = *(const Raw *)out;
+    }
+}
+
 inline int flat_grid(int64_t total) {
     int64_t b = (total + 255) / 256;
     return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
@@ -290,6 +351,12 @@ extern "C" int gwd_avgpool_forward(const void *x, void *y, int32_t B, int32_t H,
                                    int32_t dtype, void *stream) {
     if (!x || !y || B <= 0 || H < k || W < k || C <= 0 || k <= 0) return -1;
     const int64_t total = (int64_t)B * (H / k) * (W / k) * C;
+    if (dtype == GWD_BF16 && C % 4 == 0) {
+        if (C % 8 == 0) avgpool_fwd_vec_kernel<__bf16, 16><<<flat_grid(total / 8), 256, 0, (hipStream_t)stream>>>((const __bf16 *)x, (__bf16 *)y, B, H, W, C, k);
+        else avgpool_fwd_vec_kernel<__bf16, 8><<<flat_grid(total / 4), 256, 0, (hipStream_t)stream>>>((const __bf16 *)x, (__bf16 *)y, B, H, W, C, k);
+        GWD_CHECK_LAUNCH();
+        return 0;
+    }
     if (dtype == GWD_BF16) avgpool_fwd_kernel<__bf16><<<flat_grid(total), 256, 0, (hipStream_t)stream>>>((const __bf16 *)x, (__bf16 *)y, B, H, W, C, k);
     else if (dtype == GWD_F32) avgpool_fwd_kernel<float><<<flat_grid(total), 256, 0, (hipStream_t)stream>>>((const float *)x, (float *)y, B, H, W, C, k);
     else return -2;
@@ -301,6 +368,12 @@ extern "C" int gwd_avgpool_backward(const void *gy, void *gx, int32_t B, int32_t
                                     int32_t dtype, void *stream) {
     if (!gy || !gx || B <= 0 || H < k || W < k || C <= 0 || k <= 0) return -1;
     const int64_t total = (int64_t)B * H * W * C;
+    if (dtype == GWD_BF16 && C % 4 == 0) {
+        if (C % 8 == 0) avgpool_bwd_vec_kernel<__bf16, 16><<<flat_grid(total / 8), 256, 0, (hipStream_t)stream>>>((const __bf16 *)gy, (__bf16 *)gx, B, H, W, C, k);
+        else avgpool_bwd_vec_kernel<__bf16, 8><<<flat_grid(total / 4), 256, 0, (hipStream_t)stream>>>((const __bf16 *)gy, (__bf16 *)gx, B, H, W, C, k);
+        GWD_CHECK_LAUNCH();
+        return 0;
+    }
     if (dtype == GWD_BF16) avgpool_bwd_kernel<__bf16><<<flat_grid(total), 256, 0, (hipStream_t)stream>>>((const __bf16 *)gy, (__bf16 *)gx, B, H, W, C, k);
     else if (dtype == GWD_F32) avgpool_bwd_kernel<float><<<flat_grid(total), 256, 0, (hipStream_t)stream>>>((const float *)gy, (float *)gx, B, H, W, C, k);
     else return -2;

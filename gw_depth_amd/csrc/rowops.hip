@@ -427,6 +427,42 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T *__restrict__ g
     }
 }
 
+// 16-byte vector form of act_bwd_kernel (C a multiple of the vector width, so a vector never straddles rows)
+template <typename T>
+__global__ void act_bwd_vec_kernel(const T *__restrict__ gy, const T *__restrict__ ref, T *__restrict__ gx,
+                                   const float *__restrict__ scale, int64_t nvec, int C, int act, float act_scale) {
+    constexpr int VEC = VecOf<T>::N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 rg = *(const uint4 *)(gy + i * VEC);
+        uint4 rr = make_uint4(0u, 0u, 0u, 0u);
+        if (ref) rr = *(const uint4 *)(ref + i * VEC);
+        const T *pg = (const T *)&rg;
+        const T *pr = (const T *)&rr;
+        const int c0 = (int)((i * VEC) % C);
+        alignas(16) T outv[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float g = to_f32(pg[e]);
+            const float rv = to_f32(pr[e]);
+            switch (act) {
+                case GWD_ACT_RELU: g = rv > 0.f ? g : 0.f; break;
+                case GWD_ACT_GELU: g *= gelu_grad_f(rv); break;
+                case GWD_ACT_ELU: g *= (rv > 0.f ? 1.0f : rv / act_scale + 1.0f); break;
+                case GWD_ACT_SIGMOID: {
+                    const float sg = rv / act_scale;
+                    g *= sg * (1.0f - sg);
+                    break;
+                }
+                default: break;
+            }
+            g *= act_scale;
+            if (scale) g *= scale[c0 + e];
+            outv[e] = from_f32<T>(g);
+        }
+        *(uint4 *)(gx + i * VEC) = *(const uint4 *)outv;
+    }
+}
+
 // Activation backward and the bias gradient in one pass: gx = act'(ref) * gy (16-byte vectors), and the column sums
 // of gx (= dBias of the layer) accumulated in registers, reduced through LDS, one atomic per channel per workgroup.
 template <typename T>
@@ -613,6 +649,18 @@ extern "C" int gwd_act_backward(const void *gy, const void *ref, void *gx, const
     const int64_t total = rows * C;
     if (total == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    {
+        const int vec = dtype == GWD_BF16 ? 8 : 4;
+        if ((dtype == GWD_BF16 || dtype == GWD_F32) && C % vec == 0) {
+            const int64_t nvec = total / vec;
+            int64_t nb = (nvec + 255) / 256;
+            const int vgrid = (int)(nb > 8192 ? 8192 : nb);
+            if (dtype == GWD_BF16) act_bwd_vec_kernel<__bf16><<<vgrid, 256, 0, s>>>((const __bf16 *)gy, (const __bf16 *)ref, (__bf16 *)gx, scale, nvec, C, act, act_scale);
+            else act_bwd_vec_kernel<float><<<vgrid, 256, 0, s>>>((const float *)gy, (const float *)ref, (float *)gx, scale, nvec, C, act, act_scale);
+            GWD_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     int64_t b = (total + 255) / 256;
     const int grid = (int)(b > 4096 ? 4096 : b);
     DISPATCH_T(dtype,
