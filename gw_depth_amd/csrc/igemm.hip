@@ -1174,7 +1174,9 @@ int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s) {
 #define WG_LAUNCH(BN_, BK_, WN_, WK_, ST_)                                                                   \
     {                                                                                                        \
         const int tiles = ((N + BN_ - 1) / BN_) * ((K + BK_ - 1) / BK_);                                     \
-        const int lds = ST_ * 32 * (BN_ + BK_) * 2, per_cu = (160 * 1024) / lds;                             \
+        const int lds = ST_ * 32 * (BN_ + BK_) * 2;                                                          \
+        int per_cu = (160 * 1024) / lds;                  /* LDS-limited; the >= 128-wide tiles hold ~200 VGPRs */      \
+        if (BN_ * BK_ >= 128 * 128 && per_cu > 2) per_cu = 2;  /* -> 2 waves per SIMD = 2 workgroups per CU */          \
         wgrad_split(M, tiles, 32, splits, m_per_block, 256 * (per_cu > 4 ? 4 : per_cu));                     \
         dim3 grid((unsigned)tiles * splits);                                                                 \
         if (fast == 2) igemm_wgrad_dma_kernel<BN_, BK_, WN_, WK_, ST_, 2><<<grid, 256, 0, s>>>(*d, dw, m_per_block);      \
