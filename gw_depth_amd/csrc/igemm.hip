@@ -1193,6 +1193,7 @@ int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s) {
             else if (N % 160 == 0 && K >= 128 && var != 3) WG_LAUNCH(160, 128, 1, 4, 3)
             else if (N > 64 && K >= 256 && var == 1) WG_LAUNCH(128, 256, 2, 2, 3)
             else if (N > 64 && K > 64) WG_LAUNCH(128, 128, 2, 2, 3)
+            else if (N <= 32 && K >= 128 && wgrad_variant() != 5) WG_LAUNCH(32, 128, 1, 4, 4)      // narrow layers: no half-empty 64-row tile
             else WG_LAUNCH(64, 64, 2, 2, 4)
 #undef WG_LAUNCH
             GWD_CHECK_LAUNCH();
