@@ -117,19 +117,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T *__restrict_
     }
 }
 
+// y = softmax(scale * x + key mask): mask (uint8, [rows / rows_per_mask][L], nonzero = excluded key, -inf) may be NULL
 template <typename T>
-__global__ __launch_bounds__(256) void softmax_fwd_kernel(const T *__restrict__ x, T *__restrict__ y, int64_t rows, int L) {
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const T *__restrict__ x, T *__restrict__ y, int64_t rows, int L,
+                                                          float scale = 1.0f, const unsigned char *__restrict__ mask = nullptr,
+                                                          int64_t rows_per_mask = 1) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
     const int per = (L + 63) / 64;
     for (int64_t r = wave; r < rows; r += nw) {
         const T *xr = x + r * L;
+        const unsigned char *mr = mask ? mask + (r / rows_per_mask) * L : nullptr;
         float v[SM_PER_LANE];
         float mx = -INFINITY;
 #pragma unroll
         for (int i = 0; i < SM_PER_LANE; ++i) {
             const int c = lane + 64 * i;
-            v[i] = (i < per && c < L) ? to_f32(xr[c]) : -INFINITY;
+            v[i] = (i < per && c < L) ? to_f32(xr[c]) * scale : -INFINITY;
+            if (mr && i < per && c < L && mr[c]) v[i] = -INFINITY;
             mx = fmaxf(mx, v[i]);
         }
         mx = wave_max(mx);
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const T *__restrict__ 
 
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T *__restrict__ gy, const T *__restrict__ y,
-                                                          T *__restrict__ gx, int64_t rows, int L) {
+                                                          T *__restrict__ gx, int64_t rows, int L, float scale = 1.0f) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
     const int per = (L + 63) / 64;
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T *__restrict__ 
 #pragma unroll
         for (int i = 0; i < SM_PER_LANE; ++i) {
             const int c = lane + 64 * i;
-            if (i < per && c < L) gx[r * L + c] = from_f32<T>(yv[i] * (gv[i] - dot));
+            if (i < per && c < L) gx[r * L + c] = from_f32<T>(scale * yv[i] * (gv[i] - dot));
         }
     }
 }
@@ -710,6 +715,31 @@ extern "C" int gwd_act_backward_colsum(const void *gy, const void *ref, void *gx
         act_bwd_colsum_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)gy, (const __bf16 *)ref, (__bf16 *)gx, dbias, rows, C, act, act_scale);
     else
         act_bwd_colsum_kernel<float><<<grid, 256, 0, s>>>((const float *)gy, (const float *)ref, (float *)gx, dbias, rows, C, act, act_scale);
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gwd_softmax_masked_forward(const void *x, const uint8_t *key_mask, void *y, int64_t rows, int32_t L,
+                                          int64_t rows_per_mask, float scale, int32_t dtype, void *stream) {
+    if (!x || !y || rows < 0 || L <= 0 || L > 64 * SM_PER_LANE || rows_per_mask <= 0) return -1;
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = row_grid(rows, 4);
+    DISPATCH_T(dtype, (softmax_fwd_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)x, (__bf16 *)y, rows, L, scale, key_mask, rows_per_mask)),
+               (softmax_fwd_kernel<float><<<grid, 256, 0, s>>>((const float *)x, (float *)y, rows, L, scale, key_mask, rows_per_mask)));
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gwd_softmax_scaled_backward(const void *gy, const void *y, void *gx, int64_t rows, int32_t L, float scale,
+                                           int32_t dtype, void *stream) {
+    if (!gy || !y || !gx || rows < 0 || L <= 0 || L > 64 * SM_PER_LANE) return -1;
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = row_grid(rows, 4);
+    DISPATCH_T(dtype,
+               (softmax_bwd_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)gy, (const __bf16 *)y, (__bf16 *)gx, rows, L, scale)),
+               (softmax_bwd_kernel<float><<<grid, 256, 0, s>>>((const float *)gy, (const float *)y, (float *)gx, rows, L, scale)));
     GWD_CHECK_LAUNCH();
     return 0;
 }

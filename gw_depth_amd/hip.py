@@ -27,6 +27,7 @@ ENTRY_POINTS = [
     "gwd_tokattn_backward", "gwd_certain_sample", "gwd_lsap", "gwd_window_map",
     "gwd_inorm_gelu_forward", "gwd_inorm_gelu_backward", "gwd_weight_prep_batch",
     "gwd_point_sample_forward", "gwd_point_sample_backward", "gwd_act_backward_colsum", "gwd_resample_backward_sep",
+    "gwd_softmax_masked_forward", "gwd_softmax_scaled_backward",
 ]
 
 
@@ -131,6 +132,8 @@ class HipLibrary:
         L.gwd_lsap.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
         L.gwd_inorm_gelu_forward.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, ctypes.c_float, i32, vp]
         L.gwd_inorm_gelu_backward.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp]
+        L.gwd_softmax_masked_forward.argtypes = [vp, vp, vp, i64, i32, i64, ctypes.c_float, i32, vp]
+        L.gwd_softmax_scaled_backward.argtypes = [vp, vp, vp, i64, i32, ctypes.c_float, i32, vp]
         L.gwd_resample_backward_sep.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_act_backward_colsum.argtypes = [vp, vp, vp, vp, i64, i32, i32, ctypes.c_float, i32, vp]
         L.gwd_point_sample_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -213,6 +216,14 @@ class HipLibrary:
     def softmax_forward(self, x, y, rows, L):
         self._check(self.lib.gwd_softmax_forward(_ptr(x), _ptr(y), rows, L, dtype_code(x), self._stream(x, y)),
                     "gwd_softmax_forward")
+
+    def softmax_masked_forward(self, x, key_mask, y, rows, L, rows_per_mask, scale):
+        self._check(self.lib.gwd_softmax_masked_forward(_ptr(x), _ptr(key_mask), _ptr(y), rows, L, rows_per_mask, scale,
+                                                        dtype_code(x), self._stream(x, y)), "gwd_softmax_masked_forward")
+
+    def softmax_scaled_backward(self, gy, y, gx, rows, L, scale):
+        self._check(self.lib.gwd_softmax_scaled_backward(_ptr(gy), _ptr(y), _ptr(gx), rows, L, scale, dtype_code(y),
+                                                         self._stream(gy, y, gx)), "gwd_softmax_scaled_backward")
 
     def softmax_backward(self, gy, y, gx, rows, L):
         self._check(self.lib.gwd_softmax_backward(_ptr(gy), _ptr(y), _ptr(gx), rows, L, dtype_code(y),

@@ -187,13 +187,11 @@ class MultiheadAttention(nn.Module):
             q = ops.linear(query, W, b, rows=(0, E))
             k = ops.linear(key, W, b, rows=(E, 2 * E))
         v = ops.linear(value, W, b, rows=(2 * E, 3 * E))
-        q = (q * (float(hd) ** -0.5)).reshape(B, L, H, hd).transpose(1, 2)
+        q = q.reshape(B, L, H, hd).transpose(1, 2)
         k = k.reshape(B, S, H, hd).transpose(1, 2)
         v = v.reshape(B, S, H, hd).transpose(1, 2)
-        att = q @ k.transpose(-2, -1)
-        if key_padding_mask is not None:
-            att = att.masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
-        att = ops.softmax_lastdim(att)
+        # q * scaling and masked_fill(-inf) (multi_head_attention.py:329-352) are folded into the softmax kernel
+        att = ops.attention_softmax(q @ k.transpose(-2, -1), key_padding_mask, float(hd) ** -0.5)
         att = F.dropout(att, self.dropout, self.training)
         out = (att @ v).transpose(1, 2).reshape(B, L, E)
         return self.out_proj(out)

@@ -355,6 +355,37 @@ def softmax_lastdim(x):
     return _SoftmaxFn.apply(x)
 
 
+class _AttnSoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, key_mask, scale):
+        x = x.contiguous()
+        L = x.shape[-1]
+        rows = x.numel() // L
+        y = torch.empty_like(x)
+        if key_mask is not None:
+            key_mask = key_mask.contiguous().view(torch.uint8) if key_mask.dtype == torch.bool else key_mask.contiguous()
+            rpm = rows // (key_mask.numel() // L)
+        else:
+            rpm = 1
+        _lib().softmax_masked_forward(x, key_mask, y, rows, L, rpm, scale)
+        ctx.save_for_backward(y)
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        L = y.shape[-1]
+        gx = torch.empty_like(y)
+        _lib().softmax_scaled_backward(gy.contiguous(), y, gx, y.numel() // L, L, ctx.scale)
+        return gx, None, None
+
+
+def attention_softmax(scores, key_padding_mask=None, scale=1.0):
+    """softmax(scale * scores + key-padding mask) over the last dim; scores (B, H, L, S), mask (B, S) bool (True = pad)."""
+    return _AttnSoftmaxFn.apply(scores, key_padding_mask, float(scale))
+
+
 class _SilogFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, gt, weight, lam, log_err):

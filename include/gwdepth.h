@@ -105,6 +105,14 @@ int gwd_layernorm_backward(const void *gy, const void *x, const float *gamma, co
 int gwd_softmax_forward(const void *x, void *y, int64_t rows, int32_t L, int32_t dtype, void *stream);
 int gwd_softmax_backward(const void *gy, const void *y, void *gx, int64_t rows, int32_t L, int32_t dtype,
                          void *stream);
+/* Attention softmax with the score scaling and the key-padding mask folded in (src/models/multi_head_attention.py:
+ * 329-352: q * scaling, masked_fill(-inf), softmax): y = softmax_row(scale * x + mask), key_mask uint8
+ * [rows / rows_per_mask][L] (nonzero = key excluded) or NULL.  Backward: gx = scale * y * (gy - <y, gy>).       */
+int gwd_softmax_masked_forward(const void *x, const uint8_t *key_mask, void *y, int64_t rows, int32_t L, int64_t rows_per_mask,
+                               float scale, int32_t dtype, void *stream);
+int gwd_softmax_scaled_backward(const void *gy, const void *y, void *gx, int64_t rows, int32_t L, float scale, int32_t dtype,
+                                void *stream);
+
 
 /* SiLog masked reduction (src/models/glassrgbd.py:366-374 with the per-scale nearest-resized GT and
  * validity mask of src/engine_glassrgbd.py:65,76-78 gathered on the fly).

@@ -352,3 +352,14 @@ class FakeDevice:
     def resample_backward_sep(self, gy, tmp, gx, B, Hs, Ws, Ho, Wo, C, mode):
         self.resample_backward(gy, gx, B, Hs, Ws, Ho, Wo, C, mode)
         return True
+
+    def softmax_masked_forward(self, x, key_mask, y, rows, L, rows_per_mask, scale):
+        s = x.float().reshape(rows, L) * scale
+        if key_mask is not None:
+            m = key_mask.reshape(-1, L).bool().repeat_interleave(rows_per_mask, dim=0)
+            s = s.masked_fill(m, float("-inf"))
+        y.copy_(F.softmax(s, dim=-1).reshape(y.shape))
+
+    def softmax_scaled_backward(self, gy, y, gx, rows, L, scale):
+        yf, g = y.float(), gy.float()
+        gx.copy_(scale * yf * (g - (yf * g).sum(-1, keepdim=True)))

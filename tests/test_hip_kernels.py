@@ -487,3 +487,27 @@ def test_resample_backward_separable(dev, shape, mode, dtype):
         assert ok is False
         return
     assert ok and rel(gx, gx_r) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 8, 100, 300), (3, 4, 37, 65), (1, 2, 5, 7)])
+def test_attention_softmax_scale_and_key_mask(dev, shape, dtype):
+    B, H, L, S = shape
+    fake = FakeDevice()
+    x = rnd(B, H, L, S, dtype=dtype, seed=31, scale=3.0)
+    mask = torch.zeros(B, S, dtype=torch.uint8)
+    mask[-1, S // 2:] = 1
+    gy = rnd(B, H, L, S, dtype=dtype, seed=32)
+    y_r, gx_r = torch.empty(B, H, L, S, dtype=dtype), torch.empty(B, H, L, S, dtype=dtype)
+    fake.softmax_masked_forward(x, mask, y_r, B * H * L, S, H * L, 0.17677669)
+    fake.softmax_scaled_backward(gy, y_r, gx_r, B * H * L, S, 0.17677669)
+    y, gx = torch.empty_like(y_r).cuda(), torch.empty_like(gx_r).cuda()
+    dev.softmax_masked_forward(x.cuda(), mask.cuda(), y, B * H * L, S, H * L, 0.17677669)
+    dev.softmax_scaled_backward(gy.cuda(), y_r.cuda(), gx, B * H * L, S, 0.17677669)
+    assert rel(y, y_r) < TOL[dtype] and rel(gx, gx_r) < TOL[dtype]
+    assert float(y[-1, :, :, S // 2:].abs().max()) == 0.0                      # masked keys get exactly zero weight
+    y2 = torch.empty_like(y)
+    dev.softmax_masked_forward(x.cuda(), None, y2, B * H * L, S, 1, 1.0)        # no mask, unit scale == plain softmax
+    y3 = torch.empty_like(y)
+    dev.softmax_forward(x.cuda(), y3, B * H * L, S)
+    assert torch.equal(y2, y3)
