@@ -8,9 +8,9 @@ namespace {
 constexpr int MAX_PER_LANE = 8;   // C <= 512
 constexpr int SM_PER_LANE = 16;   // softmax row length <= 1024
 
-inline int row_grid(int64_t rows, int waves_per_block) {
+inline int row_grid(int64_t rows, int waves_per_block, int cap = 2048) {
     int64_t blocks = (rows + waves_per_block - 1) / waves_per_block;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
@@ -530,7 +530,10 @@ int launch_ln_fwd_vec(const T *x, const float *ga, const float *be, T *y, float 
 #define LN_FWD(LPR, NCH)                                                                                            \
     {                                                                                                               \
         const int64_t wv = (rows + (64 / LPR) - 1) / (64 / LPR);                                                    \
-        layernorm_fwd_vec_kernel<T, LPR, NCH, VB><<<row_grid(wv, 4), 256, 0, s>>>(x, ga, be, y, mean, rstd, rows, C, gelu); \
+        /* ~20 KiB of rows per workgroup: measured optimum between 10 MB (512 workgroups) and 49 MB (2048) tensors */  \
+        int64_t cap = rows * C * (int64_t)sizeof(T) / 20480;                                                        \
+        cap = cap < 256 ? 256 : (cap > 2048 ? 2048 : cap);                                                          \
+        layernorm_fwd_vec_kernel<T, LPR, NCH, VB><<<row_grid(wv, 4, (int)cap), 256, 0, s>>>(x, ga, be, y, mean, rstd, rows, C, gelu); \
         return 0;                                                                                                   \
     }
     if (need <= 8) LN_FWD(8, 1)
