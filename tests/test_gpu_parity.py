@@ -115,3 +115,25 @@ def test_device_matcher_step_equals_host_matcher_step():
     for k in t0:
         assert abs(t0[k] - t1[k]) <= 2e-5 * max(1.0, abs(t0[k])), k
     assert rel(p1, p0) < 1e-6
+
+
+def test_graph_capture_refused_when_a_memset_is_seen(monkeypatch):
+    """The capture audit: a step that issues hipMemsetAsync (nodes that do not replay faithfully) must NOT be captured;
+    the step then runs eagerly - same numbers, with a warning."""
+    import warnings
+    from gw_depth_amd.engine import TrainStep
+    from gw_depth_amd.synth import synth_batch
+    b = to_device(synth_batch(2, 96, 128, seed=45, n_lines=[3, 4]), "cuda")
+    cfg, model, crits = build(device="cuda")
+    ref = TrainStep(model, crits, cfg, compute_dtype=torch.float32)
+    _, total_ref, _ = ref(b)
+    cfg2, model2, crits2 = build(device="cuda")
+    step = TrainStep(model2, crits2, cfg2, compute_dtype=torch.float32, graph=True)
+    monkeypatch.setattr(step, "_count_memsets", lambda st: (step._sync_free_fb(st), 3)[1])
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        _, total, _ = step(b)
+        torch.cuda.synchronize()
+    assert any("capture refused" in str(x.message) for x in w)
+    assert all(e["graph"] is None for e in step._graphs.values())
+    assert abs(float(total) - float(total_ref)) <= 2e-5 * abs(float(total_ref))
