@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libgwdepth_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3, 4
+WS_INORM_GELU, WS_RESAMPLE_BWD = 0, 1          # gwd_query_workspace ops
 GATHER_CONV, GATHER_TRANSPOSED, GATHER_UPSAMPLED = 0, 1, 2
 RESAMPLE_BILINEAR_AC, RESAMPLE_NEAREST = 0, 1
 
@@ -27,7 +28,7 @@ ENTRY_POINTS = [
     "gwd_tokattn_backward", "gwd_certain_sample", "gwd_lsap", "gwd_window_map",
     "gwd_inorm_gelu_forward", "gwd_inorm_gelu_backward", "gwd_weight_prep_batch",
     "gwd_point_sample_forward", "gwd_point_sample_backward", "gwd_act_backward_colsum", "gwd_resample_backward_sep",
-    "gwd_softmax_masked_forward", "gwd_softmax_scaled_backward",
+    "gwd_softmax_masked_forward", "gwd_softmax_scaled_backward", "gwd_query_workspace",
 ]
 
 
@@ -132,6 +133,8 @@ class HipLibrary:
         L.gwd_lsap.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
         L.gwd_inorm_gelu_forward.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, ctypes.c_float, i32, vp]
         L.gwd_inorm_gelu_backward.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp]
+        L.gwd_query_workspace.argtypes = [i32, ctypes.POINTER(ctypes.c_int64), i32]
+        L.gwd_query_workspace.restype = ctypes.c_int64
         L.gwd_softmax_masked_forward.argtypes = [vp, vp, vp, i64, i32, i64, ctypes.c_float, i32, vp]
         L.gwd_softmax_scaled_backward.argtypes = [vp, vp, vp, i64, i32, ctypes.c_float, i32, vp]
         L.gwd_resample_backward_sep.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -156,6 +159,14 @@ class HipLibrary:
     def _check(rc, what):
         if rc != 0:
             raise RuntimeError("%s failed with status %d" % (what, rc))
+
+    def workspace_bytes(self, op, *dims):
+        """gwd_query_workspace: bytes of caller-provided scratch for op (WS_INORM_GELU / WS_RESAMPLE_BWD)."""
+        arr = (ctypes.c_int64 * len(dims))(*[int(d) for d in dims])
+        n = self.lib.gwd_query_workspace(op, arr, len(dims))
+        if n < 0:
+            raise ValueError("gwd_query_workspace(%d, %r) -> %d" % (op, dims, n))
+        return n
 
     def version(self):
         return self.lib.gwd_version()

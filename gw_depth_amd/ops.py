@@ -466,7 +466,7 @@ class _ResampleFn(torch.autograd.Function):
         lib = _lib()
         done = False
         if C % 4 == 0 and (Ho > Hs or Wo > Ws):
-            tmp = torch.empty((B, Ho, Ws, C), dtype=torch.float32, device=gy.device)      # x pass -> y pass scratch
+            tmp = torch.empty(lib.workspace_bytes(hip.WS_RESAMPLE_BWD, B, Ho, Ws, C) // 4, dtype=torch.float32, device=gy.device)   # x pass -> y pass scratch
             done = lib.resample_backward_sep(gy, tmp, gx, B, Hs, Ws, Ho, Wo, C, mode)
         if not done:
             lib.resample_backward(gy, gx, B, Hs, Ws, Ho, Wo, C, mode)
@@ -675,7 +675,7 @@ class _InormGeluFn(torch.autograd.Function):
         L = u.numel() // (B * C)
         S = _InormGeluFn.SLICES
         y = torch.empty_like(u)
-        part = torch.empty((B, S, C, 2), dtype=torch.float32, device=u.device)
+        part = torch.empty(_lib().workspace_bytes(hip.WS_INORM_GELU, B, S, C) // 4, dtype=torch.float32, device=u.device)
         stat = torch.empty((B, C, 2), dtype=torch.float32, device=u.device)
         _lib().inorm_gelu_forward(a, u, y, part, stat, B, L, C, S, float(eps))
         ctx.save_for_backward(u, stat)
@@ -688,7 +688,7 @@ class _InormGeluFn(torch.autograd.Function):
         B, L, C, S = ctx.cfg
         gy = gy.contiguous()
         du = torch.empty_like(u)
-        part = torch.empty((B, S, C, 2), dtype=torch.float32, device=u.device)
+        part = torch.empty(_lib().workspace_bytes(hip.WS_INORM_GELU, B, S, C) // 4, dtype=torch.float32, device=u.device)
         _lib().inorm_gelu_backward(gy, u, stat, part, du, B, L, C, S)
         return gy, du, None
 

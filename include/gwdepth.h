@@ -54,6 +54,14 @@ typedef struct {
 int gwd_version(void);
 const char *gwd_arch(void);
 
+/* Scratch sizes.  The library never allocates: the two entry points that need scratch take a caller-provided buffer,
+ * and this tells the caller how many BYTES it must hold (fully overwritten by the call, no initialisation needed).
+ *   GWD_WS_INORM_GELU      dims = {B, S, C}        -> `part` of gwd_inorm_gelu_forward / _backward
+ *   GWD_WS_RESAMPLE_BWD    dims = {B, Ho, Ws, C}   -> `tmp`  of gwd_resample_backward_sep
+ * Returns -1 for an unknown op or a wrong dimension count.                                                     */
+enum { GWD_WS_INORM_GELU = 0, GWD_WS_RESAMPLE_BWD = 1 };
+int64_t gwd_query_workspace(int32_t op, const int64_t *dims, int32_t ndims);
+
 /* Implicit-GEMM convolution on MFMA with fused epilogue y = act(scale*conv(x,w) + shift + residual).
  * Also the Linear layer (KH=KW=1, Hi=Wi=1, B=rows) and, with GWD_GATHER_TRANSPOSED and
  * the transposed weights of gwd_weight_prep, the data gradient.

@@ -363,3 +363,9 @@ class FakeDevice:
     def softmax_scaled_backward(self, gy, y, gx, rows, L, scale):
         yf, g = y.float(), gy.float()
         gx.copy_(scale * yf * (g - (yf * g).sum(-1, keepdim=True)))
+
+    def workspace_bytes(self, op, *dims):
+        n = 4
+        for d in dims:
+            n *= int(d)
+        return n * (2 if op == hip.WS_INORM_GELU else 1)

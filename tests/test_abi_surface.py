@@ -46,3 +46,14 @@ def test_compute_entry_points_refuse_cpu_tensors():
     x = torch.zeros(4, 8)
     with pytest.raises(hip.HipUnavailable):
         lib.softmax_forward(x, torch.empty_like(x), 4, 8)
+
+
+def test_workspace_query_needs_no_gpu():
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    lib.gwd_query_workspace.restype = ctypes.c_int64
+    lib.gwd_query_workspace.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_int64), ctypes.c_int32]
+    d3 = (ctypes.c_int64 * 3)(8, 32, 16)
+    assert lib.gwd_query_workspace(0, d3, 3) == 8 * 32 * 16 * 2 * 4
+    d4 = (ctypes.c_int64 * 4)(8, 120, 10, 160)
+    assert lib.gwd_query_workspace(1, d4, 4) == 8 * 120 * 10 * 160 * 4
+    assert lib.gwd_query_workspace(1, d3, 3) == -1 and lib.gwd_query_workspace(7, d3, 3) == -1
