@@ -180,6 +180,49 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T *__restrict__ 
     }
 }
 
+// Rows longer than 64 * SM_PER_LANE (the DETR encoder at 960x1280 has 1200 keys): three streaming passes per row
+// (max, sum, write) instead of holding the row in registers.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_fwd_long_kernel(const T *__restrict__ x, T *__restrict__ y, int64_t rows, int L, float scale,
+                                                               const unsigned char *__restrict__ mask, int64_t rows_per_mask) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    for (int64_t r = wave; r < rows; r += nw) {
+        const T *xr = x + r * L;
+        const unsigned char *mr = mask ? mask + (r / rows_per_mask) * L : nullptr;
+        float mx = -INFINITY;
+        for (int c = lane; c < L; c += 64) {
+            const float v = (mr && mr[c]) ? -INFINITY : to_f32(xr[c]) * scale;
+            mx = fmaxf(mx, v);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int c = lane; c < L; c += 64) {
+            const float v = (mr && mr[c]) ? -INFINITY : to_f32(xr[c]) * scale;
+            sum += (v == -INFINITY) ? 0.f : expf(v - mx);
+        }
+        const float inv = 1.0f / wave_sum(sum);
+        T *yr = y + r * L;
+        for (int c = lane; c < L; c += 64) {
+            const float v = (mr && mr[c]) ? -INFINITY : to_f32(xr[c]) * scale;
+            yr[c] = from_f32<T>(((v == -INFINITY) ? 0.f : expf(v - mx)) * inv);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_long_kernel(const T *__restrict__ gy, const T *__restrict__ y, T *__restrict__ gx,
+                                                               int64_t rows, int L, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    for (int64_t r = wave; r < rows; r += nw) {
+        float dot = 0.f;
+        for (int c = lane; c < L; c += 64) dot += to_f32(y[r * L + c]) * to_f32(gy[r * L + c]);
+        dot = wave_sum(dot);
+        for (int c = lane; c < L; c += 64) gx[r * L + c] = from_f32<T>(scale * to_f32(y[r * L + c]) * (to_f32(gy[r * L + c]) - dot));
+    }
+}
+
 template <typename T>
 __global__ void act_bwd_kernel(const T *__restrict__ gy, const T *__restrict__ ref, T *__restrict__ gx,
                                const float *__restrict__ scale, int64_t total, int C, int act, float act_scale) {
@@ -627,10 +670,16 @@ extern "C" int gwd_layernorm_backward(const void *gy, const void *x, const float
 }
 
 extern "C" int gwd_softmax_forward(const void *x, void *y, int64_t rows, int32_t L, int32_t dtype, void *stream) {
-    if (!x || !y || rows < 0 || L <= 0 || L > 64 * SM_PER_LANE) return -1;
+    if (!x || !y || rows < 0 || L <= 0) return -1;
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const int grid = row_grid(rows, 4);
+    if (L > 64 * SM_PER_LANE) {
+        DISPATCH_T(dtype, (softmax_fwd_long_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)x, (__bf16 *)y, rows, L, 1.0f, nullptr, 1)),
+                   (softmax_fwd_long_kernel<float><<<grid, 256, 0, s>>>((const float *)x, (float *)y, rows, L, 1.0f, nullptr, 1)));
+        GWD_CHECK_LAUNCH();
+        return 0;
+    }
     DISPATCH_T(dtype, (softmax_fwd_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)x, (__bf16 *)y, rows, L)),
                (softmax_fwd_kernel<float><<<grid, 256, 0, s>>>((const float *)x, (float *)y, rows, L)));
     GWD_CHECK_LAUNCH();
@@ -639,10 +688,16 @@ extern "C" int gwd_softmax_forward(const void *x, void *y, int64_t rows, int32_t
 
 extern "C" int gwd_softmax_backward(const void *gy, const void *y, void *gx, int64_t rows, int32_t L, int32_t dtype,
                                     void *stream) {
-    if (!gy || !y || !gx || rows < 0 || L <= 0 || L > 64 * SM_PER_LANE) return -1;
+    if (!gy || !y || !gx || rows < 0 || L <= 0) return -1;
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const int grid = row_grid(rows, 4);
+    if (L > 64 * SM_PER_LANE) {
+        DISPATCH_T(dtype, (softmax_bwd_long_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)gy, (const __bf16 *)y, (__bf16 *)gx, rows, L, 1.0f)),
+                   (softmax_bwd_long_kernel<float><<<grid, 256, 0, s>>>((const float *)gy, (const float *)y, (float *)gx, rows, L, 1.0f)));
+        GWD_CHECK_LAUNCH();
+        return 0;
+    }
     DISPATCH_T(dtype,
                (softmax_bwd_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)gy, (const __bf16 *)y, (__bf16 *)gx, rows, L)),
                (softmax_bwd_kernel<float><<<grid, 256, 0, s>>>((const float *)gy, (const float *)y, (float *)gx, rows, L)));
@@ -724,10 +779,16 @@ extern "C" int gwd_act_backward_colsum(const void *gy, const void *ref, void *gx
 
 extern "C" int gwd_softmax_masked_forward(const void *x, const uint8_t *key_mask, void *y, int64_t rows, int32_t L,
                                           int64_t rows_per_mask, float scale, int32_t dtype, void *stream) {
-    if (!x || !y || rows < 0 || L <= 0 || L > 64 * SM_PER_LANE || rows_per_mask <= 0) return -1;
+    if (!x || !y || rows < 0 || L <= 0 || rows_per_mask <= 0) return -1;
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const int grid = row_grid(rows, 4);
+    if (L > 64 * SM_PER_LANE) {
+        DISPATCH_T(dtype, (softmax_fwd_long_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)x, (__bf16 *)y, rows, L, scale, key_mask, rows_per_mask)),
+                   (softmax_fwd_long_kernel<float><<<grid, 256, 0, s>>>((const float *)x, (float *)y, rows, L, scale, key_mask, rows_per_mask)));
+        GWD_CHECK_LAUNCH();
+        return 0;
+    }
     DISPATCH_T(dtype, (softmax_fwd_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)x, (__bf16 *)y, rows, L, scale, key_mask, rows_per_mask)),
                (softmax_fwd_kernel<float><<<grid, 256, 0, s>>>((const float *)x, (float *)y, rows, L, scale, key_mask, rows_per_mask)));
     GWD_CHECK_LAUNCH();
@@ -736,10 +797,16 @@ extern "C" int gwd_softmax_masked_forward(const void *x, const uint8_t *key_mask
 
 extern "C" int gwd_softmax_scaled_backward(const void *gy, const void *y, void *gx, int64_t rows, int32_t L, float scale,
                                            int32_t dtype, void *stream) {
-    if (!gy || !y || !gx || rows < 0 || L <= 0 || L > 64 * SM_PER_LANE) return -1;
+    if (!gy || !y || !gx || rows < 0 || L <= 0) return -1;
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const int grid = row_grid(rows, 4);
+    if (L > 64 * SM_PER_LANE) {
+        DISPATCH_T(dtype, (softmax_bwd_long_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)gy, (const __bf16 *)y, (__bf16 *)gx, rows, L, scale)),
+                   (softmax_bwd_long_kernel<float><<<grid, 256, 0, s>>>((const float *)gy, (const float *)y, (float *)gx, rows, L, scale)));
+        GWD_CHECK_LAUNCH();
+        return 0;
+    }
     DISPATCH_T(dtype,
                (softmax_bwd_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)gy, (const __bf16 *)y, (__bf16 *)gx, rows, L, scale)),
                (softmax_bwd_kernel<float><<<grid, 256, 0, s>>>((const float *)gy, (const float *)y, (float *)gx, rows, L, scale)));

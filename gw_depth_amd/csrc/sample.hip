@@ -7,18 +7,21 @@
 
 namespace {
 
-constexpr int MAX_PIX = 8192, MAX_S = 256, MAX_INT = 8, THREADS = 256;
+constexpr int MAX_PIX = 36864, MAX_S = 256, MAX_INT = 8, THREADS = 256;
+constexpr int TABLE_BYTES = (5 * MAX_S + 2 * MAX_INT + 2 * (THREADS / 64)) * 4;   // variance map in dynamic LDS: up to 144 KiB (192 x 192)
 
 __global__ __launch_bounds__(THREADS) void certain_sample_kernel(const float *__restrict__ small, const float *__restrict__ large,
                                                                   float *__restrict__ coords, int hs, int ws, int H, int W,
                                                                   const float *__restrict__ edges, int n_int, int S) {
-    __shared__ float var[MAX_PIX];
-    __shared__ int order[MAX_S];            // top pixels, descending variance
-    __shared__ int outidx[4 * MAX_S];
-    __shared__ int cnt[MAX_INT];
-    __shared__ float red_v[THREADS / 64];
-    __shared__ int red_i[THREADS / 64];
-    __shared__ int kk[MAX_INT];
+    // one dynamic LDS block, carved by hand: [small tables (fixed size)] [variance map: H * W floats]
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+    int *order = (int *)dyn_lds;            // [MAX_S] top pixels, descending variance
+    int *outidx = order + MAX_S;            // [4 * MAX_S]
+    int *cnt = outidx + 4 * MAX_S;          // [MAX_INT]
+    float *red_v = (float *)(cnt + MAX_INT);  // [THREADS / 64]
+    int *red_i = (int *)(red_v + THREADS / 64);
+    int *kk = red_i + THREADS / 64;         // [MAX_INT]
+    float *var = (float *)(kk + MAX_INT);   // [H * W]
     const int b = blockIdx.x, tid = threadIdx.x, HW = H * W;
     const float *sm = small + (size_t)b * hs * ws;
     const float *lg = large + (size_t)b * HW;
@@ -159,8 +162,14 @@ extern "C" int gwd_certain_sample(const float *pred_small, const float *pred_lar
     if (!pred_small || !pred_large || !coords || !edges || B <= 0 || hs <= 0 || ws <= 0 || H <= 0 || W <= 0) return -1;
     if (H * W > MAX_PIX || sample_num <= 0 || sample_num > MAX_S || n_intervals <= 0 || n_intervals > MAX_INT) return -4;
     if (sample_num > H * W) return -4;
-    certain_sample_kernel<<<B, THREADS, 0, (hipStream_t)stream>>>(pred_small, pred_large, coords, hs, ws, H, W, edges,
-                                                                  n_intervals, sample_num);
+    static bool attr_set = false;
+    if (!attr_set) {                                      // dynamic LDS beyond 64 KiB has to be requested once
+        (void)hipFuncSetAttribute((const void *)certain_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  TABLE_BYTES + MAX_PIX * (int)sizeof(float));
+        attr_set = true;
+    }
+    certain_sample_kernel<<<B, THREADS, TABLE_BYTES + (size_t)H * W * sizeof(float), (hipStream_t)stream>>>(
+        pred_small, pred_large, coords, hs, ws, H, W, edges, n_intervals, sample_num);
     GWD_CHECK_LAUNCH();
     return 0;
 }

@@ -490,7 +490,7 @@ def test_resample_backward_separable(dev, shape, mode, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(2, 8, 100, 300), (3, 4, 37, 65), (1, 2, 5, 7)])
+@pytest.mark.parametrize("shape", [(2, 8, 100, 300), (3, 4, 37, 65), (1, 2, 5, 7), (2, 2, 9, 1200)])
 def test_attention_softmax_scale_and_key_mask(dev, shape, dtype):
     B, H, L, S = shape
     fake = FakeDevice()
