@@ -122,7 +122,7 @@ def main():
     if rank == 0:
         roofline = dominant_kernel_roofline(lib, dtype)
     out = {
-        "metric": "images/sec (train fwd+bwd) 480x640 bs=8/GPU",
+        "metric": "images/sec (train fwd+bwd) %dx%d bs=%d/GPU" % (a.height, a.width, a.batch),     # BASELINE.json's metric at the defaults
         "value": round(ips, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(1000 * el / a.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
