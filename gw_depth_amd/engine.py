@@ -44,6 +44,7 @@ class TrainStep:
         self.use_graph = bool(graph)      # capture zero_grad+forward+losses+backward of a batch signature in one HIP graph
         self._graphs = {}
         self._gstream = None
+        self._pending_checks = []
         self.weights = None           # built after the parameters moved into the flat buffer
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (data_parallel and dist.is_available() and dist.is_initialized()) else 1
@@ -361,9 +362,35 @@ class TrainStep:
         else:
             out, total, terms = self.forward_backward(batch, taps)
         self.optimizer_step()
-        if self.check_finite:                       # engine_glassrgbd.py:143-153 (one host sync, after all launches)
-            v = float(total.detach())
-            if not math.isfinite(v):
-                bad = {k: float(t) for k, t in terms.items() if not math.isfinite(float(t))}
-                raise FloatingPointError("Loss is %r at step %d, stopping training (non-finite terms: %r)" % (v, self.step_count, bad))
+        if self.check_finite:                       # engine_glassrgbd.py:143-153
+            if total.is_cuda and self.use_graph:
+                # graph mode keeps the host a step ahead of the device: the loss goes to pinned memory asynchronously and
+                # is examined when the NEXT step has been enqueued (or in flush()), so the check costs no device idle
+                # time (a blocking read here leaves the GPU idle for the ~1 ms the host needs to launch the next graph)
+                self._queue_finite_check(total)
+                self._poll_finite_checks(keep=1)
+            else:
+                v = float(total.detach())
+                if not math.isfinite(v):
+                    bad = {k: float(t) for k, t in terms.items() if not math.isfinite(float(t))}
+                    raise FloatingPointError("Loss is %r at step %d, stopping training (non-finite terms: %r)" % (v, self.step_count, bad))
         return out, total.detach(), terms
+
+    def _queue_finite_check(self, total):
+        slot = torch.empty(1, dtype=torch.float32, pin_memory=True)
+        slot.copy_(total.detach().reshape(1).float(), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending_checks.append((self.step_count, slot, ev))
+
+    def _poll_finite_checks(self, keep=0):
+        while len(self._pending_checks) > keep:
+            step_no, slot, ev = self._pending_checks.pop(0)
+            ev.synchronize()
+            v = float(slot[0])
+            if not math.isfinite(v):
+                raise FloatingPointError("Loss is %r at step %d, stopping training" % (v, step_no))
+
+    def flush(self):
+        """Examine every outstanding loss (graph mode checks one step late); call at the end of an epoch."""
+        self._poll_finite_checks(keep=0)

@@ -186,3 +186,23 @@ def test_inference_960x1280_bf16_batch_invariance():
     for d in out["pred_depth"]:
         assert torch.isfinite(d.float()).all() and torch.equal(d[0], d[1])
     assert float(out["pred_depth"][-1].min()) >= 0.0 and float(out["pred_depth"][-1].max()) <= 10.0
+
+
+def test_graph_mode_reports_non_finite_loss_one_step_late():
+    """engine_glassrgbd.py:150-153 stops on a non-finite loss.  Graph mode reads the loss asynchronously (no device idle
+    time): the step that produced it returns, the NEXT step - or flush() - raises."""
+    from gw_depth_amd.engine import TrainStep
+    from gw_depth_amd.synth import synth_batch
+    b = to_device(synth_batch(1, 96, 128, seed=47, n_lines=[3]), "cuda")
+    cfg, model, crits = build(device="cuda")
+    step = TrainStep(model, crits, cfg, compute_dtype=torch.float32, graph=True)
+    step(b)
+    step.flush()
+    step.flat_p[:64].fill_(float("nan"))
+    step(b)                                      # produces the NaN loss, does not raise yet
+    with pytest.raises(FloatingPointError):
+        step.flush()
+    eager = TrainStep(*((lambda c: (c[1], c[2], c[0]))(build(device="cuda"))), compute_dtype=torch.float32)
+    eager.flat_p[:64].fill_(float("nan"))
+    with pytest.raises(FloatingPointError):      # eager mode: immediately, as the reference
+        eager(b)
