@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 kernels (wave = 64 lanes, MFMA 32x32 tiles).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include "gwdepth.h"
 
@@ -43,6 +44,22 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+// Sum over the 64 lanes as a wave-UNIFORM value: six DPP adds on the VALU (quad swaps, row mirrors, row broadcasts)
+// and one v_readlane - no LDS crossbar (a __shfl_xor butterfly is six ds_bpermute round trips) and the result can live
+// in an SGPR.  Needs all 64 lanes active (inactive data must already be zero).
+__device__ __forceinline__ float wave_sum_uniform(float v) {
+    auto add_dpp = [](float x, auto ctrl, auto row_mask) {
+        constexpr int C = decltype(ctrl)::value, RM = decltype(row_mask)::value;
+        return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), C, RM, 0xf, true));
+    };
+    v = add_dpp(v, std::integral_constant<int, 0xb1>{}, std::integral_constant<int, 0xf>{});    // quad_perm [1,0,3,2]
+    v = add_dpp(v, std::integral_constant<int, 0x4e>{}, std::integral_constant<int, 0xf>{});    // quad_perm [2,3,0,1]
+    v = add_dpp(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{});   // row_half_mirror
+    v = add_dpp(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{});   // row_mirror: every lane = its row's sum
+    v = add_dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});   // row_bcast15 into rows 1, 3
+    v = add_dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});   // row_bcast31 into rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll

@@ -74,7 +74,7 @@ __device__ __forceinline__ void scores_softmax(const float (&qr)[R], const float
         float mx = -INFINITY;
 #pragma unroll
         for (int c = 0; c < E; ++c) {
-            a[r][c] = wave_sum(qr[r] * kr[c]) * scale;
+            a[r][c] = wave_sum_uniform(qr[r] * kr[c]) * scale;
             mx = fmaxf(mx, a[r][c]);
         }
         float l = 0.f;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void tokattn_bwd_kernel(Op q, Op k, Op v, Op g
             float dot = 0.f;
 #pragma unroll
             for (int c = 0; c < E; ++c) {
-                da[c] = wave_sum(dor[r] * vr[c]);          // dA[r][c] = sum_n dO[n][r] v[n][c]
+                da[c] = wave_sum_uniform(dor[r] * vr[c]);          // dA[r][c] = sum_n dO[n][r] v[n][c]
                 dot += a[r][c] * da[c];
                 dv[c] += a[r][c] * dor[r];
             }
