@@ -61,6 +61,21 @@ __device__ __forceinline__ float wave_sum_uniform(float v) {
     v = add_dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});   // row_bcast31 into rows 2, 3
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// max over the 64 lanes, wave-uniform, same DPP ladder (the old value of a lane outside the row mask is the lane's own)
+__device__ __forceinline__ float wave_max_uniform(float v) {
+    auto max_dpp = [](float x, auto ctrl, auto row_mask) {
+        constexpr int C = decltype(ctrl)::value, RM = decltype(row_mask)::value;
+        const int xi = __builtin_bit_cast(int, x);
+        return fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, C, RM, 0xf, false)));
+    };
+    v = max_dpp(v, std::integral_constant<int, 0xb1>{}, std::integral_constant<int, 0xf>{});
+    v = max_dpp(v, std::integral_constant<int, 0x4e>{}, std::integral_constant<int, 0xf>{});
+    v = max_dpp(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{});
+    v = max_dpp(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{});
+    v = max_dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});
+    v = max_dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

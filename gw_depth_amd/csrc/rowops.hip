@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T *__restrict_
             v[i] = (i < per && c < C) ? to_f32(xr[c]) : 0.f;
             s += v[i];
         }
-        const float mu = wave_sum(s) / (float)C;
+        const float mu = wave_sum_uniform(s) / (float)C;
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < MAX_PER_LANE; ++i) {
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T *__restrict_
             const float dlt = (i < per && c < C) ? v[i] - mu : 0.f;
             q += dlt * dlt;
         }
-        const float rs = rsqrtf(wave_sum(q) / (float)C + 1e-5f);
+        const float rs = rsqrtf(wave_sum_uniform(q) / (float)C + 1e-5f);
         if (lane == 0) {
             mean[r] = mu;
             rstd[r] = rs;
@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T *__restrict_
             s1 += gw[i];
             s2 += gw[i] * xh[i];
         }
-        s1 = wave_sum(s1) / (float)C;
-        s2 = wave_sum(s2) / (float)C;
+        s1 = wave_sum_uniform(s1) / (float)C;
+        s2 = wave_sum_uniform(s2) / (float)C;
         T *gxr = gx + r * C;
 #pragma unroll
         for (int i = 0; i < MAX_PER_LANE; ++i) {
@@ -137,14 +137,14 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const T *__restrict__ 
             if (mr && i < per && c < L && mr[c]) v[i] = -INFINITY;
             mx = fmaxf(mx, v[i]);
         }
-        mx = wave_max(mx);
+        mx = wave_max_uniform(mx);
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < SM_PER_LANE; ++i) {
             v[i] = (v[i] == -INFINITY) ? 0.f : expf(v[i] - mx);
             s += v[i];
         }
-        const float inv = 1.0f / wave_sum(s);
+        const float inv = 1.0f / wave_sum_uniform(s);
         T *yr = y + r * L;
 #pragma unroll
         for (int i = 0; i < SM_PER_LANE; ++i) {
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T *__restrict__ 
             gv[i] = ok ? to_f32(gy[r * L + c]) : 0.f;
             dot += yv[i] * gv[i];
         }
-        dot = wave_sum(dot);
+        dot = wave_sum_uniform(dot);
 #pragma unroll
         for (int i = 0; i < SM_PER_LANE; ++i) {
             const int c = lane + 64 * i;
@@ -195,13 +195,13 @@ __global__ __launch_bounds__(256) void softmax_fwd_long_kernel(const T *__restri
             const float v = (mr && mr[c]) ? -INFINITY : to_f32(xr[c]) * scale;
             mx = fmaxf(mx, v);
         }
-        mx = wave_max(mx);
+        mx = wave_max_uniform(mx);
         float sum = 0.f;
         for (int c = lane; c < L; c += 64) {
             const float v = (mr && mr[c]) ? -INFINITY : to_f32(xr[c]) * scale;
             sum += (v == -INFINITY) ? 0.f : expf(v - mx);
         }
-        const float inv = 1.0f / wave_sum(sum);
+        const float inv = 1.0f / wave_sum_uniform(sum);
         T *yr = y + r * L;
         for (int c = lane; c < L; c += 64) {
             const float v = (mr && mr[c]) ? -INFINITY : to_f32(xr[c]) * scale;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_long_kernel(const T *__restri
     for (int64_t r = wave; r < rows; r += nw) {
         float dot = 0.f;
         for (int c = lane; c < L; c += 64) dot += to_f32(y[r * L + c]) * to_f32(gy[r * L + c]);
-        dot = wave_sum(dot);
+        dot = wave_sum_uniform(dot);
         for (int c = lane; c < L; c += 64) gx[r * L + c] = from_f32<T>(scale * to_f32(y[r * L + c]) * (to_f32(gy[r * L + c]) - dot));
     }
 }
