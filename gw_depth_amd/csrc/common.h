@@ -61,6 +61,24 @@ __device__ __forceinline__ float wave_sum_uniform(float v) {
     v = add_dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});   // row_bcast31 into rows 2, 3
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// Sum over each aligned group of LPR consecutive lanes (LPR = 8, 16, 32, 64), result in every lane of the group: DPP
+// for the strides inside a 16-lane row, ds_bpermute only across rows.
+template <int LPR>
+__device__ __forceinline__ float segment_sum(float v) {
+    auto add_dpp = [](float x, auto ctrl) {
+        constexpr int C = decltype(ctrl)::value;
+        return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), C, 0xf, 0xf, true));
+    };
+    static_assert(LPR == 8 || LPR == 16 || LPR == 32 || LPR == 64, "segment width");
+    v = add_dpp(v, std::integral_constant<int, 0xb1>{});            // lane ^ 1
+    v = add_dpp(v, std::integral_constant<int, 0x4e>{});            // lane ^ 2
+    v = add_dpp(v, std::integral_constant<int, 0x141>{});           // row_half_mirror: completes each group of 8
+    if constexpr (LPR >= 16) v = add_dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror: groups of 16
+    if constexpr (LPR >= 32) v += __shfl_xor(v, 16, 64);
+    if constexpr (LPR >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
 // max over the 64 lanes, wave-uniform, same DPP ladder (the old value of a lane outside the row mask is the lane's own)
 __device__ __forceinline__ float wave_max_uniform(float v) {
     auto max_dpp = [](float x, auto ctrl, auto row_mask) {

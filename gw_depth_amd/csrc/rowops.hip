@@ -308,8 +308,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T *__restr
                 s += v[c][e];
             }
         }
-#pragma unroll
-        for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        s = segment_sum<LPR>(s);
         const float mu = s / (float)C;
         float q = 0.f;
 #pragma unroll
@@ -319,8 +318,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T *__restr
                 const float dlt = okc[c] ? v[c][e] - mu : 0.f;
                 q += dlt * dlt;
             }
-#pragma unroll
-        for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        q = segment_sum<LPR>(q);
         const float rs = rsqrtf(q / (float)C + 1e-5f);
         if (okr && sub == 0) {
             mean[r] = mu;
@@ -394,11 +392,8 @@ __global__ __launch_bounds__(NWV * 64) void layernorm_bwd_vec_kernel(const T *__
                 s2 += gw[c][e] * xh[c][e];
             }
         }
-#pragma unroll
-        for (int o = LPR / 2; o > 0; o >>= 1) {
-            s1 += __shfl_xor(s1, o, 64);
-            s2 += __shfl_xor(s2, o, 64);
-        }
+        s1 = segment_sum<LPR>(s1);
+        s2 = segment_sum<LPR>(s2);
         s1 /= (float)C;
         s2 /= (float)C;
 #pragma unroll
