@@ -277,10 +277,15 @@ class TrainStep:
     def _count_memsets(self, st):
         """Run one sync-free pass under the profiler and count the hipMemsetAsync runtime calls it makes."""
         from torch.profiler import ProfilerActivity, profile
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        try:
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+                self._sync_free_fb(st)
+                torch.cuda.synchronize()
+            return sum(1 for e in prof.events() if e.name == "hipMemsetAsync")
+        except Exception as exc:                     # no tracer on this host: without the audit there is no capture
+            warnings.warn("gw_depth_amd: capture audit unavailable (%s)" % exc)
             self._sync_free_fb(st)
-            torch.cuda.synchronize()
-        return sum(1 for e in prof.events() if e.name == "hipMemsetAsync")
+            return -1
 
     def _graph_entry(self, batch):
         sizes = tuple(int(len(t["labels"])) for t in batch["targets"])
@@ -302,6 +307,8 @@ class TrainStep:
         if any("AccumulateGrad node's stream does not match" in str(w.message) for w in caught):
             reason = ("an autograd graph built on another stream is still alive (e.g. the outputs of an eager step): its "
                       "AccumulateGrad nodes would be captured on a forked stream")
+        elif memsets < 0:
+            reason = "the capture audit (torch.profiler runtime-call trace) is not available on this host"
         elif memsets:
             reason = ("%d hipMemsetAsync call(s) in the step (ATen multi-block reductions zero their semaphores that way); "
                       "memset nodes do not replay correctly in HIP graphs on this ROCm" % memsets)
