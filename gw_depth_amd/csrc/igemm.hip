@@ -11,6 +11,7 @@
 // exact-fp32 v_mfma_f32_32x32x2_f32 (parity mode).  The epilogue fuses FrozenBN affine / bias,
 // residual add and ReLU / GELU / ELU / sigmoid so a Bottleneck conv writes its activation once.
 #include "common.h"
+#include <cmath>
 
 namespace {
 
@@ -1152,10 +1153,17 @@ static int wgrad_variant() {
     return v;
 }
 
-static void wgrad_split(int M, int tiles, int rm, int &splits, int &m_per_block, int resident = 768) {
+static void wgrad_split(int M, int tiles, int rm, int &splits, int &m_per_block, int resident = 768, double balance = 0.0) {
     // M-splits so that tiles x splits fills the chip's resident workgroup slots once; >= 8 reduction steps each
     splits = wgrad_target_blocks(resident) / tiles;
     if (splits * tiles < wgrad_target_blocks(resident) * 3 / 4) ++splits;     // far below a full round: round up instead
+    if (balance > 0.0) {
+        // every split flushes tiles x (tile bytes) of fp32 atomics (~1.3 TB/s chip-wide) but shortens each workgroup's
+        // serial chain of (M / 32 / splits) steps: time ~ steps * t_step / S + S * flush  ->  S* = sqrt(steps * t_step / flush),
+        // passed in as balance = t_step / (flush time of one split)
+        const int s_opt = (int)(sqrt((double)(M / rm) * balance) + 0.5);
+        if (s_opt >= 1 && s_opt < splits) splits = s_opt;
+    }
     const int max_splits = (M + 8 * rm - 1) / (8 * rm);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -1177,7 +1185,9 @@ int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s) {
         const int lds = ST_ * 32 * (BN_ + BK_) * 2;                                                          \
         int per_cu = (160 * 1024) / lds;                  /* LDS-limited; the >= 128-wide tiles hold ~200 VGPRs */      \
         if (BN_ * BK_ >= 128 * 128 && per_cu > 2) per_cu = 2;  /* -> 2 waves per SIMD = 2 workgroups per CU */          \
-        wgrad_split(M, tiles, 32, splits, m_per_block, 256 * (per_cu > 4 ? 4 : per_cu));                     \
+        /* plain GEMMs: a step costs ~0.45 us, one split's flush tiles * BN * BK * 4 bytes at ~1.3 TB/s */                \
+        const double bal = (fast == 2 && wgrad_variant() != 9) ? 0.45e-6 * 1.3e12 / ((double)tiles * BN_ * BK_ * 4) : 0.0;  \
+        wgrad_split(M, tiles, 32, splits, m_per_block, 256 * (per_cu > 4 ? 4 : per_cu), bal);                \
         dim3 grid((unsigned)tiles * splits);                                                                 \
         if (fast == 2) igemm_wgrad_dma_kernel<BN_, BK_, WN_, WK_, ST_, 2><<<grid, 256, 0, s>>>(*d, dw, m_per_block);      \
         else if (fast == 1) igemm_wgrad_dma_kernel<BN_, BK_, WN_, WK_, ST_, 1><<<grid, 256, 0, s>>>(*d, dw, m_per_block); \
