@@ -42,8 +42,8 @@ class Linear(nn.Module):
         nn.init.trunc_normal_(self.weight, std=0.02)
         self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
 
-    def forward(self, x, act=ops.ACT_NONE):
-        return ops.linear(x, self.weight, self.bias, act)
+    def forward(self, x, act=ops.ACT_NONE, residual=None):
+        return ops.linear(x, self.weight, self.bias, act, residual=residual)
 
 
 class LayerNorm(nn.Module):
@@ -95,8 +95,9 @@ class Mlp(nn.Module):
         self.fc1 = Linear(cin, hidden or cin)
         self.fc2 = Linear(hidden or cin, cout or cin)
 
-    def forward(self, x):
-        return self.fc2(self.fc1(x, ops.ACT_GELU))
+    def forward(self, x, residual=None):
+        """fc2(gelu(fc1(x))) [+ residual, added in fc2's GEMM epilogue]."""
+        return self.fc2(self.fc1(x, ops.ACT_GELU), residual=residual)
 
 
 class MlpNorm(nn.Module):

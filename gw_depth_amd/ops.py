@@ -254,7 +254,7 @@ def conv2d(x, w, bias=None, *, stride=1, pad=0, act=ACT_NONE, act_scale=1.0, res
                          getattr(w, "_gwd_bf16", None), sinks if (sinks[0] or sinks[1]) else None)
 
 
-def linear(x, w, bias=None, act=ACT_NONE, rows=None):
+def linear(x, w, bias=None, act=ACT_NONE, rows=None, residual=None):
     """x (..., K) @ w(N, K)^T + bias, optional fused activation; same kernel as conv2d (1x1, one pixel per row).
     rows=(r0, r1): use only that row range of a packed parameter (the q/k/v blocks of an attention in-projection);
     the gradient then goes straight into that slice of the parameter's flat gradient instead of through a
@@ -275,7 +275,8 @@ def linear(x, w, bias=None, act=ACT_NONE, rows=None):
         bias = None if bias is None else bias[r0:r1]
     n = w.shape[0]
     sinks = (None if ws is None else (ws[0].view(n, 1, 1, K), ws[1]), bs)
-    y = _ConvFn.apply(x2, w.view(n, 1, 1, K), bias, None, None, None, 1, 0, act, 1.0, None,
+    res = None if residual is None else residual.reshape(-1, 1, 1, n)
+    y = _ConvFn.apply(x2, w.view(n, 1, 1, K), bias, res, None, None, 1, 0, act, 1.0, None,
                       None if shadow is None else shadow.view(n, 1, 1, K),
                       sinks if (sinks[0] or sinks[1]) else None)
     return y.view(*lead, n)
