@@ -7,8 +7,20 @@
 
 namespace {
 
-template <bool GATHER>
-__global__ void winmap_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int B, int H, int W, int CV, int shift) {
+// 16 bytes of T plus 16 bytes of T, element-wise in fp32
+template <typename T> __device__ __forceinline__ uint4 add_vec(const uint4 &a, const uint4 &b) {
+    constexpr int N = 16 / sizeof(T);
+    uint4 r;
+    const T *pa = (const T *)&a, *pb = (const T *)&b;
+    T *pr = (T *)&r;
+#pragma unroll
+    for (int e = 0; e < N; ++e) pr[e] = from_f32<T>(to_f32(pa[e]) + to_f32(pb[e]));
+    return r;
+}
+
+template <bool GATHER, typename T>
+__global__ void winmap_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, const uint4 *__restrict__ res, int B, int H, int W,
+                              int CV, int shift) {
     const int Hp = (H + 6) / 7 * 7, Wp = (W + 6) / 7 * 7, nwx = Wp / 7, nwy = Hp / 7;
     const int64_t total = (int64_t)B * Hp * Wp * CV;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -28,16 +40,17 @@ __global__ void winmap_kernel(const uint4 *__restrict__ src, uint4 *__restrict__
         if (GATHER) {
             dst[i] = inside ? src[map_idx] : make_uint4(0u, 0u, 0u, 0u);
         } else if (inside) {
-            dst[map_idx] = src[i];
+            dst[map_idx] = res ? add_vec<T>(src[i], res[map_idx]) : src[i];     // window reverse (+ the block's residual stream)
         }
     }
 }
 
 }  // namespace
 
-extern "C" int gwd_window_map(const void *src, void *dst, int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift,
+extern "C" int gwd_window_map(const void *src, void *dst, const void *residual, int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift,
                               int32_t gather, int32_t dtype, void *stream) {
     if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || C <= 0 || shift < 0 || shift >= 7) return -1;
+    if (gather && residual) return -1;
     const int esz = dtype == GWD_BF16 ? 2 : (dtype == GWD_F32 ? 4 : 0);
     if (!esz) return -2;
     if ((C * esz) % 16) return -4;
@@ -46,10 +59,13 @@ extern "C" int gwd_window_map(const void *src, void *dst, int32_t B, int32_t H, 
     const int64_t total = (int64_t)B * Hp * Wp * CV;
     int64_t nb = (total + 255) / 256;
     const int grid = (int)(nb > 8192 ? 8192 : nb);
+    const uint4 *r4 = (const uint4 *)residual;
     if (gather)
-        winmap_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>((const uint4 *)src, (uint4 *)dst, B, H, W, CV, shift);
+        winmap_kernel<true, float><<<grid, 256, 0, (hipStream_t)stream>>>((const uint4 *)src, (uint4 *)dst, nullptr, B, H, W, CV, shift);
+    else if (dtype == GWD_BF16)
+        winmap_kernel<false, __bf16><<<grid, 256, 0, (hipStream_t)stream>>>((const uint4 *)src, (uint4 *)dst, r4, B, H, W, CV, shift);
     else
-        winmap_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>((const uint4 *)src, (uint4 *)dst, B, H, W, CV, shift);
+        winmap_kernel<false, float><<<grid, 256, 0, (hipStream_t)stream>>>((const uint4 *)src, (uint4 *)dst, r4, B, H, W, CV, shift);
     GWD_CHECK_LAUNCH();
     return 0;
 }

@@ -142,7 +142,7 @@ class HipLibrary:
         L.gwd_point_sample_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_point_sample_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_weight_prep_batch.argtypes = [vp, i32, i32, vp]
-        L.gwd_window_map.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+        L.gwd_window_map.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_sqnorm.argtypes = [vp, vp, i64, vp]
         L.gwd_adamw_step.argtypes = [vp, vp, vp, vp, vp, vp, i64] + [f32] * 9 + [vp]
 
@@ -343,8 +343,8 @@ class HipLibrary:
         """table: device uint8 tensor holding n_jobs packed gwd_prep_job records (see PrepJob)."""
         self._check(self.lib.gwd_weight_prep_batch(_ptr(table), n_jobs, total_blocks, self._stream(table)), "gwd_weight_prep_batch")
 
-    def window_map(self, src, dst, B, H, W, C, shift, gather):
-        self._check(self.lib.gwd_window_map(_ptr(src), _ptr(dst), B, H, W, C, shift, int(gather), dtype_code(src),
+    def window_map(self, src, dst, B, H, W, C, shift, gather, residual=None):
+        self._check(self.lib.gwd_window_map(_ptr(src), _ptr(dst), _ptr(residual), B, H, W, C, shift, int(gather), dtype_code(src),
                                             self._stream(src, dst)), "gwd_window_map")
 
     def sqnorm(self, g, sq, n):

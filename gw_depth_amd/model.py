@@ -461,11 +461,11 @@ class SwinBlock(nn.Module):
             dn = ops.window_gather(self.norm_depth1(dtok).view(B, H, W, tC), shift)
             sn = ops.window_gather(self.norm_seg1(stok).view(B, H, W, tC), shift)
             aw, dw, sw = self.attn(ops.window_gather(xn, shift), dn, sn, mask)
-            x = x + ops.window_scatter(aw, B, H, W, shift).view(B, H * W, C)
+            x = ops.window_scatter(aw, B, H, W, shift, residual=x).view(B, H * W, C)
             x = self.mlp(self.norm2(x), residual=x)
-            d = dtok + ops.window_scatter(dw, B, H, W, shift).view(B, H * W, tC)
+            d = ops.window_scatter(dw, B, H, W, shift, residual=dtok).view(B, H * W, tC)
             d = self.mlp_depth(self.norm_depth2(d), residual=d)
-            s = stok + ops.window_scatter(sw, B, H, W, shift).view(B, H * W, tC)
+            s = ops.window_scatter(sw, B, H, W, shift, residual=stok).view(B, H * W, tC)
             s = self.mlp_seg(self.norm_seg2(s), residual=s)
             return x, d, s
         x = x + unroll_crop(aw, H, W, Hp, Wp, shift).reshape(B, H * W, C)

@@ -640,20 +640,22 @@ class _WindowGatherFn(torch.autograd.Function):
 
 class _WindowScatterFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, win, B, H, W, shift):
+    def forward(ctx, win, B, H, W, shift, residual):
         win = win.contiguous()
         C = win.shape[-1]
         out = torch.empty((B, H, W, C), dtype=win.dtype, device=win.device)
-        _lib().window_map(win, out, B, H, W, C, shift, False)
-        ctx.cfg = (B, H, W, C, shift, tuple(win.shape))
+        res = None if residual is None else residual.contiguous()
+        _lib().window_map(win, out, B, H, W, C, shift, False, residual=res)
+        ctx.cfg = (B, H, W, C, shift, tuple(win.shape), residual is not None and tuple(residual.shape))
         return out
 
     @staticmethod
     def backward(ctx, g):
-        B, H, W, C, shift, shape = ctx.cfg
+        B, H, W, C, shift, shape, rshape = ctx.cfg
+        g = g.contiguous()
         gw = torch.empty(shape, dtype=g.dtype, device=g.device)
-        _lib().window_map(g.contiguous(), gw, B, H, W, C, shift, True)
-        return gw, None, None, None, None
+        _lib().window_map(g, gw, B, H, W, C, shift, True)
+        return gw, None, None, None, None, (g.view(rshape) if rshape else None)
 
 
 def window_gather(x, shift):
@@ -661,9 +663,9 @@ def window_gather(x, shift):
     return _WindowGatherFn.apply(x, int(shift))
 
 
-def window_scatter(win, B, H, W, shift):
-    """Inverse of window_gather (window reverse, un-shift, crop) -> (B,H,W,C)."""
-    return _WindowScatterFn.apply(win, int(B), int(H), int(W), int(shift))
+def window_scatter(win, B, H, W, shift, residual=None):
+    """Inverse of window_gather (window reverse, un-shift, crop) -> (B,H,W,C) [+ residual, any shape with B*H*W*C elements]."""
+    return _WindowScatterFn.apply(win, int(B), int(H), int(W), int(shift), residual)
 
 
 class _InormGeluFn(torch.autograd.Function):

@@ -218,8 +218,9 @@ int gwd_inorm_gelu_backward(const void *gy, const void *u, const float *stat, fl
 
 /* Window partition (gather != 0) / reverse (gather == 0) of a (B,H,W,C) token map into (B*nWin,49,C) 7x7 windows
  * with zero padding to multiples of 7 and cyclic shift `shift` (src/models/multiscale_transformerr.py:667-676,
- * 705-707 / 730-747).  C * sizeof(dtype) must be a multiple of 16.                                            */
-int gwd_window_map(const void *src, void *dst, int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift,
+ * 705-707 / 730-747).  C * sizeof(dtype) must be a multiple of 16.  residual (reverse only, may be NULL): a (B,H,W,C)
+ * map added to the result - the block's residual stream, `x = shortcut + x` of :749.                           */
+int gwd_window_map(const void *src, void *dst, const void *residual, int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift,
                    int32_t gather, int32_t dtype, void *stream);
 
 /* Pixel-major resampling ([B][H][W][C]).  mode 0 = bilinear align_corners=True (PSP branches of

@@ -299,7 +299,7 @@ class FakeDevice:
                 for q, t in zip(qi, ti):
                     out[l, off[b] + t] = int(q)
 
-    def window_map(self, src, dst, B, H, W, C, shift, gather):
+    def window_map(self, src, dst, B, H, W, C, shift, gather, residual=None):
         Hp, Wp = (H + 6) // 7 * 7, (W + 6) // 7 * 7
         if gather:
             x = F.pad(src.reshape(B, H, W, C), (0, 0, 0, Wp - W, 0, Hp - H))
@@ -311,7 +311,10 @@ class FakeDevice:
             x = src.reshape(B, Hp // 7, Wp // 7, 7, 7, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
             if shift:
                 x = torch.roll(x, shifts=(shift, shift), dims=(1, 2))
-            dst.copy_(x[:, :H, :W].reshape(dst.shape))
+            x = x[:, :H, :W]
+            if residual is not None:
+                x = (x.float() + residual.reshape(x.shape).float()).to(dst.dtype)
+            dst.copy_(x.reshape(dst.shape))
 
     def inorm_gelu_forward(self, a, u, y, part, stat, B, L, C, S, eps):
         uf = u.reshape(B, L, C).float()

@@ -372,6 +372,12 @@ def test_window_map(dev, shape, dtype):
     rt = torch.empty(B, H, W, C, dtype=dtype).cuda()
     dev.window_map(win, rt, B, H, W, C, shift, False)
     assert torch.equal(rt.cpu(), x)
+    res = rnd(B, H, W, C, dtype=dtype, seed=6)                    # reverse + residual stream in one pass
+    fused_r = torch.empty(B, H, W, C, dtype=dtype)
+    fake.window_map(g, fused_r, B, H, W, C, shift, False, residual=res)
+    fused = torch.empty(B, H, W, C, dtype=dtype).cuda()
+    dev.window_map(g.cuda(), fused, B, H, W, C, shift, False, residual=res.cuda())
+    assert torch.equal(fused.cpu(), fused_r)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
