@@ -19,7 +19,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T *__restrict__ x, const float *__restrict__ gamma,
                                                             const float *__restrict__ beta, T *__restrict__ y,
                                                             float *__restrict__ mean, float *__restrict__ rstd,
-                                                            int64_t rows, int C, int gelu) {
+                                                            int64_t rows, int C, int gelu, const T *__restrict__ res = nullptr) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
     const int per = (C + 63) / 64;
@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T *__restrict_
                 float o = (v[i] - mu) * rs;
                 if (gamma) o = o * gamma[c] + beta[c];
                 if (gelu) o = gelu_f(o);
+                if (res) o += to_f32(res[r * C + c]);
                 yr[c] = from_f32<T>(o);
             }
         }
@@ -276,7 +277,7 @@ template <typename T, int LPR, int NCH, int VB>
 __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T *__restrict__ x, const float *__restrict__ gamma,
                                                                 const float *__restrict__ beta, T *__restrict__ y,
                                                                 float *__restrict__ mean, float *__restrict__ rstd,
-                                                                int64_t rows, int C, int gelu) {
+                                                                int64_t rows, int C, int gelu, const T *__restrict__ res) {
     constexpr int VEC = VB / (int)sizeof(T), RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, sub = lane % LPR, rsel = lane / LPR;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
@@ -328,10 +329,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T *__restr
         for (int c = 0; c < NCH; ++c) {
             if (!(okr && okc[c])) continue;
             alignas(16) T outv[VEC];
+            Raw<VB> rraw = {};
+            if (res) rraw = *(const Raw<VB> *)(res + r * C + (sub + c * LPR) * VEC);
+            const T *pr = (const T *)&rraw;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 float o = (v[c][e] - mu) * rs * g[c][e] + b[c][e];
                 if (gelu) o = gelu_f(o);
+                if (res) o += to_f32(pr[e]);
                 outv[e] = from_f32<T>(o);
             }
             *(Raw<VB> *)(y + r * C + (sub + c * LPR) * VEC) = *(const Raw<VB> *)outv;
@@ -562,7 +567,7 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const T *__restrict
 
 template <typename T, int VB>
 int launch_ln_fwd_vec(const T *x, const float *ga, const float *be, T *y, float *mean, float *rstd, int64_t rows, int C, int gelu,
-                      hipStream_t s) {
+                      const T *res, hipStream_t s) {
     constexpr int VEC = VB / (int)sizeof(T);
     const int need = C / VEC;
 #define LN_FWD(LPR, NCH)                                                                                            \
@@ -571,7 +576,7 @@ int launch_ln_fwd_vec(const T *x, const float *ga, const float *be, T *y, float 
         /* ~20 KiB of rows per workgroup: measured optimum between 10 MB (512 workgroups) and 49 MB (2048) tensors */  \
         int64_t cap = rows * C * (int64_t)sizeof(T) / 20480;                                                        \
         cap = cap < 256 ? 256 : (cap > 2048 ? 2048 : cap);                                                          \
-        layernorm_fwd_vec_kernel<T, LPR, NCH, VB><<<row_grid(wv, 4, (int)cap), 256, 0, s>>>(x, ga, be, y, mean, rstd, rows, C, gelu); \
+        layernorm_fwd_vec_kernel<T, LPR, NCH, VB><<<row_grid(wv, 4, (int)cap), 256, 0, s>>>(x, ga, be, y, mean, rstd, rows, C, gelu, res); \
         return 0;                                                                                                   \
     }
     if (need <= 8) LN_FWD(8, 1)
@@ -618,7 +623,7 @@ int launch_ln_bwd_vec(const T *gy, const T *x, const float *ga, const float *be,
     else if ((dtype) == GWD_F32) { CALL_F32; } \
     else return -2;
 
-extern "C" int gwd_layernorm_forward(const void *x, const float *gamma, const float *beta, void *y, float *mean,
+extern "C" int gwd_layernorm_forward(const void *x, const float *gamma, const float *beta, const void *residual, void *y, float *mean,
                                      float *rstd, int64_t rows, int32_t C, int32_t gelu, int32_t dtype, void *stream) {
     if (!x || !y || !mean || !rstd || rows < 0 || C <= 0 || C > 64 * MAX_PER_LANE) return -1;
     if ((gamma == nullptr) != (beta == nullptr)) return -1;
@@ -626,16 +631,16 @@ extern "C" int gwd_layernorm_forward(const void *x, const float *gamma, const fl
     hipStream_t s = (hipStream_t)stream;
     {
         int rc = -5;
-        if (dtype == GWD_BF16 && C % 8 == 0) rc = launch_ln_fwd_vec<__bf16, 16>((const __bf16 *)x, gamma, beta, (__bf16 *)y, mean, rstd, rows, C, gelu, s);
-        else if (dtype == GWD_BF16 && C % 4 == 0) rc = launch_ln_fwd_vec<__bf16, 8>((const __bf16 *)x, gamma, beta, (__bf16 *)y, mean, rstd, rows, C, gelu, s);
-        else if (dtype == GWD_F32 && C % 4 == 0) rc = launch_ln_fwd_vec<float, 16>((const float *)x, gamma, beta, (float *)y, mean, rstd, rows, C, gelu, s);
-        else if (dtype == GWD_F32 && C % 2 == 0) rc = launch_ln_fwd_vec<float, 8>((const float *)x, gamma, beta, (float *)y, mean, rstd, rows, C, gelu, s);
+        if (dtype == GWD_BF16 && C % 8 == 0) rc = launch_ln_fwd_vec<__bf16, 16>((const __bf16 *)x, gamma, beta, (__bf16 *)y, mean, rstd, rows, C, gelu, (const __bf16 *)residual, s);
+        else if (dtype == GWD_BF16 && C % 4 == 0) rc = launch_ln_fwd_vec<__bf16, 8>((const __bf16 *)x, gamma, beta, (__bf16 *)y, mean, rstd, rows, C, gelu, (const __bf16 *)residual, s);
+        else if (dtype == GWD_F32 && C % 4 == 0) rc = launch_ln_fwd_vec<float, 16>((const float *)x, gamma, beta, (float *)y, mean, rstd, rows, C, gelu, (const float *)residual, s);
+        else if (dtype == GWD_F32 && C % 2 == 0) rc = launch_ln_fwd_vec<float, 8>((const float *)x, gamma, beta, (float *)y, mean, rstd, rows, C, gelu, (const float *)residual, s);
         if (rc == 0) { GWD_CHECK_LAUNCH(); return 0; }
     }
     const int grid = row_grid(rows, 4);
     DISPATCH_T(dtype,
-               (layernorm_fwd_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)x, gamma, beta, (__bf16 *)y, mean, rstd, rows, C, gelu)),
-               (layernorm_fwd_kernel<float><<<grid, 256, 0, s>>>((const float *)x, gamma, beta, (float *)y, mean, rstd, rows, C, gelu)));
+               (layernorm_fwd_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)x, gamma, beta, (__bf16 *)y, mean, rstd, rows, C, gelu, (const __bf16 *)residual)),
+               (layernorm_fwd_kernel<float><<<grid, 256, 0, s>>>((const float *)x, gamma, beta, (float *)y, mean, rstd, rows, C, gelu, (const float *)residual)));
     GWD_CHECK_LAUNCH();
     return 0;
 }

@@ -112,7 +112,7 @@ class HipLibrary:
         L.gwd_weight_prep.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
         L.gwd_act_backward.argtypes = [vp, vp, vp, vp, i64, i32, i32, f32, i32, vp]
         L.gwd_colsum.argtypes = [vp, vp, i64, i32, i32, vp]
-        L.gwd_layernorm_forward.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
+        L.gwd_layernorm_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
         L.gwd_layernorm_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
         L.gwd_softmax_forward.argtypes = [vp, vp, i64, i32, i32, vp]
         L.gwd_softmax_backward.argtypes = [vp, vp, vp, i64, i32, i32, vp]
@@ -214,8 +214,8 @@ class HipLibrary:
     def colsum(self, g, out, rows, C):
         self._check(self.lib.gwd_colsum(_ptr(g), _ptr(out), rows, C, dtype_code(g), self._stream(g, out)), "gwd_colsum")
 
-    def layernorm_forward(self, x, gamma, beta, y, mean, rstd, rows, C, gelu):
-        self._check(self.lib.gwd_layernorm_forward(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd),
+    def layernorm_forward(self, x, gamma, beta, y, mean, rstd, rows, C, gelu, residual=None):
+        self._check(self.lib.gwd_layernorm_forward(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(y), _ptr(mean), _ptr(rstd),
                                                    rows, C, int(gelu), dtype_code(x), self._stream(x, y)),
                     "gwd_layernorm_forward")
 

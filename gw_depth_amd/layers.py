@@ -52,8 +52,8 @@ class LayerNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(c))
         self.bias = nn.Parameter(torch.zeros(c))
 
-    def forward(self, x, gelu=False):
-        return ops.layer_norm(x, self.weight, self.bias, gelu)
+    def forward(self, x, gelu=False, residual=None):
+        return ops.layer_norm(x, self.weight, self.bias, gelu, residual=residual)
 
 
 class FrozenBN(nn.Module):

@@ -497,8 +497,8 @@ class ConvLn(nn.Module):
         self.layer_norm = LayerNorm(cout)
         self.pad = k // 2
 
-    def forward(self, x, gelu=False):
-        return self.layer_norm(ops.conv2d(x, self.conv.weight, pad=self.pad), gelu)
+    def forward(self, x, gelu=False, residual=None):
+        return self.layer_norm(ops.conv2d(x, self.conv.weight, pad=self.pad), gelu, residual=residual)
 
 
 class PyrBlock(nn.Module):
@@ -510,7 +510,7 @@ class PyrBlock(nn.Module):
         self.conv2 = ConvLn(c, c, 3)
 
     def forward(self, x):
-        return self.conv2(self.conv1[0](x, True)) + x
+        return self.conv2(self.conv1[0](x, True), residual=x)            # the skip is added in the LayerNorm kernel
 
 
 class PyramidLayer(nn.Module):

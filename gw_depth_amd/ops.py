@@ -284,9 +284,10 @@ def linear(x, w, bias=None, act=ACT_NONE, rows=None, residual=None):
 
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, gelu, sinks):
+    def forward(ctx, x, gamma, beta, gelu, sinks, residual):
         lib = _lib()
         ctx.sinks = sinks
+        ctx.has_res = residual is not None
         x = x.contiguous()
         C = x.shape[-1]
         rows = x.numel() // C
@@ -295,7 +296,7 @@ class _LayerNormFn(torch.autograd.Function):
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         g = gamma.detach() if gamma is not None else None
         b = beta.detach() if beta is not None else None
-        lib.layernorm_forward(x, g, b, y, mean, rstd, rows, C, gelu)
+        lib.layernorm_forward(x, g, b, y, mean, rstd, rows, C, gelu, residual=None if residual is None else residual.contiguous())
         ctx.save_for_backward(x, g, b, mean, rstd)
         ctx.gelu = gelu
         return y
@@ -316,21 +317,22 @@ class _LayerNormFn(torch.autograd.Function):
             dg = torch.zeros(C, dtype=torch.float32, device=x.device)
             db = torch.zeros(C, dtype=torch.float32, device=x.device)
         lib.layernorm_backward(gy, x, g, b, mean, rstd, gx, dg, db, rows, C, ctx.gelu)
+        gres = gy if ctx.has_res else None                # y = LN(x) + residual: the skip gets the incoming gradient as is
         if direct:
             for h in (h1, h2):
                 if h is not None:
                     h()
-            return gx, None, None, None, None
-        return gx, dg, db, None, None
+            return gx, None, None, None, None, gres
+        return gx, dg, db, None, None, gres
 
 
-def layer_norm(x, gamma, beta, gelu=False):
-    """LayerNorm over the last dim (eps 1e-5) with optional fused exact GELU."""
+def layer_norm(x, gamma, beta, gelu=False, residual=None):
+    """LayerNorm over the last dim (eps 1e-5) with optional fused exact GELU; residual (same shape) is added afterwards."""
     sinks = None
     if gamma is not None:
         sg, sb = _sink(gamma), _sink(beta)
         sinks = (sg, sb) if (sg is not None and sb is not None) else None
-    return _LayerNormFn.apply(x, gamma, beta, bool(gelu), sinks)
+    return _LayerNormFn.apply(x, gamma, beta, bool(gelu), sinks, residual)
 
 
 class _SoftmaxFn(torch.autograd.Function):

@@ -101,7 +101,9 @@ int gwd_act_backward_colsum(const void *gy, const void *ref, void *gx, float *db
  * Replaces nn.LayerNorm (+ nn.GELU) call sites: src/models/points/points_sample.py:19-25,
  * src/models/multiscale_transformerr.py:612-632,659-665,755-777, src/models/transformer.py:138-162,
  * src/models/dense_upsample.py:125,138,166,177.                                                  */
-int gwd_layernorm_forward(const void *x, const float *gamma, const float *beta, void *y, float *mean,
+/* residual (may be NULL): [rows][C], added AFTER the normalisation / GELU: y = gelu?(LN(x)) + residual - the skip
+ * connection of BasicBlock (src/models/points/points_sample.py:41-42); its gradient is gy itself.              */
+int gwd_layernorm_forward(const void *x, const float *gamma, const float *beta, const void *residual, void *y, float *mean,
                           float *rstd, int64_t rows, int32_t C, int32_t gelu, int32_t dtype, void *stream);
 int gwd_layernorm_backward(const void *gy, const void *x, const float *gamma, const float *beta,
                            const float *mean, const float *rstd, void *gx, float *dgamma, float *dbeta,

@@ -140,7 +140,7 @@ class FakeDevice:
     def colsum(self, g, out, rows, C):
         out.add_(g.reshape(rows, C).float().sum(0))
 
-    def layernorm_forward(self, x, gamma, beta, y, mean, rstd, rows, C, gelu):
+    def layernorm_forward(self, x, gamma, beta, y, mean, rstd, rows, C, gelu, residual=None):
         xf = x.reshape(rows, C).float()
         mu = xf.mean(1)
         rs = (xf.var(1, unbiased=False) + 1e-5).rsqrt()
@@ -149,6 +149,8 @@ class FakeDevice:
             o = o * gamma + beta
         if gelu:
             o = F.gelu(o)
+        if residual is not None:
+            o = o + residual.reshape(rows, C).float()
         y.copy_(o.reshape(y.shape))
         mean.copy_(mu)
         rstd.copy_(rs)

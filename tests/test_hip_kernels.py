@@ -141,6 +141,12 @@ def test_layernorm(dev, rows, C, gelu, affine, dtype):
     assert rel(gx, gx_r) < TOL[dtype]
     if affine:
         assert rel(dg, dg_r) < TOL[dtype] and rel(db, db_r) < TOL[dtype]
+    res = rnd(rows, C, dtype=dtype, seed=5)                      # skip connection added in the same kernel
+    y2_r = torch.empty_like(x)
+    fake.layernorm_forward(x, ga, be, y2_r, m_r, r_r, rows, C, gelu, residual=res)
+    y2 = torch.empty_like(x).cuda()
+    dev.layernorm_forward(x.cuda(), cu(ga), cu(be), y2, m, r, rows, C, gelu, residual=res.cuda())
+    assert rel(y2, y2_r) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
