@@ -67,6 +67,39 @@ def cpu_baseline(sd_cpu, cfg, budget_s):
             "sample": "%d fp32 train step(s), batch 1, 480x640, oracle/gwdepth_ref.py on %d host threads (%.1f s)" % (n, cores, el)}
 
 
+def depth_rmse_leg(sd_cpu, cfg, dtype):
+    """The other half of BASELINE.json's metric: depth RMSE (`rms` of compute_depth_errors, src/util/metrics.py:203-204,
+    after evaluate()'s clamp + validity mask) of the product against the oracle on identical weights and inputs - ONE
+    480x640 image, eval mode.  Product: HIP forward in the bench dtype and in fp32, metrics by gwd_eval_accumulate on the
+    device.  Oracle (checker): CPU fp32 forward + oracle/eval_ref.py.  Outside the timed region."""
+    from gw_depth_amd import build_model
+    from gw_depth_amd.evaluate import DenseMetrics
+    from gw_depth_amd.model import NestedTensor
+    from gw_depth_amd.synth import synth_batch
+    from oracle import eval_ref
+    from oracle import gwdepth_ref as R
+    b = synth_batch(1, 480, 640, seed=1)
+    with torch.no_grad():
+        ref = R.forward({k: v.clone() for k, v in sd_cpu.items()}, b["images"], b["pad_mask"],
+                        R.Cfg(dropout=cfg.dropout, log_depth_error=cfg.log_depth_error), training=False)
+    per_image, _ = eval_ref.evaluate_dense(ref["pred_depth"][-1].numpy(), b["depth"].numpy(), ref["pred_seg"].numpy(), b["seg"].numpy())
+    out = {"oracle_fp32": float(per_image[0, 3]), "sample": "1 image 480x640, weight seed 0, data seed 1, eval mode"}
+    model, _, _ = build_model(cfg)
+    model.load_state_dict(sd_cpu)
+    model.cuda().eval()
+    for name, dt in (("product_fp32", torch.float32), ("product_" + ("bf16" if dtype == torch.bfloat16 else "fp32"), dtype)):
+        if name in out:
+            continue
+        model.compute_dtype = dt
+        with torch.no_grad():
+            o = model(NestedTensor(b["images"].cuda(), b["pad_mask"].cuda()))
+        dm = DenseMetrics("cuda")
+        dm.update(o["pred_depth"][-1], b["depth"].cuda(), o["pred_seg"], b["seg"].cuda())
+        out[name] = dm.compute()["rms"]
+        out[name.replace("product", "abs_diff")] = abs(out[name] - out["oracle_fp32"])
+    return out
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -139,6 +172,7 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         print("[bench] GPU leg done: %.2f images/s; timing the CPU baseline (oracle) ..." % ips, file=sys.stderr, flush=True)
         out["cpu_baseline"] = cpu_baseline(sd_cpu, cfg, a.cpu_baseline_budget_s)
+        out["depth_rmse"] = depth_rmse_leg(sd_cpu, cfg, dtype)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

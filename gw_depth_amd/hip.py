@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libgwdepth_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3, 4
-WS_INORM_GELU, WS_RESAMPLE_BWD = 0, 1          # gwd_query_workspace ops
+WS_INORM_GELU, WS_RESAMPLE_BWD, WS_EVAL = 0, 1, 2          # gwd_query_workspace ops
 GATHER_CONV, GATHER_TRANSPOSED, GATHER_UPSAMPLED = 0, 1, 2
 RESAMPLE_BILINEAR_AC, RESAMPLE_NEAREST = 0, 1
 
@@ -28,7 +28,7 @@ ENTRY_POINTS = [
     "gwd_tokattn_backward", "gwd_certain_sample", "gwd_lsap", "gwd_window_map",
     "gwd_inorm_gelu_forward", "gwd_inorm_gelu_backward", "gwd_weight_prep_batch",
     "gwd_point_sample_forward", "gwd_point_sample_backward", "gwd_act_backward_colsum", "gwd_resample_backward_sep",
-    "gwd_softmax_masked_forward", "gwd_softmax_scaled_backward", "gwd_query_workspace",
+    "gwd_softmax_masked_forward", "gwd_softmax_scaled_backward", "gwd_query_workspace", "gwd_eval_accumulate",
 ]
 
 
@@ -135,6 +135,7 @@ class HipLibrary:
         L.gwd_inorm_gelu_backward.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp]
         L.gwd_query_workspace.argtypes = [i32, ctypes.POINTER(ctypes.c_int64), i32]
         L.gwd_query_workspace.restype = ctypes.c_int64
+        L.gwd_eval_accumulate.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp, vp, vp, vp, i32, i64, f32, f32, i32, i32, vp]
         L.gwd_softmax_masked_forward.argtypes = [vp, vp, vp, i64, i32, i64, ctypes.c_float, i32, vp]
         L.gwd_softmax_scaled_backward.argtypes = [vp, vp, vp, i64, i32, ctypes.c_float, i32, vp]
         L.gwd_resample_backward_sep.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -239,6 +240,15 @@ class HipLibrary:
     def softmax_backward(self, gy, y, gx, rows, L):
         self._check(self.lib.gwd_softmax_backward(_ptr(gy), _ptr(y), _ptr(gx), rows, L, dtype_code(y),
                                                   self._stream(gy, y, gx)), "gwd_softmax_backward")
+
+    def eval_accumulate(self, pred, gt, seg, seg_strides, seg_gt, workspace, measures, running, confusion, B, HW, dmin, dmax):
+        """gwd_eval_accumulate.  seg may be a strided view: seg_strides = (image, pixel, class) element strides."""
+        sb, sp, sc = (int(v) for v in seg_strides) if seg is not None else (0, 0, 0)
+        self._check(self.lib.gwd_eval_accumulate(
+            _ptr(pred), _ptr(gt), None if seg is None else ctypes.c_void_p(seg.data_ptr()), sb, sp, sc, _ptr(seg_gt),
+            _ptr(workspace), _ptr(measures), _ptr(running), _ptr(confusion), B, HW, float(dmin), float(dmax),
+            dtype_code(pred) if pred is not None else F32, dtype_code(seg) if seg is not None else F32,
+            self._stream(pred, gt, seg, seg_gt, workspace, measures, running, confusion)), "gwd_eval_accumulate")
 
     def silog_sums(self, pred, gt, sums, B, h, w, H, W, log_err):
         self._check(self.lib.gwd_silog_sums(_ptr(pred), _ptr(gt), _ptr(sums), B, h, w, H, W, int(log_err),

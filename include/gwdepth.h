@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GWD_VERSION 3
+#define GWD_VERSION 4
 
 enum { GWD_F32 = 0, GWD_BF16 = 1 };
 enum { GWD_ACT_NONE = 0, GWD_ACT_RELU = 1, GWD_ACT_GELU = 2, GWD_ACT_ELU = 3, GWD_ACT_SIGMOID = 4 };
@@ -58,8 +58,9 @@ const char *gwd_arch(void);
  * and this tells the caller how many BYTES it must hold (fully overwritten by the call, no initialisation needed).
  *   GWD_WS_INORM_GELU      dims = {B, S, C}        -> `part` of gwd_inorm_gelu_forward / _backward
  *   GWD_WS_RESAMPLE_BWD    dims = {B, Ho, Ws, C}   -> `tmp`  of gwd_resample_backward_sep
+ *   GWD_WS_EVAL            dims = {B, H*W}         -> `workspace` of gwd_eval_accumulate
  * Returns -1 for an unknown op or a wrong dimension count.                                                     */
-enum { GWD_WS_INORM_GELU = 0, GWD_WS_RESAMPLE_BWD = 1 };
+enum { GWD_WS_INORM_GELU = 0, GWD_WS_RESAMPLE_BWD = 1, GWD_WS_EVAL = 2 };
 int64_t gwd_query_workspace(int32_t op, const int64_t *dims, int32_t ndims);
 
 /* Implicit-GEMM convolution on MFMA with fused epilogue y = act(scale*conv(x,w) + shift + residual).
@@ -255,6 +256,28 @@ int gwd_sqnorm(const float *g, double *sq, int64_t n, void *stream);
 int gwd_adamw_step(float *p, const float *g, float *m, float *v, void *p_bf16, const double *sq,
                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                    float bias_corr1, float bias_corr2, float max_norm, float grad_scale, void *stream);
+
+/* Dense evaluation metrics of a batch of B images with H*W = HW pixels each, accumulated on the device.
+ * Replaces the device->host copies and per-image numpy of evaluate(): the prediction clamp and GT validity mask
+ * (src/engine_glassrgbd.py:249-253), compute_depth_errors (src/util/metrics.py:198-218), the argmax + ignore-255
+ * confusion counts of compute_mean_ioU / get_confusion_matrix (src/util/metrics.py:37-74, engine :236-241) and the
+ * running sums `depth_eval_measures[:9] += measures; [9] += 1` (engine :262-263).
+ *   pred_depth [B][HW] (depth_dtype), gt_depth [B][HW] fp32 - both NULL: no depth part;
+ *   seg_logits: class c of pixel i of image b at seg_logits[b*seg_sb + i*seg_sp + c*seg_sc] (seg_dtype; element strides, so
+ *               both the reference's (B,2,H,W) and the pixel-major (B,H,W,2) layout are read in place),
+ *   seg_gt [B][HW] int64 (255 = ignore)                     - both NULL: no segmentation part;
+ *   workspace: gwd_query_workspace(GWD_WS_EVAL, {B, HW}) bytes, fully overwritten;
+ *   measures [B][9] f64 OUT: silog, abs_rel, log10, rms, sq_rel, log_rms, d1, d2, d3 of each image (engine :204 order;
+ *               all NaN for an image without a valid pixel, as numpy's mean of an empty array);
+ *   running [10] f64 IN/OUT: += the nine measures of every image, in image order; [9] += B;
+ *   confusion [4] int64 IN/OUT: [gt*2 + pred] += pixel counts.
+ * Per-pixel terms are formed in fp32 exactly as numpy forms them (IEEE division, so the three threshold counts are
+ * bit-exact); sums are f64 and folded in a fixed order: results are bit-reproducible.  Two launches, no atomics.     */
+#define GWD_EVAL_NSUM 10
+int gwd_eval_accumulate(const void *pred_depth, const float *gt_depth, const void *seg_logits, int64_t seg_sb,
+                        int64_t seg_sp, int64_t seg_sc, const int64_t *seg_gt, void *workspace, double *measures,
+                        double *running, int64_t *confusion, int32_t B, int64_t HW, float min_depth,
+                        float max_depth, int32_t depth_dtype, int32_t seg_dtype, void *stream);
 
 #ifdef __cplusplus
 }

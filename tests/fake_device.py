@@ -137,6 +137,38 @@ class FakeDevice:
             g = g * scale
         gx.copy_(g.reshape(gx.shape))
 
+    def eval_accumulate(self, pred, gt, seg, seg_strides, seg_gt, workspace, measures, running, confusion, B, HW, dmin, dmax):
+        """gwd_eval_accumulate in torch: fp32 per-pixel terms, f64 sums (src/engine_glassrgbd.py:249-263, util/metrics.py:37-99,198-218)."""
+        if pred is not None:
+            f32 = torch.float32
+            for b in range(B):
+                p = pred[b].float().clone()
+                p[p < dmin] = dmin
+                p[p > dmax] = dmax
+                p[torch.isnan(p)] = dmin
+                v = (gt[b] > dmin) & (gt[b] < dmax)
+                g, p = gt[b][v].to(f32), p[v]
+                n = float(g.numel())
+                thr = torch.maximum(g / p, p / g)
+                err = (p.double().log().to(f32) - g.double().log().to(f32))
+                l10 = (p.double().log10().to(f32) - g.double().log10().to(f32)).abs()
+                sq = (g - p) ** 2
+                me, me2 = err.double().sum() / n if n else float("nan"), (err * err).double().sum() / n if n else float("nan")
+                m = [torch.sqrt(torch.as_tensor(me2 - me * me)) * 100, ((g - p).abs() / g).double().sum() / n if n else float("nan"),
+                     l10.double().sum() / n if n else float("nan"), torch.sqrt(sq.double().sum() / n) if n else float("nan"),
+                     (sq / g).double().sum() / n if n else float("nan"), torch.sqrt(torch.as_tensor(me2)),
+                     (thr < 1.25).double().sum() / n if n else float("nan"), (thr < 1.5625).double().sum() / n if n else float("nan"),
+                     (thr < 1.953125).double().sum() / n if n else float("nan")]
+                measures[b] = torch.as_tensor([float(x) for x in m], dtype=torch.float64)
+                running[:9] += measures[b]
+                running[9] += 1
+        if seg is not None:
+            lg = seg.as_strided((B, HW, 2), tuple(seg_strides)).float()
+            c = (lg[..., 1] > lg[..., 0]).long()
+            for t in (0, 1):
+                for k in (0, 1):
+                    confusion[t * 2 + k] += int(((seg_gt == t) & (c == k)).sum())
+
     def colsum(self, g, out, rows, C):
         out.add_(g.reshape(rows, C).float().sum(0))
 
