@@ -217,7 +217,9 @@ class TrainStep:
         self.sq.zero_()
         lib.sqnorm(self.flat_g, self.sq, self.total)
         gs = 1.0 / self.world
-        for lo, hi, lr in ((0, self.split, cfg.lr), (self.split, self.total, cfg.lr_backbone)):
+        opt = getattr(self, "optimizer", None)      # checkpoint.FlatAdamW: a StepLR may have moved the groups' rates
+        lr0, lr1 = opt.lrs() if opt is not None else (cfg.lr, cfg.lr_backbone)
+        for lo, hi, lr in ((0, self.split, lr0), (self.split, self.total, lr1)):
             if hi > lo:
                 lib.adamw_step(self.flat_p[lo:hi], self.flat_g[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi],
                                None if self.flat_p16 is None else self.flat_p16[lo:hi], self.sq, hi - lo, lr, 0.9, 0.999,
