@@ -1078,6 +1078,15 @@ static int small_tile_threshold() {
     return v;
 }
 
+static int fwd_variant() {                   // experiment switch (tools/convbench.py); 0 = the shipped selection
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GWD_IGEMM_VARIANT");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
 static bool dma_enabled() {
     static int v = -1;
     if (v < 0) {
@@ -1104,7 +1113,10 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
             const bool big = big_tiles_enabled() && M >= 256 * 512;      // >= 2 workgroups per CU with 256-row tiles
             const unsigned gm2 = (M + 255) / 256;
             if (N % 160 == 0) {
-                if (big) { DMA_LAUNCH(256, 160, 8, 1, 3, dim3(gm2 * (N / 160))) } else { DMA_LAUNCH(128, 160, 4, 1, 3, dim3(gm * (N / 160))) }
+                const int var = fwd_variant();
+                if (var == 1) { DMA_LAUNCH(128, 160, 4, 1, 3, dim3(gm * (N / 160))) }
+                else if (var == 2) { DMA_LAUNCH(128, 160, 4, 1, 2, dim3(gm * (N / 160))) }
+                else if (big) { DMA_LAUNCH(256, 160, 8, 1, 3, dim3(gm2 * (N / 160))) } else { DMA_LAUNCH(128, 160, 4, 1, 3, dim3(gm * (N / 160))) }
             } else if (N > 64) {
                 const unsigned t128 = gm * ((N + 127) / 128);
                 const int small_thr = small_tile_threshold();

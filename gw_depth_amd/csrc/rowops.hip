@@ -475,6 +475,50 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T *__restrict__ g
     }
 }
 
+// Up to GWD_COLSUM_BATCH column sums in ONE launch: the job records travel by value in the kernel arguments (no table
+// upload, so the launch is capturable as it is); workgroup -> job through the block0 prefix.  The step has ~180 bias
+// gradients of 6-25 us each; most of that is per-launch latency.
+struct ColsumBatch {
+    gwd_colsum_job j[GWD_COLSUM_BATCH];
+    int n;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_batch_kernel(const ColsumBatch b) {
+    constexpr int VEC = VecOf<T>::N;
+    __shared__ float red[256 * VEC];
+    int ji = 0;
+#pragma unroll 1
+    for (int k = 1; k < b.n; ++k)
+        if ((int)blockIdx.x >= b.j[k].block0) ji = k;
+    const gwd_colsum_job job = b.j[ji];
+    const int blk = blockIdx.x - job.block0, nblk = job.blocks;
+    const T *gmat = (const T *)job.g;
+    const int C = job.C;
+    const int64_t rows = job.rows;
+    const int vpr = C / VEC, rpb = 256 / vpr;
+    const int slot = threadIdx.x / vpr, v = threadIdx.x % vpr;
+    float s[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+    if (slot < rpb) {
+        for (int64_t r = (int64_t)blk * rpb + slot; r < rows; r += (int64_t)nblk * rpb) {
+            const uint4 raw = *(const uint4 *)(gmat + r * C + v * VEC);
+            const T *p = (const T *)&raw;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s[e] += to_f32(p[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) red[threadIdx.x * VEC + e] = s[e];
+    __syncthreads();
+    for (int t = threadIdx.x; t < vpr * VEC; t += 256) {
+        const int vv = t / VEC, e = t % VEC;
+        float a = 0.f;
+        for (int sl = 0; sl < rpb; ++sl) a += red[(sl * vpr + vv) * VEC + e];
+        unsafeAtomicAdd(job.out + t, a);
+    }
+}
+
 // 16-byte vector form of act_bwd_kernel (C a multiple of the vector width, so a vector never straddles rows)
 template <typename T>
 __global__ void act_bwd_vec_kernel(const T *__restrict__ gy, const T *__restrict__ ref, T *__restrict__ gx,
@@ -753,6 +797,31 @@ extern "C" int gwd_colsum(const void *g, float *out, int64_t rows, int32_t C, in
     const int grid = (int)(b > 512 ? 512 : (b < 1 ? 1 : b));
     DISPATCH_T(dtype, (colsum_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)g, out, rows, C)),
                (colsum_kernel<float><<<grid, 256, 0, s>>>((const float *)g, out, rows, C)));
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gwd_colsum_batch(const gwd_colsum_job *jobs, int32_t n_jobs, int32_t dtype, void *stream) {
+    if (!jobs || n_jobs <= 0 || n_jobs > GWD_COLSUM_BATCH) return -1;
+    if (dtype != GWD_BF16 && dtype != GWD_F32) return -2;
+    const int vec = dtype == GWD_BF16 ? 8 : 4;
+    ColsumBatch b;
+    int total = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        gwd_colsum_job j = jobs[i];
+        if (!j.g || !j.out || j.rows <= 0 || j.C <= 0) return -1;
+        if (j.C % vec != 0 || j.C / vec > 256) return -4;          // not a vector shape: use gwd_colsum for this one
+        const int rpb = 256 / (j.C / vec);
+        int64_t nb = (j.rows + (int64_t)rpb * 16 - 1) / ((int64_t)rpb * 16);
+        j.blocks = (int)(nb > 512 ? 512 : (nb < 1 ? 1 : nb));    // the grid gwd_colsum gives the same shape
+        j.block0 = total;
+        total += j.blocks;
+        b.j[i] = j;
+    }
+    b.n = n_jobs;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GWD_BF16) colsum_batch_kernel<__bf16><<<total, 256, 0, s>>>(b);
+    else colsum_batch_kernel<float><<<total, 256, 0, s>>>(b);
     GWD_CHECK_LAUNCH();
     return 0;
 }

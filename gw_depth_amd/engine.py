@@ -242,7 +242,8 @@ class TrainStep:
             total, terms = self.losses(out, batch["depth"], batch["seg"], batch["targets"], packed=packed)
             self.zero_grad()
             self._begin_backward()
-            total.backward()
+            with ops.COLSUMS:                           # bias-gradient column sums batched 16 to a launch
+                total.backward()
             self._finish_backward()
         finally:
             if weights is not None:
@@ -261,7 +262,8 @@ class TrainStep:
             out = self.model(NestedTensor(st["images"], st["pad_mask"]), taps=st.get("taps"))
             total, terms = self.losses(out, st["depth"], st["seg"], None, packed=st["packed"])
             self.flat_g.zero_()
-            total.backward()
+            with ops.COLSUMS:
+                total.backward()
         finally:
             if weights is not None:
                 weights.end_pass()

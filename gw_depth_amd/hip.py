@@ -28,7 +28,7 @@ ENTRY_POINTS = [
     "gwd_tokattn_backward", "gwd_certain_sample", "gwd_lsap", "gwd_window_map",
     "gwd_inorm_gelu_forward", "gwd_inorm_gelu_backward", "gwd_weight_prep_batch",
     "gwd_point_sample_forward", "gwd_point_sample_backward", "gwd_act_backward_colsum", "gwd_resample_backward_sep",
-    "gwd_softmax_masked_forward", "gwd_softmax_scaled_backward", "gwd_query_workspace", "gwd_eval_accumulate",
+    "gwd_softmax_masked_forward", "gwd_softmax_scaled_backward", "gwd_query_workspace", "gwd_eval_accumulate", "gwd_colsum_batch",
 ]
 
 
@@ -49,6 +49,15 @@ class PrepJob(ctypes.Structure):
     """gwd_prep_job (include/gwdepth.h)."""
     _fields_ = [("w", ctypes.c_void_p), ("row_scale", ctypes.c_void_p), ("w_fwd", ctypes.c_void_p), ("w_dgrad", ctypes.c_void_p),
                 ("N", ctypes.c_int32), ("taps", ctypes.c_int32), ("C", ctypes.c_int32), ("block0", ctypes.c_int32)]
+
+
+class ColsumJob(ctypes.Structure):
+    """gwd_colsum_job (include/gwdepth.h)."""
+    _fields_ = [("g", ctypes.c_void_p), ("out", ctypes.c_void_p), ("rows", ctypes.c_int64), ("C", ctypes.c_int32),
+                ("block0", ctypes.c_int32), ("blocks", ctypes.c_int32)]
+
+
+COLSUM_BATCH = 16
 
 
 class Strided(ctypes.Structure):
@@ -112,6 +121,7 @@ class HipLibrary:
         L.gwd_weight_prep.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
         L.gwd_act_backward.argtypes = [vp, vp, vp, vp, i64, i32, i32, f32, i32, vp]
         L.gwd_colsum.argtypes = [vp, vp, i64, i32, i32, vp]
+        L.gwd_colsum_batch.argtypes = [ctypes.POINTER(ColsumJob), i32, i32, vp]
         L.gwd_layernorm_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
         L.gwd_layernorm_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
         L.gwd_softmax_forward.argtypes = [vp, vp, i64, i32, i32, vp]
@@ -214,6 +224,21 @@ class HipLibrary:
 
     def colsum(self, g, out, rows, C):
         self._check(self.lib.gwd_colsum(_ptr(g), _ptr(out), rows, C, dtype_code(g), self._stream(g, out)), "gwd_colsum")
+
+    def colsum_batch(self, jobs):
+        """jobs: up to COLSUM_BATCH tuples (g, out, rows, C) of ONE dtype with vector-shaped C (colsum_batchable)."""
+        recs = (ColsumJob * len(jobs))()
+        for r, (g, out, rows, C) in zip(recs, jobs):
+            r.g, r.out, r.rows, r.C = g.data_ptr(), out.data_ptr(), rows, C
+            if not (g.is_contiguous() and out.is_contiguous()):
+                raise ValueError("kernel operand must be contiguous")
+        ts = [t for j in jobs for t in j[:2]]
+        self._check(self.lib.gwd_colsum_batch(recs, len(jobs), dtype_code(jobs[0][0]), self._stream(*ts)), "gwd_colsum_batch")
+
+    @staticmethod
+    def colsum_batchable(g, C):
+        vec = 8 if g.dtype == torch.bfloat16 else 4
+        return C % vec == 0 and C // vec <= 256
 
     def layernorm_forward(self, x, gamma, beta, y, mean, rstd, rows, C, gelu, residual=None):
         self._check(self.lib.gwd_layernorm_forward(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(y), _ptr(mean), _ptr(rstd),

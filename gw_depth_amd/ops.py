@@ -101,6 +101,53 @@ class WeightCache:
         _ACTIVE_WEIGHTS = None
 
 
+class ColsumQueue:
+    """Bias gradients of a backward pass, batched: the column sums of up to hip.COLSUM_BATCH layers run as ONE launch
+    (gwd_colsum_batch) instead of one 6-25 us launch each.  engine.TrainStep opens the queue around backward and
+    flushes it at the end; outside (plain ops calls) every column sum runs at once, as before.  A queued job keeps its
+    gradient tensor alive until the flush; the hooks of the DDP bucket plan fire after the sums have been enqueued."""
+
+    def __init__(self):
+        self.jobs, self.active = [], False
+
+    def add(self, g, out, rows, C, hook=None):
+        lib = _lib()
+        if not self.active or rows <= 0 or not lib.colsum_batchable(g, C) or (self.jobs and self.jobs[0][0].dtype != g.dtype):
+            if self.jobs and self.active:
+                self.flush()                        # keep program order between jobs that may share `out`
+            lib.colsum(g, out, rows, C)
+            if hook is not None:
+                hook()
+            return
+        self.jobs.append((g, out, rows, C, hook))
+        if len(self.jobs) == hip.COLSUM_BATCH:
+            self.flush()
+
+    def flush(self):
+        if not self.jobs:
+            return
+        jobs, self.jobs = self.jobs, []
+        _lib().colsum_batch([j[:4] for j in jobs])
+        for j in jobs:
+            if j[4] is not None:
+                j[4]()
+
+    def __enter__(self):
+        self.active = True
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            if exc[0] is None:
+                self.flush()
+        finally:
+            self.jobs, self.active = [], False
+        return False
+
+
+COLSUMS = ColsumQueue()
+
+
 _ACTIVE_WEIGHTS = None
 
 
@@ -213,9 +260,7 @@ class _ConvFn(torch.autograd.Function):
                     gw.mul_(row_scale.view(-1, 1, 1, 1))
         if has_bias and ctx.needs_input_grad[2] and not bias_done:
             if b_sink is not None:
-                lib.colsum(dv, b_sink[0], rows, Cout)
-                if b_sink[1] is not None:
-                    b_sink[1]()
+                COLSUMS.add(dv, b_sink[0], rows, Cout, b_sink[1])
             else:
                 gb = torch.zeros(Cout, dtype=torch.float32, device=gy.device)
                 lib.colsum(dv, gb, rows, Cout)

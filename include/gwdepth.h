@@ -91,6 +91,19 @@ int gwd_act_backward(const void *gy, const void *ref, void *gx, const float *sca
 
 /* out[c] += sum_rows g[row][c]  (bias / shift gradients; fp32 atomics, caller zeroes).           */
 int gwd_colsum(const void *g, float *out, int64_t rows, int32_t C, int32_t dtype, void *stream);
+/* Up to GWD_COLSUM_BATCH gwd_colsum calls (same dtype) as ONE launch: out[c] += column sums of g for every job.  The
+ * records are read on the host and travel in the kernel arguments (nothing is uploaded, nothing must outlive the call).
+ * block0 / blocks are filled in by the library.  Returns -4 if a job's C is not a multiple of 16 bytes or wider than
+ * 256 vectors (run that one through gwd_colsum).                                                               */
+#define GWD_COLSUM_BATCH 16
+typedef struct {
+    const void *g;        /* [rows][C] (dtype)                       */
+    float *out;           /* [C] fp32, accumulated                   */
+    int64_t rows;
+    int32_t C;
+    int32_t block0, blocks;   /* library-internal                    */
+} gwd_colsum_job;
+int gwd_colsum_batch(const gwd_colsum_job *jobs, int32_t n_jobs, int32_t dtype, void *stream);
 /* gwd_act_backward and gwd_colsum of its result in one pass (activation backward of a biased layer: dBias is the column
  * sum of gx).  dbias is ACCUMULATED into.  Returns -4 when C is not a multiple of 16 bytes / wider than 256 vectors:
  * the caller then uses the two separate entry points.                                                            */

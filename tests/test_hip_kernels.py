@@ -523,3 +523,31 @@ def test_attention_softmax_scale_and_key_mask(dev, shape, dtype):
     y3 = torch.empty_like(y)
     dev.softmax_forward(x.cuda(), y3, B * H * L, S)
     assert torch.equal(y2, y3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_colsum_batch(dev, dtype):
+    """gwd_colsum_batch == one gwd_colsum per job (accumulating into a non-zero out), 1..16 jobs of mixed shapes, two of
+    them sharing one output; a non-vector channel count is refused (-4) before anything is launched."""
+    shapes = [(300, 256), (2400, 256), (153600, 64), (5, 8), (19200, 136), (800, 1024), (1, 512), (4800, 128),
+              (77, 24), (9600, 320), (1200, 512), (64, 64), (100, 256), (38400, 160), (333, 40), (2048, 1024)]
+    for n in (1, 3, 16):
+        jobs, refs = [], []
+        for i, (rows, C) in enumerate(shapes[:n]):
+            g = rnd(rows, C, dtype=dtype, seed=i).cuda()
+            out = rnd(C, seed=100 + i).cuda()
+            refs.append(out.clone() + g.float().sum(0))
+            jobs.append((g, out, rows, C))
+        if n == 16:                                           # two layers sharing one bias (a weight used twice)
+            jobs[12] = (jobs[12][0], jobs[0][1], jobs[12][2], jobs[12][3])
+            refs[0] = refs[0] + jobs[12][0].float().sum(0)
+        assert all(dev.colsum_batchable(j[0], j[3]) for j in jobs)
+        dev.colsum_batch(jobs)
+        torch.cuda.synchronize()
+        for i, (j, r) in enumerate(zip(jobs, refs)):
+            if n == 16 and i == 12:
+                continue
+            assert rel(j[1], r) < (2e-5 if dtype == torch.float32 else 2e-3), (n, i)
+    assert not dev.colsum_batchable(torch.empty(3, 30, dtype=dtype), 30)
+    with pytest.raises(RuntimeError):
+        dev.colsum_batch([(torch.zeros(3, 30, dtype=dtype).cuda(), torch.zeros(30).cuda(), 3, 30)])
