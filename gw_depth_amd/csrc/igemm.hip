@@ -802,8 +802,10 @@ template <int ROWB> __device__ __forceinline__ int wg_swz(int row) {
 // convolution (Ho == Hi, Wo == Wi >= 11): the source pixel of output pixel m under tap (kh, kw) is m + const, so a
 // lane's address advances by a constant per step and only the in-image test needs (oh, ow), kept by branch-free
 // conditional subtractions; 2 = 1x1 / stride 1 / no padding (every Linear): purely linear, always in range.
+// The body takes its workgroup index and count as arguments: igemm_wgrad_dma_kernel passes the hardware ids,
+// igemm_wgrad_group_kernel (several layers' weight gradients in one launch) the ids inside the layer's own block range.
 template <int BNW, int BKW, int WN, int WK, int STAGES, int FAST>
-__global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(const gwd_conv_desc d, float *__restrict__ dw, int m_per_block) {
+__device__ __forceinline__ void wgrad_dma_body(const gwd_conv_desc &d, float *__restrict__ dw, int m_per_block, int wg_id, int wg_count) {
     typedef __bf16 T;
     constexpr int RM = 32;
     constexpr int TN = BNW / WN / 32, TK = BKW / WK / 32;
@@ -821,7 +823,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(const gwd_conv_des
     const int wn = wave / WK, wk = wave % WK;
     // one XCD owns a contiguous run of (split, tile) pairs: all tiles of a reduction split re-read the same pixels
     const int k_tiles = (K + BKW - 1) / BKW, tiles = k_tiles * ((N + BNW - 1) / BNW);
-    const int band_id = xcd_band(blockIdx.x, gridDim.x);
+    const int band_id = xcd_band(wg_id, wg_count);
     const int tile = band_id % tiles;
     const int kb0 = (tile % k_tiles) * BKW, n0 = (tile / k_tiles) * BNW;
     const int m_begin = (band_id / tiles) * m_per_block;
@@ -993,6 +995,35 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(const gwd_conv_des
                 if (n < N) unsafeAtomicAdd(dw + (size_t)n * K + kcol, acc[i][j][r]);
             }
     }
+}
+
+template <int BNW, int BKW, int WN, int WK, int STAGES, int FAST>
+__global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(const gwd_conv_desc d, float *__restrict__ dw, int m_per_block) {
+    wgrad_dma_body<BNW, BKW, WN, WK, STAGES, FAST>(d, dw, m_per_block, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Weight gradients of up to WG_GROUP layers in ONE launch.  The step has ~230 weight gradients of small plain GEMMs
+// (every Linear / 1x1 layer of the transformers) whose best split count gives 16-400 workgroups for 10-60 us: alone
+// each leaves most of the 512 resident slots empty, and consecutive launches of one stream do not overlap.  The job
+// records travel by value in the kernel arguments; every job's block range starts at a multiple of 8 so that the
+// hardware's round-robin XCD assignment of the GLOBAL workgroup id is also the XCD of the id inside the job (xcd_band).
+constexpr int WG_GROUP = 16;
+struct WgradGroup {
+    gwd_conv_desc d[WG_GROUP];
+    float *dw[WG_GROUP];
+    int m_per_block[WG_GROUP], block0[WG_GROUP], blocks[WG_GROUP];
+    int n;
+};
+template <int BNW, int BKW, int WN, int WK, int STAGES, int FAST>
+__global__ __launch_bounds__(256) void igemm_wgrad_group_kernel(const WgradGroup g) {
+    int ji = 0;
+#pragma unroll 1
+    for (int k = 1; k < g.n; ++k)
+        if ((int)blockIdx.x >= g.block0[k]) ji = k;
+    const int id = (int)blockIdx.x - g.block0[ji];
+    if (id >= g.blocks[ji]) return;                       // padding up to the next multiple of 8 (whole workgroup: no barrier is skipped)
+    const gwd_conv_desc d = g.d[ji];                      // workgroup-uniform: lives in SGPRs
+    wgrad_dma_body<BNW, BKW, WN, WK, STAGES, FAST>(d, g.dw[ji], g.m_per_block[ji], id, g.blocks[ji]);
 }
 
 template <typename T>
@@ -1184,8 +1215,35 @@ static void wgrad_split(int M, int tiles, int rm, int &splits, int &m_per_block,
     splits = (M + m_per_block - 1) / m_per_block;
 }
 
+// gwd_conv_wgrad_batch: plain-GEMM weight gradients on the two hot tile shapes are collected here instead of being
+// launched one by one; flush() runs each non-empty group as one igemm_wgrad_group_kernel launch.
+struct WgradCollector {
+    WgradGroup g128, g64;
+    int total128 = 0, total64 = 0;
+    WgradCollector() { g128.n = g64.n = 0; }
+    bool take(int bn, int bk, int fast, const gwd_conv_desc &d, float *dw, int m_per_block, int blocks) {
+        if (fast != 2 || !((bn == 128 && bk == 128) || (bn == 64 && bk == 64))) return false;
+        WgradGroup &g = bn == 128 ? g128 : g64;
+        int &total = bn == 128 ? total128 : total64;
+        if (g.n >= WG_GROUP) return false;
+        const int i = g.n++;
+        g.d[i] = d;
+        g.dw[i] = dw;
+        g.m_per_block[i] = m_per_block;
+        g.block0[i] = total;
+        g.blocks[i] = blocks;
+        total += (blocks + 7) & ~7;
+        return true;
+    }
+    void flush(hipStream_t s) {
+        if (g128.n) igemm_wgrad_group_kernel<128, 128, 2, 2, 3, 2><<<total128, 256, 0, s>>>(g128);
+        if (g64.n) igemm_wgrad_group_kernel<64, 64, 2, 2, 4, 2><<<total64, 256, 0, s>>>(g64);
+        g128.n = g64.n = total128 = total64 = 0;
+    }
+};
+
 template <typename T>
-int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s) {
+int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s, WgradCollector *coll = nullptr) {
     constexpr int RM = Cfg<T>::BK;
     const int M = d->B * d->Ho * d->Wo, N = d->Cout, K = d->KH * d->KW * d->Cin;
     int splits, m_per_block;
@@ -1201,7 +1259,8 @@ int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s) {
         const double bal = (fast == 2 && wgrad_variant() != 9) ? 0.45e-6 * 1.3e12 / ((double)tiles * BN_ * BK_ * 4) : 0.0;  \
         wgrad_split(M, tiles, 32, splits, m_per_block, 256 * (per_cu > 4 ? 4 : per_cu), bal);                \
         dim3 grid((unsigned)tiles * splits);                                                                 \
-        if (fast == 2) igemm_wgrad_dma_kernel<BN_, BK_, WN_, WK_, ST_, 2><<<grid, 256, 0, s>>>(*d, dw, m_per_block);      \
+        if (coll && coll->take(BN_, BK_, fast, *d, dw, m_per_block, tiles * splits)) { /* runs at flush() */ }             \
+        else if (fast == 2) igemm_wgrad_dma_kernel<BN_, BK_, WN_, WK_, ST_, 2><<<grid, 256, 0, s>>>(*d, dw, m_per_block);      \
         else if (fast == 1) igemm_wgrad_dma_kernel<BN_, BK_, WN_, WK_, ST_, 1><<<grid, 256, 0, s>>>(*d, dw, m_per_block); \
         else igemm_wgrad_dma_kernel<BN_, BK_, WN_, WK_, ST_, 0><<<grid, 256, 0, s>>>(*d, dw, m_per_block);   \
     }
@@ -1263,6 +1322,27 @@ extern "C" int gwd_conv_wgrad(const gwd_conv_desc *d, float *dw, void *stream) {
     }
     return d->dtype == GWD_BF16 ? launch_wgrad<__bf16>(d, dw, (hipStream_t)stream)
                                 : launch_wgrad<float>(d, dw, (hipStream_t)stream);
+}
+
+extern "C" int gwd_conv_wgrad_batch(const gwd_conv_desc *descs, float *const *dws, int32_t n, void *stream) {
+    if (!descs || !dws || n <= 0) return -1;
+    for (int i = 0; i < n; ++i) {                         // validate everything before the first launch
+        const int rc = check_desc(descs + i);
+        if (rc) return rc;
+        if (!dws[i]) return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    WgradCollector coll;
+    for (int i = 0; i < n; ++i) {
+        const gwd_conv_desc *d = descs + i;
+        if (coll.g128.n == WG_GROUP || coll.g64.n == WG_GROUP) coll.flush(s);
+        if (gwd_thin_conv_wgrad(d, dws[i], s)) continue;
+        const int rc = d->dtype == GWD_BF16 ? launch_wgrad<__bf16>(d, dws[i], s, &coll) : launch_wgrad<float>(d, dws[i], s);
+        if (rc) return rc;
+    }
+    coll.flush(s);
+    GWD_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int gwd_weight_prep(const float *w, const float *row_scale, void *w_fwd, void *w_dgrad, int32_t N,

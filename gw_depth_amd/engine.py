@@ -242,7 +242,7 @@ class TrainStep:
             total, terms = self.losses(out, batch["depth"], batch["seg"], batch["targets"], packed=packed)
             self.zero_grad()
             self._begin_backward()
-            with ops.COLSUMS:                           # bias-gradient column sums batched 16 to a launch
+            with ops.COLSUMS, ops.WGRADS:               # bias / weight gradients of small layers run as grouped launches
                 total.backward()
             self._finish_backward()
         finally:
@@ -262,7 +262,7 @@ class TrainStep:
             out = self.model(NestedTensor(st["images"], st["pad_mask"]), taps=st.get("taps"))
             total, terms = self.losses(out, st["depth"], st["seg"], None, packed=st["packed"])
             self.flat_g.zero_()
-            with ops.COLSUMS:
+            with ops.COLSUMS, ops.WGRADS:
                 total.backward()
         finally:
             if weights is not None:

@@ -28,7 +28,7 @@ ENTRY_POINTS = [
     "gwd_tokattn_backward", "gwd_certain_sample", "gwd_lsap", "gwd_window_map",
     "gwd_inorm_gelu_forward", "gwd_inorm_gelu_backward", "gwd_weight_prep_batch",
     "gwd_point_sample_forward", "gwd_point_sample_backward", "gwd_act_backward_colsum", "gwd_resample_backward_sep",
-    "gwd_softmax_masked_forward", "gwd_softmax_scaled_backward", "gwd_query_workspace", "gwd_eval_accumulate", "gwd_colsum_batch",
+    "gwd_softmax_masked_forward", "gwd_softmax_scaled_backward", "gwd_query_workspace", "gwd_eval_accumulate", "gwd_colsum_batch", "gwd_conv_wgrad_batch",
 ]
 
 
@@ -121,6 +121,7 @@ class HipLibrary:
         L.gwd_weight_prep.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
         L.gwd_act_backward.argtypes = [vp, vp, vp, vp, i64, i32, i32, f32, i32, vp]
         L.gwd_colsum.argtypes = [vp, vp, i64, i32, i32, vp]
+        L.gwd_conv_wgrad_batch.argtypes = [ctypes.POINTER(ConvDesc), ctypes.POINTER(ctypes.c_void_p), i32, vp]
         L.gwd_colsum_batch.argtypes = [ctypes.POINTER(ColsumJob), i32, i32, vp]
         L.gwd_layernorm_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
         L.gwd_layernorm_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
@@ -204,6 +205,17 @@ class HipLibrary:
     def conv_wgrad(self, x, gy, dw, dims, **kw):
         d = self._desc(x, None, gy, dims, **kw)
         self._check(self.lib.gwd_conv_wgrad(ctypes.byref(d), _ptr(dw), self._stream(x, gy, dw)), "gwd_conv_wgrad")
+
+    def conv_wgrad_batch(self, jobs):
+        """jobs: tuples (x, gy, dw, dims, kw) as for conv_wgrad; one library call, grouped launches (gwd_conv_wgrad_batch)."""
+        descs = (ConvDesc * len(jobs))()
+        dws = (ctypes.c_void_p * len(jobs))()
+        ts = []
+        for i, (x, gy, dw, dims, kw) in enumerate(jobs):
+            descs[i] = self._desc(x, None, gy, dims, **kw)
+            dws[i] = _ptr(dw)
+            ts += [x, gy, dw]
+        self._check(self.lib.gwd_conv_wgrad_batch(descs, dws, len(jobs), self._stream(*ts)), "gwd_conv_wgrad_batch")
 
     def weight_prep(self, w, row_scale, w_fwd, w_dgrad, N, taps, C, dtype):
         self._check(self.lib.gwd_weight_prep(_ptr(w), _ptr(row_scale), _ptr(w_fwd), _ptr(w_dgrad), N, taps, C, dtype,

@@ -148,6 +148,50 @@ class ColsumQueue:
 COLSUMS = ColsumQueue()
 
 
+class WgradQueue:
+    """Weight gradients that accumulate into the flat gradient buffer, handed to the library WGRAD_BATCH at a time
+    (gwd_conv_wgrad_batch runs the small plain-GEMM ones of a batch as one grouped launch).  Same life cycle as
+    ColsumQueue: open around backward, flushed at its end; a queued job keeps its activation and gradient alive."""
+    BATCH = 32
+
+    def __init__(self):
+        self.jobs, self.active = [], False
+
+    def add(self, x, dv, dw, dims, kw, hook=None):
+        if not self.active:
+            _lib().conv_wgrad(x, dv, dw, dims, **kw)
+            if hook is not None:
+                hook()
+            return
+        self.jobs.append((x, dv, dw, dims, kw, hook))
+        if len(self.jobs) == self.BATCH:
+            self.flush()
+
+    def flush(self):
+        if not self.jobs:
+            return
+        jobs, self.jobs = self.jobs, []
+        _lib().conv_wgrad_batch([j[:5] for j in jobs])
+        for j in jobs:
+            if j[5] is not None:
+                j[5]()
+
+    def __enter__(self):
+        self.active = True
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            if exc[0] is None:
+                self.flush()
+        finally:
+            self.jobs, self.active = [], False
+        return False
+
+
+WGRADS = WgradQueue()
+
+
 _ACTIVE_WEIGHTS = None
 
 
@@ -250,9 +294,7 @@ class _ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if w_sink is not None and row_scale is None:
                 # the kernel ACCUMULATES (fp32 atomics): add straight into the flat gradient buffer, no temporary
-                lib.conv_wgrad(x, dv, w_sink[0], dims, stride=stride, pad=pad, gather=gather, virt=vv)
-                if w_sink[1] is not None:
-                    w_sink[1]()
+                WGRADS.add(x, dv, w_sink[0], dims, dict(stride=stride, pad=pad, gather=gather, virt=vv), w_sink[1])
             else:
                 gw = torch.zeros(w.shape, dtype=torch.float32, device=w.device)
                 lib.conv_wgrad(x, dv, gw, dims, stride=stride, pad=pad, gather=gather, virt=vv)

@@ -77,6 +77,11 @@ int gwd_conv_forward(const gwd_conv_desc *d, void *stream);
  * d->x = layer input, d->y = gradient w.r.t. the layer output (already multiplied by act'), gather
  * as in the forward.  Replaces aten::convolution_backward (weight) / addmm weight grads.          */
 int gwd_conv_wgrad(const gwd_conv_desc *d, float *dw, void *stream);
+/* n independent gwd_conv_wgrad calls handed over together (descs[i] -> dws[i], each accumulated as gwd_conv_wgrad does;
+ * two jobs may name the same dw).  Results are those of n single calls; the library is free to run jobs of one
+ * kernel shape as ONE launch - the weight gradients of the ~230 Linear / 1x1 layers of a train step are 10-60 us
+ * launches of 16-400 workgroups that cannot overlap inside one stream.  Nothing in descs / dws must outlive the call. */
+int gwd_conv_wgrad_batch(const gwd_conv_desc *descs, float *const *dws, int32_t n, void *stream);
 
 /* w (fp32 [N][taps][C]), optionally multiplied by row_scale[N] (a frozen BatchNorm folded into the
  * convolution) -> w_fwd (dtype, same layout; may be NULL) and w_dgrad (dtype, [C][taps][N]; may be

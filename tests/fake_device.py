@@ -169,6 +169,10 @@ class FakeDevice:
                 for k in (0, 1):
                     confusion[t * 2 + k] += int(((seg_gt == t) & (c == k)).sum())
 
+    def conv_wgrad_batch(self, jobs):
+        for x, gy, dw, dims, kw in jobs:
+            self.conv_wgrad(x, gy, dw, dims, **kw)
+
     def colsum_batch(self, jobs):
         for g, out, rows, C in jobs:
             self.colsum(g, out, rows, C)

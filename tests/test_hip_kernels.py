@@ -551,3 +551,32 @@ def test_colsum_batch(dev, dtype):
     assert not dev.colsum_batchable(torch.empty(3, 30, dtype=dtype), 30)
     with pytest.raises(RuntimeError):
         dev.colsum_batch([(torch.zeros(3, 30, dtype=dtype).cuda(), torch.zeros(30).cuda(), 3, 30)])
+
+
+def test_conv_wgrad_batch_equals_single_calls(dev):
+    """gwd_conv_wgrad_batch: 40 mixed jobs (plain GEMMs on both grouped tile shapes - more than one group's worth -, a
+    3x3 convolution, a narrow layer, a shared gradient buffer) give exactly what 40 gwd_conv_wgrad calls give up to the
+    order of the fp32 atomics."""
+    dt = torch.bfloat16
+    specs = [(2400, 1, 1, 256, 256, 1), (800, 1, 1, 256, 2048, 1), (300, 1, 1, 2048, 256, 1), (19200, 1, 1, 64, 128, 1),
+             (2, 12, 16, 64, 64, 3), (4800, 1, 1, 128, 24, 1), (153600, 1, 1, 64, 64, 1), (1176, 1, 1, 64, 192, 1)]
+    jobs, refs = [], []
+    for i in range(40):
+        B, H, W, Ci, Co, K = specs[i % len(specs)]
+        x = rnd(B, H, W, Ci, dtype=dt, seed=i).cuda()
+        gy = rnd(B, H, W, Co, dtype=dt, seed=50 + i).cuda()
+        dims = (B, H, W, Ci, H, W, Co, K, K)
+        kw = dict(stride=1, pad=K // 2)
+        dw = rnd(Co, K, K, Ci, seed=200 + i).cuda()
+        ref = dw.clone()
+        dev.conv_wgrad(x, gy, ref, dims, **kw)
+        jobs.append((x, gy, dw, dims, kw))
+        refs.append(ref)
+    jobs[8] = jobs[8][:2] + (jobs[0][2],) + jobs[8][3:]          # job 8 (same shape as job 0) accumulates into job 0's buffer
+    dev.conv_wgrad(jobs[8][0], jobs[8][1], refs[0], jobs[8][3], **jobs[8][4])
+    dev.conv_wgrad_batch(jobs)
+    torch.cuda.synchronize()
+    for i, (j, r) in enumerate(zip(jobs, refs)):
+        if i == 8:
+            continue
+        assert rel(j[2], r) < 1e-5, i
