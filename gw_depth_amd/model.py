@@ -343,7 +343,7 @@ class WindowAttnBase(nn.Module):
     def bias_dense(self):
         """(heads, 49, 49) fp32 relative-position bias (multiscale_transformerr.py:313-315)."""
         n = WS * WS
-        return self.relative_position_bias_table[self.relative_position_index.view(-1)].view(n, n, -1).permute(2, 0, 1)
+        return ops.table_gather(self.relative_position_bias_table, self.relative_position_index.view(-1)).view(n, n, -1).permute(2, 0, 1)
 
 
 class WindowAttention(WindowAttnBase):
