@@ -777,7 +777,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const gwd_conv_desc d,
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * (BNW / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (n < N) unsafeAtomicAdd(dw + (size_t)n * K + k, acc[i][j][r]);
+                if (n < N) unsafeAtomicAdd(dw + (size_t)n * K + k, d.scale ? acc[i][j][r] * d.scale[n] : acc[i][j][r]);
             }
     }
 }
@@ -992,7 +992,7 @@ __device__ __forceinline__ void wgrad_dma_body(const gwd_conv_desc &d, float *__
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * (BNW / WN) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (n < N) unsafeAtomicAdd(dw + (size_t)n * K + kcol, acc[i][j][r]);
+                if (n < N) unsafeAtomicAdd(dw + (size_t)n * K + kcol, d.scale ? acc[i][j][r] * d.scale[n] : acc[i][j][r]);
             }
     }
 }

@@ -292,14 +292,13 @@ class _ConvFn(torch.autograd.Function):
                 lib.conv_forward(dv, wt, gx, (B, Ho, Wo, Cout, Hi, Wi, Cin, KH, KW), stride=stride, pad=pad,
                                  gather=GATHER_TRANSPOSED)
         if ctx.needs_input_grad[1]:
-            if w_sink is not None and row_scale is None:
+            # row_scale (folded FrozenBN: the layer ran with w * scale) multiplies the gradient inside the kernel's epilogue
+            if w_sink is not None:
                 # the kernel ACCUMULATES (fp32 atomics): add straight into the flat gradient buffer, no temporary
-                WGRADS.add(x, dv, w_sink[0], dims, dict(stride=stride, pad=pad, gather=gather, virt=vv), w_sink[1])
+                WGRADS.add(x, dv, w_sink[0], dims, dict(stride=stride, pad=pad, gather=gather, virt=vv, scale=row_scale), w_sink[1])
             else:
                 gw = torch.zeros(w.shape, dtype=torch.float32, device=w.device)
-                lib.conv_wgrad(x, dv, gw, dims, stride=stride, pad=pad, gather=gather, virt=vv)
-                if row_scale is not None:
-                    gw.mul_(row_scale.view(-1, 1, 1, 1))
+                lib.conv_wgrad(x, dv, gw, dims, stride=stride, pad=pad, gather=gather, virt=vv, scale=row_scale)
         if has_bias and ctx.needs_input_grad[2] and not bias_done:
             if b_sink is not None:
                 COLSUMS.add(dv, b_sink[0], rows, Cout, b_sink[1])

@@ -75,7 +75,9 @@ int gwd_conv_forward(const gwd_conv_desc *d, void *stream);
 
 /* Weight gradient dw[Cout][KH][KW][Cin] (fp32, ACCUMULATED into dw with atomics; caller zeroes it):
  * d->x = layer input, d->y = gradient w.r.t. the layer output (already multiplied by act'), gather
- * as in the forward.  Replaces aten::convolution_backward (weight) / addmm weight grads.          */
+ * as in the forward.  d->scale (may be NULL): per-Cout multiplier of the result, dw[n] += scale[n] * (...) - the
+ * layer computed with w * scale (folded FrozenBatchNorm, src/models/backbone.py:45-55), so this IS the gradient of
+ * the unscaled parameter.  Replaces aten::convolution_backward (weight) / addmm weight grads.      */
 int gwd_conv_wgrad(const gwd_conv_desc *d, float *dw, void *stream);
 /* n independent gwd_conv_wgrad calls handed over together (descs[i] -> dws[i], each accumulated as gwd_conv_wgrad does;
  * two jobs may name the same dw).  Results are those of n single calls; the library is free to run jobs of one

@@ -102,13 +102,14 @@ class FakeDevice:
             z.copy_(v.reshape(z.shape))
         y.copy_((_act(v, act) * act_scale).reshape(y.shape))
 
-    def conv_wgrad(self, x, gy, dw, dims, stride=1, pad=0, gather=hip.GATHER_CONV, virt=(0, 0), **_):
+    def conv_wgrad(self, x, gy, dw, dims, stride=1, pad=0, gather=hip.GATHER_CONV, virt=(0, 0), scale=None, **_):
         B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW = dims
         w0 = torch.zeros(Cout, KH, KW, Cin, requires_grad=True)
         with torch.enable_grad():
             out = self._conv_core(x, w0, dims, stride, pad, gather, virt)
             (g,) = torch.autograd.grad(out, w0, gy.reshape(out.shape).float())
-        dw.add_(g.reshape(dw.shape))
+        g = g.reshape(dw.shape)
+        dw.add_(g if scale is None else g * scale.view(-1, 1, 1, 1))
 
     def weight_prep(self, w, row_scale, w_fwd, w_dgrad, N, taps, C, dtype):
         v = w.reshape(N, taps, C).float()

@@ -580,3 +580,23 @@ def test_conv_wgrad_batch_equals_single_calls(dev):
         if i == 8:
             continue
         assert rel(j[2], r) < 1e-5, i
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("spec", [(2, 12, 16, 64, 64, 3, 1), (2, 12, 16, 256, 128, 1, 1), (2, 12, 16, 128, 128, 3, 2), (300, 1, 1, 72, 40, 1, 1)])
+def test_conv_wgrad_row_scale(dev, dtype, spec):
+    """d->scale in gwd_conv_wgrad: dw[n] += scale[n] * grad[n] (gradient of the unscaled weight of a BN-folded layer),
+    single call and batched call, DMA and register-staged kernels."""
+    B, H, W, Ci, Co, K, stride = spec
+    pad = K // 2
+    Ho, Wo = conv_out(H, K, stride, pad), conv_out(W, K, stride, pad)
+    x = rnd(B, H, W, Ci, dtype=dtype, seed=1)
+    gy = rnd(B, Ho, Wo, Co, dtype=dtype, seed=2)
+    sc = rnd(Co, seed=3) + 1.5
+    dims = (B, H, W, Ci, Ho, Wo, Co, K, K)
+    ref = rnd(Co, K, K, Ci, seed=4)
+    dw1, dw2 = ref.clone().cuda(), ref.clone().cuda()
+    FakeDevice().conv_wgrad(x, gy, ref, dims, stride=stride, pad=pad, scale=sc)
+    dev.conv_wgrad(x.cuda(), gy.cuda(), dw1, dims, stride=stride, pad=pad, scale=sc.cuda())
+    dev.conv_wgrad_batch([(x.cuda(), gy.cuda(), dw2, dims, dict(stride=stride, pad=pad, scale=sc.cuda()))])
+    assert rel(dw1, ref) < TOL[dtype] and rel(dw2, ref) < TOL[dtype]
