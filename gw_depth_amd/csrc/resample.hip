@@ -93,6 +93,46 @@ template <int VB> struct RsRaw;
 template <> struct RsRaw<16> { typedef uint4 type; };
 template <> struct RsRaw<8> { typedef uint2 type; };
 
+// Nearest-mode backward, 16/8-byte channel vectors: the footprint of source pixel (sy, sx) is the set of outputs whose
+// legacy-nearest source is (sy, sx) - at most ceil(Ho/Hs)+1 candidates per axis, tested with the forward's own rule.
+// (gradient of the virtually up-sampled convolution inputs of the decoder: 314 MB per call at full resolution)
+template <typename T, int VB>
+__global__ void resample_nearest_bwd_vec_kernel(const T *__restrict__ gy, T *__restrict__ gx, int B, int Hs, int Ws, int Ho, int Wo, int C) {
+    constexpr int VEC = VB / (int)sizeof(T);
+    typedef typename RsRaw<VB>::type Raw;
+    const int CV = C / VEC;
+    const int64_t total = (int64_t)B * Hs * Ws * CV;
+    const float sh = (float)Hs / (float)Ho, sw = (float)Ws / (float)Wo;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        int64_t r = i / CV;
+        const int sx = (int)(r % Ws);
+        r /= Ws;
+        const int sy = (int)(r % Hs);
+        const int b = (int)(r / Hs);
+        const int ylo = max(0, (int)floorf(sy / sh) - 1), yhi = min(Ho - 1, (int)ceilf((sy + 1) / sh) + 1);
+        const int xlo = max(0, (int)floorf(sx / sw) - 1), xhi = min(Wo - 1, (int)ceilf((sx + 1) / sw) + 1);
+        const T *gb = gy + (size_t)b * Ho * Wo * C + cv * VEC;
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+        for (int oy = ylo; oy <= yhi; ++oy) {
+            if (tap_weight(oy, sy, Hs, sh, MODE_NEAREST) == 0.f) continue;
+            for (int ox = xlo; ox <= xhi; ++ox) {
+                if (tap_weight(ox, sx, Ws, sw, MODE_NEAREST) == 0.f) continue;
+                const Raw raw = *(const Raw *)(gb + ((size_t)oy * Wo + ox) * C);
+                const T *p = (const T *)&raw;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] += to_f32(p[e]);
+            }
+        }
+        alignas(16) T out[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) out[e] = from_f32<T>(acc[e]);
+        *(Raw *)(gx + (size_t)i * VEC) = *(const Raw *)out;
+    }
+}
+
 template <typename T, int VB>
 __global__ void resample_fwd_vec_kernel(const T *__restrict__ x, T *__restrict__ y, int B, int Hs, int Ws, int Ho, int Wo, int C,
                                         int mode) {
@@ -340,6 +380,18 @@ extern "C" int gwd_resample_backward(const void *gy, void *gx, int32_t B, int32_
                                      int32_t C, int32_t mode, int32_t dtype, void *stream) {
     if (!gy || !gx || B <= 0 || Hs <= 0 || Ws <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || mode < 0 || mode > 1) return -1;
     const int64_t total = (int64_t)B * Hs * Ws * C;
+    if (mode == MODE_NEAREST && dtype == GWD_BF16 && C % 4 == 0) {
+        hipStream_t s = (hipStream_t)stream;
+        if (C % 8 == 0) resample_nearest_bwd_vec_kernel<__bf16, 16><<<flat_grid(total / 8), 256, 0, s>>>((const __bf16 *)gy, (__bf16 *)gx, B, Hs, Ws, Ho, Wo, C);
+        else resample_nearest_bwd_vec_kernel<__bf16, 8><<<flat_grid(total / 4), 256, 0, s>>>((const __bf16 *)gy, (__bf16 *)gx, B, Hs, Ws, Ho, Wo, C);
+        GWD_CHECK_LAUNCH();
+        return 0;
+    }
+    if (mode == MODE_NEAREST && dtype == GWD_F32 && C % 4 == 0) {
+        resample_nearest_bwd_vec_kernel<float, 16><<<flat_grid(total / 4), 256, 0, (hipStream_t)stream>>>((const float *)gy, (float *)gx, B, Hs, Ws, Ho, Wo, C);
+        GWD_CHECK_LAUNCH();
+        return 0;
+    }
     if (dtype == GWD_BF16) resample_bwd_kernel<__bf16><<<flat_grid(total), 256, 0, (hipStream_t)stream>>>((const __bf16 *)gy, (__bf16 *)gx, B, Hs, Ws, Ho, Wo, C, mode);
     else if (dtype == GWD_F32) resample_bwd_kernel<float><<<flat_grid(total), 256, 0, (hipStream_t)stream>>>((const float *)gy, (float *)gx, B, Hs, Ws, Ho, Wo, C, mode);
     else return -2;
