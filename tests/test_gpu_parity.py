@@ -206,3 +206,77 @@ def test_graph_mode_reports_non_finite_loss_one_step_late():
     eager.flat_p[:64].fill_(float("nan"))
     with pytest.raises(FloatingPointError):      # eager mode: immediately, as the reference
         eager(b)
+
+
+def test_evaluate_end_to_end_matches_oracle():
+    """§8f-1 end to end on the GPU: evaluate() (eval-mode HIP forward, fp32, batches of 2 with ragged sizes, metrics by
+    gwd_eval_accumulate) against the oracle forward + oracle/eval_ref.py on the same weights and inputs - depth RMSE and
+    the other eight measures within 1e-3 relative (BASELINE's bar), confusion-derived scores within 0.05 points (a
+    handful of pixels whose two logits tie to 1e-6 may flip)."""
+    import numpy as np
+    from gw_depth_amd.evaluate import METRIC_NAMES, evaluate
+    from gw_depth_amd.model import NestedTensor
+    from gw_depth_amd.synth import synth_batch
+    from oracle import eval_ref
+    from oracle import gwdepth_ref as R
+    cfg, model, crits = build(device="cuda")
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    batches = [synth_batch(2, 96, 128, seed=61, n_lines=[3, 4], sizes=[(96, 128), (80, 104)]),
+               synth_batch(2, 96, 128, seed=62, n_lines=[2, 5])]
+    per_image, conf = [], np.zeros((2, 2))
+    loader = []
+    for b in batches:
+        with torch.no_grad():
+            ref = R.forward(sd, b["images"], b["pad_mask"], R.Cfg(dropout=0.0, log_depth_error=True), training=False)
+        g = b["depth"].clone()
+        s = b["seg"].clone()
+        pad = b["pad_mask"].unsqueeze(1)
+        g[pad] = 0.0                                                      # padding is not evaluated
+        s[pad] = 255
+        rec, _ = eval_ref.evaluate_dense(ref["pred_depth"][-1].numpy(), g.numpy(), ref["pred_seg"].numpy(), s.numpy())
+        per_image.append(rec)
+        for i in range(g.shape[0]):
+            conf += eval_ref.confusion_matrix(s[i, 0].numpy(), ref["pred_seg"][i].argmax(0).numpy())
+        loader.append((NestedTensor(b["images"], b["pad_mask"]), NestedTensor(b["depth"], b["pad_mask"]),
+                       NestedTensor(b["seg"], b["pad_mask"]), b["targets"], ["synthetic\n"]))
+    want = eval_ref.seg_scores(conf)
+    want.update({k: float(v) for k, v in zip(METRIC_NAMES, np.concatenate(per_image).mean(0))})
+    args = type("A", (), {"with_line": False, "with_dense": True, "min_depth_eval": 1e-3, "max_depth_eval": 10.0})()
+    stats = evaluate(model, crits, None, loader, None, "cuda", None, args)
+    for k in METRIC_NAMES:
+        assert abs(stats[k] - want[k]) <= 1e-3 * max(abs(want[k]), 1e-6), (k, stats[k], want[k])
+    for k in ("Background", "Glass", "Pixel accuracy", "Mean accuracy", "Mean IU"):
+        assert abs(stats[k] - want[k]) <= 0.05, (k, stats[k], want[k])
+
+
+def test_flat_adamw_on_device_matches_torch_adamw():
+    """§8f-3 on the GPU: FlatAdamW.step (fused device clip + AdamW) under a StepLR == torch.optim.AdamW +
+    clip_grad_norm_ on the same gradients, two epochs with an LR drop in between."""
+    from gw_depth_amd.checkpoint import FlatAdamW
+    from gw_depth_amd.engine import TrainStep
+    cfg, model, crits = build(device="cuda")
+    step = TrainStep(model, crits, cfg, compute_dtype=torch.float32)
+    opt = FlatAdamW(step)
+    sched = torch.optim.lr_scheduler.StepLR(opt, 1)
+    named = [(n, torch.nn.Parameter(p.detach().clone())) for n, p in model.named_parameters() if p.requires_grad]
+    ref = torch.optim.AdamW([{"params": [p for n, p in named if "backbone" not in n]},
+                             {"params": [p for n, p in named if "backbone" in n], "lr": cfg.lr_backbone}],
+                            lr=cfg.lr, weight_decay=cfg.weight_decay)
+    ref_sched = torch.optim.lr_scheduler.StepLR(ref, 1)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for epoch in range(2):
+        step.flat_g.zero_()
+        for n, p in named:
+            g = torch.randn(p.shape, generator=gen, device="cuda") * 1e-3
+            p.grad = g
+            o = step.offsets[n]
+            step.flat_g[o:o + p.numel()].copy_(g.reshape(-1))
+        torch.nn.utils.clip_grad_norm_([p for _, p in named], cfg.clip_max_norm)
+        ref.step()
+        ref_sched.step()
+        opt.step()
+        sched.step()
+    torch.cuda.synchronize()
+    assert opt.lrs() == tuple(g["lr"] for g in ref.param_groups)
+    worst = max(float((model.get_parameter(n).detach() - p.detach()).abs().max() / (p.detach().abs().max() + 1e-12)) for n, p in named)
+    assert worst < 1e-6, worst
