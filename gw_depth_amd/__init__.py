@@ -9,7 +9,7 @@ from .config import Config
 def build_model(args):
     """Drop-in for the reference's models.build_model (glassrgbd.py:509-579)."""
     import torch
-    from .criteria import HungarianMatcherLine, PostProcessLine, SegLoss, SetCriterion, SilogLoss
+    from .criteria import HungarianMatcherLine, PlaneLoss, PostProcessLine, SegLoss, SetCriterion, SilogLoss
     from .model import GlassRGBD
     cfg = Config.from_args(args)
     model = GlassRGBD(cfg)
@@ -24,6 +24,5 @@ def build_model(args):
         criterion.to(device)
     criterion_depth = SilogLoss(cfg.variance_focus, cfg.log_depth_error)
     criterion_seg = SegLoss()
-    if cfg.with_plane_norm_loss:
-        raise NotImplementedError("--with_plane_norm_loss (PlaneLoss) is outside the accelerated path (SURVEY.md §8f)")
-    return model, [criterion, criterion_depth, criterion_seg, None], {"line": PostProcessLine()}
+    criterion_plane = PlaneLoss(28, line_score_thresh=0.6, min_plane_area=100) if cfg.with_plane_norm_loss else None   # glassrgbd.py:573-577
+    return model, [criterion, criterion_depth, criterion_seg, criterion_plane], {"line": PostProcessLine()}

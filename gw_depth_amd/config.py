@@ -38,6 +38,7 @@ class Config:
     with_center = True
     with_dense = True
     with_plane_norm_loss = False
+    plane_norm_loss_coef = 50.0          # src/args.py:81
 
     def __init__(self, **kw):
         for k, v in kw.items():

@@ -176,6 +176,32 @@ class SilogLoss(nn.Module):
         return ops.silog_loss(depth_est, depth_gt_full, weight, self.variance_focus, self.log_depth_error)
 
 
+class PlaneLoss(nn.Module):
+    """criterion_plane(depth_pred, depth_gt, line_pred, line_score, valid_mask): glassrgbd.py:385-450, one image per call.
+    The reference selects `top_num` lines with a host sync and rasterises every triangle on the CPU (matplotlib); here the
+    count stays a device scalar, the num_ref best lines are always gathered and the kernel ignores those beyond it."""
+
+    def __init__(self, num_ref=28, line_score_thresh=0.6, min_plane_area=100):
+        super().__init__()
+        self.num_ref, self.line_score_thresh, self.min_plane_area = num_ref, line_score_thresh, min_plane_area
+
+    def forward(self, depth_pred, depth_gt, line_pred, line_score, valid_mask):
+        if line_score.shape[0] != 1:
+            raise AssertionError("one image each iter")                                   # :397
+        H, W = depth_pred.shape[-2:]
+        score, logit = line_score.detach().float(), line_score.detach().float()[0, :, 0]
+        keep = torch.softmax(score, dim=-1)[0, :, 0] > self.line_score_thresh             # :399-400
+        n_planes = keep.sum().clamp(max=self.num_ref).to(torch.int32).reshape(1)          # top_num, on the device
+        k = min(self.num_ref, logit.shape[0])
+        ids = torch.topk(logit, k)[1]                                                     # :402 (raw class-0 logit)
+        scale = torch.tensor([W, H, W, H, W, H], dtype=torch.float32, device=line_pred.device)
+        lines = torch.round(line_pred.detach().float()[0][ids] * scale)                   # :412-414
+        hi = torch.tensor([W - 1, H - 1] * 3, dtype=torch.float32, device=lines.device)
+        tri = torch.minimum(lines.clamp(min=0), hi).to(torch.int64).contiguous()          # :415-417, (k, 6)
+        valid = valid_mask.reshape(H, W).to(torch.uint8).contiguous()
+        return ops.plane_loss(depth_pred.float(), valid, tri, n_planes, self.min_plane_area)
+
+
 class SegLoss(nn.Module):
     """criterion_seg(logits (B,2,H,W), target (B,H,W) int64): glassrgbd.py:376-383."""
 

@@ -77,6 +77,7 @@ extern "C" int gwd_adamw_step(float *p, const float *g, float *m, float *v, void
 extern "C" int gwd_version(void) { return GWD_VERSION; }
 
 int64_t gwd_eval_workspace_bytes(int64_t B, int64_t HW);    // evalmetrics.hip
+int64_t gwd_plane_workspace_bytes(int64_t P, int64_t HW);   // planeloss.hip
 
 extern "C" int64_t gwd_query_workspace(int32_t op, const int64_t *dims, int32_t ndims) {
     if (!dims) return -1;
@@ -84,6 +85,7 @@ extern "C" int64_t gwd_query_workspace(int32_t op, const int64_t *dims, int32_t 
         case GWD_WS_INORM_GELU: return ndims == 3 ? dims[0] * dims[1] * dims[2] * 2 * (int64_t)sizeof(float) : -1;
         case GWD_WS_RESAMPLE_BWD: return ndims == 4 ? dims[0] * dims[1] * dims[2] * dims[3] * (int64_t)sizeof(float) : -1;
         case GWD_WS_EVAL: return ndims == 2 ? gwd_eval_workspace_bytes(dims[0], dims[1]) : -1;
+        case GWD_WS_PLANE: return ndims == 2 ? gwd_plane_workspace_bytes(dims[0], dims[1]) : -1;
         default: return -1;
     }
 }

@@ -35,7 +35,7 @@ class TrainStep:
     def __init__(self, model, criterions, cfg, compute_dtype=torch.float32, bucket_mb=32.0, process_group=None,
                  check_finite=True, data_parallel=True, graph=False):
         self.model, self.cfg = model, cfg
-        self.criterion, self.criterion_depth, self.criterion_seg, _ = criterions
+        self.criterion, self.criterion_depth, self.criterion_seg, self.criterion_plane = criterions
         self.compute_dtype = compute_dtype
         model.compute_dtype = compute_dtype
         self.check_finite = check_finite
@@ -194,6 +194,13 @@ class TrainStep:
             terms["loss_depth_" + names[i]] = ld
             parts.append(ld)
             coef.append(1.0)
+        if self.criterion_plane is not None:
+            # --with_plane_norm_loss, one image per step (engine_glassrgbd.py:85-86).  The reference LOGS 50 x this loss
+            # (:133-135) but never adds it to `losses` (:109-115), so it is a reported term only here as well - no gradient.
+            with torch.no_grad():
+                mask = (depth_gt >= 0.2) & (depth_gt < 10.0)
+                lp = self.criterion_plane(out["pred_depth"][-1], depth_gt, out["pred_lines"], out["pred_logits"], mask)
+            terms["loss_plane"] = lp * float(cfg.plane_norm_loss_coef)
         ls = self.criterion_seg(out["pred_seg"], seg_gt.reshape(seg_gt.shape[0], *seg_gt.shape[-2:]), cfg.seg_loss_weight)
         terms["loss_seg"] = ls
         parts.append(ls)

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libgwdepth_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3, 4
-WS_INORM_GELU, WS_RESAMPLE_BWD, WS_EVAL = 0, 1, 2          # gwd_query_workspace ops
+WS_INORM_GELU, WS_RESAMPLE_BWD, WS_EVAL, WS_PLANE = 0, 1, 2, 3          # gwd_query_workspace ops
 GATHER_CONV, GATHER_TRANSPOSED, GATHER_UPSAMPLED = 0, 1, 2
 RESAMPLE_BILINEAR_AC, RESAMPLE_NEAREST = 0, 1
 
@@ -29,6 +29,7 @@ ENTRY_POINTS = [
     "gwd_inorm_gelu_forward", "gwd_inorm_gelu_backward", "gwd_weight_prep_batch",
     "gwd_point_sample_forward", "gwd_point_sample_backward", "gwd_act_backward_colsum", "gwd_resample_backward_sep",
     "gwd_softmax_masked_forward", "gwd_softmax_scaled_backward", "gwd_query_workspace", "gwd_eval_accumulate", "gwd_colsum_batch", "gwd_conv_wgrad_batch",
+    "gwd_plane_loss_forward", "gwd_plane_loss_backward",
 ]
 
 
@@ -122,6 +123,8 @@ class HipLibrary:
         L.gwd_act_backward.argtypes = [vp, vp, vp, vp, i64, i32, i32, f32, i32, vp]
         L.gwd_colsum.argtypes = [vp, vp, i64, i32, i32, vp]
         L.gwd_conv_wgrad_batch.argtypes = [ctypes.POINTER(ConvDesc), ctypes.POINTER(ctypes.c_void_p), i32, vp]
+        L.gwd_plane_loss_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp]
+        L.gwd_plane_loss_backward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp]
         L.gwd_colsum_batch.argtypes = [ctypes.POINTER(ColsumJob), i32, i32, vp]
         L.gwd_layernorm_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
         L.gwd_layernorm_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
@@ -286,6 +289,16 @@ class HipLibrary:
             _ptr(workspace), _ptr(measures), _ptr(running), _ptr(confusion), B, HW, float(dmin), float(dmax),
             dtype_code(pred) if pred is not None else F32, dtype_code(seg) if seg is not None else F32,
             self._stream(pred, gt, seg, seg_gt, workspace, measures, running, confusion)), "gwd_eval_accumulate")
+
+    def plane_loss_forward(self, depth, valid, tri, n_planes, P, H, W, min_area, workspace, stats, loss):
+        self._check(self.lib.gwd_plane_loss_forward(_ptr(depth), _ptr(valid), _ptr(tri), _ptr(n_planes), P, H, W, min_area,
+                                                    _ptr(workspace), _ptr(stats), _ptr(loss), dtype_code(depth),
+                                                    self._stream(depth, valid, tri, n_planes, workspace, stats, loss)), "gwd_plane_loss_forward")
+
+    def plane_loss_backward(self, depth, valid, tri, n_planes, P, H, W, stats, gloss, gdepth):
+        self._check(self.lib.gwd_plane_loss_backward(_ptr(depth), _ptr(valid), _ptr(tri), _ptr(n_planes), P, H, W, _ptr(stats),
+                                                     _ptr(gloss), _ptr(gdepth), dtype_code(depth),
+                                                     self._stream(depth, valid, tri, n_planes, stats, gloss, gdepth)), "gwd_plane_loss_backward")
 
     def silog_sums(self, pred, gt, sums, B, h, w, H, W, log_err):
         self._check(self.lib.gwd_silog_sums(_ptr(pred), _ptr(gt), _ptr(sums), B, h, w, H, W, int(log_err),

@@ -808,6 +808,36 @@ class _InormGeluFn(torch.autograd.Function):
         return gy, du, None
 
 
+class _PlaneLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, valid, tri, n_planes, min_area):
+        lib = _lib()
+        H, W = depth.shape[-2:]
+        P = tri.shape[0]
+        d = depth.reshape(H, W).contiguous()
+        stats = torch.empty(4 * P + 1, dtype=torch.float64, device=d.device)
+        loss = torch.empty(1, dtype=torch.float32, device=d.device)
+        ws = torch.empty(lib.workspace_bytes(hip.WS_PLANE, P, H * W), dtype=torch.uint8, device=d.device)
+        lib.plane_loss_forward(d, valid, tri, n_planes, P, H, W, int(min_area), ws, stats, loss)
+        ctx.save_for_backward(d, valid, tri, n_planes, stats)
+        ctx.shape = depth.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        d, valid, tri, n_planes, stats = ctx.saved_tensors
+        H, W = d.shape
+        gd = torch.empty_like(d)
+        _lib().plane_loss_backward(d, valid, tri, n_planes, tri.shape[0], H, W, stats, g.reshape(1).float().contiguous(), gd)
+        return gd.view(ctx.shape), None, None, None, None
+
+
+def plane_loss(depth, valid, tri, n_planes, min_area):
+    """PlaneLoss of one image (glassrgbd.py:385-450): depth (1,1,H,W), valid (H,W) uint8, tri (P,6) int64 rounded / clamped
+    vertices, n_planes device int32 (how many of the P triangles count).  Returns the scalar loss; gradient to depth."""
+    return _PlaneLossFn.apply(depth, valid, tri, n_planes, int(min_area))
+
+
 def inorm_gelu_residual(a, u, eps=1e-5):
     """a + gelu(instance_norm(u)): statistics over every dim but the first (image) and last (channel)."""
     return _InormGeluFn.apply(a, u, eps)

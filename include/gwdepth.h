@@ -59,8 +59,9 @@ const char *gwd_arch(void);
  *   GWD_WS_INORM_GELU      dims = {B, S, C}        -> `part` of gwd_inorm_gelu_forward / _backward
  *   GWD_WS_RESAMPLE_BWD    dims = {B, Ho, Ws, C}   -> `tmp`  of gwd_resample_backward_sep
  *   GWD_WS_EVAL            dims = {B, H*W}         -> `workspace` of gwd_eval_accumulate
+ *   GWD_WS_PLANE           dims = {P, H*W}         -> `workspace` of gwd_plane_loss_forward
  * Returns -1 for an unknown op or a wrong dimension count.                                                     */
-enum { GWD_WS_INORM_GELU = 0, GWD_WS_RESAMPLE_BWD = 1, GWD_WS_EVAL = 2 };
+enum { GWD_WS_INORM_GELU = 0, GWD_WS_RESAMPLE_BWD = 1, GWD_WS_EVAL = 2, GWD_WS_PLANE = 3 };
 int64_t gwd_query_workspace(int32_t op, const int64_t *dims, int32_t ndims);
 
 /* Implicit-GEMM convolution on MFMA with fused epilogue y = act(scale*conv(x,w) + shift + residual).
@@ -298,6 +299,22 @@ int gwd_eval_accumulate(const void *pred_depth, const float *gt_depth, const voi
                         int64_t seg_sp, int64_t seg_sc, const int64_t *seg_gt, void *workspace, double *measures,
                         double *running, int64_t *confusion, int32_t B, int64_t HW, float min_depth,
                         float max_depth, int32_t depth_dtype, int32_t seg_dtype, void *stream);
+
+/* PlaneLoss (src/models/glassrgbd.py:385-450, --with_plane_norm_loss) of ONE image, on the device: Sobel normals of the
+ * predicted depth (src/models/losses/sobel.py:5-27), the masks of up to P <= 64 line triangles restricted to the valid
+ * pixels (the reference: matplotlib.path.Path.contains_points on the host; same crossing test here, exact in integers),
+ * per-plane biased variances of both normal components; loss = sum over planes with >= min_area pixels / max(1, count).
+ *   depth [H][W] (dtype), valid [H][W] uint8, tri [P][6] int64 = (x0,y0,x1,y1,x2,y2) already rounded and clamped (:413-418),
+ *   n_planes: DEVICE int32 - only the first *n_planes triangles count (the reference's data-dependent top_num, :400, without
+ *   a host round trip); workspace: gwd_query_workspace(GWD_WS_PLANE, {P, H*W}) bytes;
+ *   stats [4*P + 1] f64 OUT: per plane n, mean_x, mean_y, active; then the number of active planes (read by the backward);
+ *   loss [1] fp32 OUT.  backward: gdepth [H][W] (dtype) = gloss[0] * d loss / d depth (every element written).          */
+int gwd_plane_loss_forward(const void *depth, const uint8_t *valid, const int64_t *tri, const int32_t *n_planes, int32_t P,
+                           int32_t H, int32_t W, int32_t min_area, void *workspace, double *stats, float *loss,
+                           int32_t dtype, void *stream);
+int gwd_plane_loss_backward(const void *depth, const uint8_t *valid, const int64_t *tri, const int32_t *n_planes, int32_t P,
+                            int32_t H, int32_t W, const double *stats, const float *gloss, void *gdepth, int32_t dtype,
+                            void *stream);
 
 #ifdef __cplusplus
 }

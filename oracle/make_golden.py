@@ -28,6 +28,10 @@ CASES = {
     "tiny_b2_96x128": dict(batch=2, height=96, width=128, sizes=None, n_lines=[5, 3], seed=11),
     "ragged_b2_96x128": dict(batch=2, height=96, width=128, sizes=[(96, 128), (80, 104)], n_lines=[4, 6], seed=12),
     "mid_b1_224x288": dict(batch=1, height=224, width=288, sizes=None, n_lines=[7], seed=13),
+    # --with_plane_norm_loss (one image per step, engine_glassrgbd.py:85-86,133-135); the class head gets a bias towards
+    # "line" so that PlaneLoss finds confident lines on random-init weights
+    "plane_b1_96x128": dict(batch=1, height=96, width=128, sizes=None, n_lines=[5], seed=14,
+                            extra=["--with_plane_norm_loss"], class_bias=(1.5, -1.5)),
 }
 
 
@@ -44,9 +48,16 @@ def run_case(name, cfg, train=True):
     torch.manual_seed(0)
     random.seed(0)
     np.random.seed(0)
-    args = ref_stubs.reference_args()
+    args = ref_stubs.reference_args(cfg.get("extra", ()))
+    orig_cuda = (torch.Tensor.cuda, torch.nn.Module.cuda)
+    if cfg.get("extra"):                 # PlaneLoss calls .cuda() on its constants (glassrgbd.py:391,404,412); no GPU here
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        torch.nn.Module.cuda = lambda self, *a, **k: self
     model, criterions, _ = build_model(args)
     det_fill_(model.state_dict(), seed=0)
+    if cfg.get("class_bias"):
+        with torch.no_grad():
+            model.class_embed.bias.copy_(torch.tensor(cfg["class_bias"]))
 
     b = synth_batch(cfg["batch"], cfg["height"], cfg["width"], seed=cfg["seed"],
                     n_lines=cfg["n_lines"], sizes=cfg["sizes"])
@@ -97,6 +108,7 @@ def run_case(name, cfg, train=True):
                                     args.clip_max_norm, args, save_dir=None)
     finally:
         torch.nn.utils.clip_grad_norm_ = orig_clip
+        torch.Tensor.cuda, torch.nn.Module.cuda = orig_cuda
         for h in handles:
             h.remove()
 

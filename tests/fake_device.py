@@ -138,6 +138,51 @@ class FakeDevice:
             g = g * scale
         gx.copy_(g.reshape(gx.shape))
 
+    @staticmethod
+    def _plane_loss_torch(depth, valid, tri, n_planes, P, H, W, min_area):
+        """glassrgbd.py:385-450 in torch (differentiable in depth); returns (loss, stats)."""
+        k = torch.tensor([[[1., 0., -1.], [2., 0., -2.], [1., 0., -1.]], [[1., 2., 1.], [0., 0., 0.], [-1., -2., -1.]]]).view(2, 1, 3, 3)
+        g = F.conv2d(depth.reshape(1, 1, H, W).float(), k, padding=1)
+        nx, ny = -g[0, 0].flatten(), -g[0, 1].flatten()
+        ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+        px, py, v = xs.flatten(), ys.flatten(), valid.flatten().bool()
+        stats = torch.zeros(4 * P + 1, dtype=torch.float64)
+        total, cnt = depth.new_zeros((), dtype=torch.float32), 0
+        for j in range(min(int(n_planes[0]), P)):
+            t = tri[j].reshape(3, 2)
+            inside = torch.zeros_like(v)
+            for a, b in ((0, 1), (1, 2), (2, 0)):
+                ax, ay, bx, by = t[a, 0], t[a, 1], t[b, 0], t[b, 1]
+                f0, f1 = ay >= py, by >= py
+                inside ^= (f0 != f1) & (((by - py) * (ax - bx) >= (bx - px) * (ay - by)) == f1)
+            m = inside & v
+            n = int(m.sum())
+            stats[4 * j] = n
+            if n < min_area:
+                continue
+            stats[4 * j + 1], stats[4 * j + 2], stats[4 * j + 3] = float(nx[m].detach().mean()), float(ny[m].detach().mean()), 1.0
+            total = total + torch.var(nx[m], unbiased=False) + torch.var(ny[m], unbiased=False)
+            cnt += 1
+        stats[4 * P] = cnt
+        return total / max(1, cnt), stats
+
+    def plane_loss_forward(self, depth, valid, tri, n_planes, P, H, W, min_area, workspace, stats, loss):
+        with torch.no_grad():
+            l, st = self._plane_loss_torch(depth, valid, tri, n_planes, P, H, W, min_area)
+        loss.copy_(l.reshape(1))
+        stats.copy_(st)
+        self._plane_min_area = min_area
+
+    def plane_loss_backward(self, depth, valid, tri, n_planes, P, H, W, stats, gloss, gdepth):
+        d = depth.detach().float().clone().requires_grad_(True)
+        with torch.enable_grad():
+            l, _ = self._plane_loss_torch(d, valid, tri, n_planes, P, H, W, self._plane_min_area)
+        if l.requires_grad:
+            (g,) = torch.autograd.grad(l, d)
+            gdepth.copy_((g * gloss[0]).reshape(gdepth.shape))
+        else:
+            gdepth.zero_()
+
     def eval_accumulate(self, pred, gt, seg, seg_strides, seg_gt, workspace, measures, running, confusion, B, HW, dmin, dmax):
         """gwd_eval_accumulate in torch: fp32 per-pixel terms, f64 sums (src/engine_glassrgbd.py:249-263, util/metrics.py:37-99,198-218)."""
         if pred is not None:

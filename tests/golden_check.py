@@ -48,10 +48,15 @@ class TeacherForcedMatcher(torch.nn.Module):
         return forced
 
 
-def build(dropout=0.0, device="cpu"):
-    cfg = Config(device=device, dropout=dropout, log_depth_error=True)
+def build(dropout=0.0, device="cpu", case=None):
+    case = case or {}
+    cfg = Config(device=device, dropout=dropout, log_depth_error=True,
+                 with_plane_norm_loss="--with_plane_norm_loss" in case.get("extra", ()))
     model, crits, _ = build_model(cfg)
-    model.load_state_dict(det_fill_(reference_state_shapes(), seed=0), strict=True)
+    sd = det_fill_(reference_state_shapes(), seed=0)
+    if case.get("class_bias"):
+        sd["class_embed.bias"] = torch.tensor(case["class_bias"])
+    model.load_state_dict(sd, strict=True)
     model.to(device)
     crits[0].to(device)
     return cfg, model, crits
@@ -96,7 +101,7 @@ def check_train_step(case, golden_dir, device, tol, grad_tol):
     """One full train step (fp32) of the product against the reference's golden vectors."""
     g = np.load(os.path.join(golden_dir, case + ".npz"))
     c = CASES[case]
-    cfg, model, crits = build(device=device)
+    cfg, model, crits = build(device=device, case=c)
     b = to_device(synth_batch(c["batch"], c["height"], c["width"], seed=c["seed"], n_lines=c["n_lines"], sizes=c["sizes"]), device)
     step = TrainStep(model, crits, cfg, compute_dtype=torch.float32)
     tf = TeacherForcedMatcher(step.criterion.matcher, g)

@@ -20,7 +20,7 @@ def real_library():
     yield
 
 
-@pytest.mark.parametrize("case", ["tiny_b2_96x128", "ragged_b2_96x128", "mid_b1_224x288"])
+@pytest.mark.parametrize("case", ["tiny_b2_96x128", "ragged_b2_96x128", "mid_b1_224x288", "plane_b1_96x128"])
 def test_fp32_train_step_matches_reference(golden_dir, case):
     check_train_step(case, golden_dir, "cuda", tol=1e-3, grad_tol=5e-3)
 

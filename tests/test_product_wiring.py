@@ -49,7 +49,7 @@ def test_no_cpu_path_without_device_library():
         model([b["images"][0]])
 
 
-@pytest.mark.parametrize("case", ["tiny_b2_96x128", "ragged_b2_96x128"])
+@pytest.mark.parametrize("case", ["tiny_b2_96x128", "ragged_b2_96x128", "plane_b1_96x128"])
 def test_train_step_wiring_matches_reference(fake, golden_dir, case):
     check_train_step(case, golden_dir, "cpu", tol=FP_TOL, grad_tol=3e-3)
 
