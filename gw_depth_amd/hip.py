@@ -29,7 +29,7 @@ ENTRY_POINTS = [
     "gwd_inorm_gelu_forward", "gwd_inorm_gelu_backward", "gwd_weight_prep_batch",
     "gwd_point_sample_forward", "gwd_point_sample_backward", "gwd_act_backward_colsum", "gwd_resample_backward_sep",
     "gwd_softmax_masked_forward", "gwd_softmax_scaled_backward", "gwd_query_workspace", "gwd_eval_accumulate", "gwd_colsum_batch", "gwd_conv_wgrad_batch",
-    "gwd_plane_loss_forward", "gwd_plane_loss_backward",
+    "gwd_plane_loss_forward", "gwd_plane_loss_backward", "gwd_collate",
 ]
 
 
@@ -59,6 +59,13 @@ class ColsumJob(ctypes.Structure):
 
 
 COLSUM_BATCH = 16
+COLLATE_BATCH = 16
+
+
+class ImageJob(ctypes.Structure):
+    """gwd_image_job (include/gwdepth.h)."""
+    _fields_ = [("rgb", ctypes.c_void_p), ("depth_mm", ctypes.c_void_p), ("labels", ctypes.c_void_p),
+                ("h", ctypes.c_int32), ("w", ctypes.c_int32)]
 
 
 class Strided(ctypes.Structure):
@@ -125,6 +132,8 @@ class HipLibrary:
         L.gwd_conv_wgrad_batch.argtypes = [ctypes.POINTER(ConvDesc), ctypes.POINTER(ctypes.c_void_p), i32, vp]
         L.gwd_plane_loss_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp]
         L.gwd_plane_loss_backward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp]
+        L.gwd_collate.argtypes = [ctypes.POINTER(ImageJob), i32, i32, i32, ctypes.POINTER(ctypes.c_float),
+                                  ctypes.POINTER(ctypes.c_float), vp, vp, vp, vp, i32, vp]
         L.gwd_colsum_batch.argtypes = [ctypes.POINTER(ColsumJob), i32, i32, vp]
         L.gwd_layernorm_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
         L.gwd_layernorm_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
@@ -299,6 +308,18 @@ class HipLibrary:
         self._check(self.lib.gwd_plane_loss_backward(_ptr(depth), _ptr(valid), _ptr(tri), _ptr(n_planes), P, H, W, _ptr(stats),
                                                      _ptr(gloss), _ptr(gdepth), dtype_code(depth),
                                                      self._stream(depth, valid, tri, n_planes, stats, gloss, gdepth)), "gwd_plane_loss_backward")
+
+    def collate(self, samples, H, W, mean, std, images, mask, depth, seg):
+        """gwd_collate.  samples: (rgb uint8 (h,w,3), depth_mm int32 (h,w) | None, labels uint8 (h,w) | None) device tensors."""
+        jobs = (ImageJob * len(samples))()
+        ts = [images, mask, depth, seg]
+        for j, (rgb, dmm, lab) in zip(jobs, samples):
+            j.rgb, j.depth_mm, j.labels = _ptr(rgb), _ptr(dmm), _ptr(lab)
+            j.h, j.w = rgb.shape[0], rgb.shape[1]
+            ts += [rgb, dmm, lab]
+        f3 = ctypes.c_float * 3
+        self._check(self.lib.gwd_collate(jobs, len(samples), H, W, f3(*mean), f3(*std), _ptr(images), _ptr(mask), _ptr(depth),
+                                         _ptr(seg), dtype_code(images), self._stream(*ts)), "gwd_collate")
 
     def silog_sums(self, pred, gt, sums, B, h, w, H, W, log_err):
         self._check(self.lib.gwd_silog_sums(_ptr(pred), _ptr(gt), _ptr(sums), B, h, w, H, W, int(log_err),

@@ -316,6 +316,22 @@ int gwd_plane_loss_backward(const void *depth, const uint8_t *valid, const int64
                             int32_t H, int32_t W, const double *stats, const float *gloss, void *gdepth, int32_t dtype,
                             void *stream);
 
+/* Batch assembly from raw decoded images (the tail of the input pipeline): ToTensor + Normalize
+ * (src/datasets/transforms_depth.py:618-660; torchvision's to_tensor / normalize: x/255, - mean, / std in fp32), the
+ * dataset's depth_mm / 1000 and label > 0 (src/datasets/glassrgbd_norhint.py:277-281) and collate_fn_aux's zero padding
+ * + padding mask (src/util/misc.py:273-313), one launch for up to GWD_COLLATE_BATCH images.
+ *   jobs[i]: device pointers to image i as decoded - rgb uint8 [h][w][3], depth_mm int32 [h][w], labels uint8 [h][w] (a
+ *            pointer may be NULL when the matching output is NULL); read on the host, passed in the kernel arguments;
+ *   images [n][H][W][3] (dtype, pixel-major), mask [n][H][W] uint8 (1 = padding), depth [n][H][W] fp32 metres,
+ *   seg [n][H][W] int64 {0,1}; every element is written (padding = 0); any output may be NULL.                      */
+#define GWD_COLLATE_BATCH 16
+typedef struct {
+    const void *rgb, *depth_mm, *labels;
+    int32_t h, w;
+} gwd_image_job;
+int gwd_collate(const gwd_image_job *jobs, int32_t n, int32_t H, int32_t W, const float *mean, const float *std,
+                void *images, uint8_t *mask, float *depth, int64_t *seg, int32_t dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

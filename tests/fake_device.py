@@ -183,6 +183,19 @@ class FakeDevice:
         else:
             gdepth.zero_()
 
+    def collate(self, samples, H, W, mean, std, images, mask, depth, seg):
+        """gwd_collate in torch (transforms_depth.py:618-660, glassrgbd_norhint.py:277-281, util/misc.py:273-313)."""
+        m, s_ = torch.tensor(mean, dtype=torch.float32), torch.tensor(std, dtype=torch.float32)
+        images.zero_(); mask.fill_(1); depth.zero_(); seg.zero_()
+        for b, (rgb, dmm, lab) in enumerate(samples):
+            h, w = rgb.shape[:2]
+            images[b, :h, :w] = ((rgb.to(torch.float32).div(255) - m) / s_).to(images.dtype)
+            mask[b, :h, :w] = 0
+            if dmm is not None:
+                depth[b, :h, :w] = dmm / 1000.0
+            if lab is not None:
+                seg[b, :h, :w] = (lab > 0).long()
+
     def eval_accumulate(self, pred, gt, seg, seg_strides, seg_gt, workspace, measures, running, confusion, B, HW, dmin, dmax):
         """gwd_eval_accumulate in torch: fp32 per-pixel terms, f64 sums (src/engine_glassrgbd.py:249-263, util/metrics.py:37-99,198-218)."""
         if pred is not None:
