@@ -63,17 +63,26 @@ __global__ __launch_bounds__(THREADS) void certain_sample_kernel(const float *__
         total += kk[i];
     }
     if (total == 0) kmax = S;                     // "sample globally when no interval points found" (:331-339)
-    // ---- top-kmax by repeated arg-max, ties to the lowest pixel index
-    for (int r = 0; r < kmax; ++r) {
-        float bv = -1.f;
-        int bi = 0x7fffffff;
+    // ---- top-kmax by repeated arg-max, ties to the lowest pixel index.  Every thread caches the best of ITS strided pixel
+    // subset; a round is one block-wide reduction of the cached values, and only the thread that owned the winner rescans
+    // (19 LDS reads for one thread instead of a full sweep of the map by all of them, per round).
+    auto local_best = [&](float &bv, int &bi) {
+        bv = -1.f;
+        bi = 0x7fffffff;
         for (int p = tid; p < HW; p += THREADS) {
             const float v = var[p];
-            if (v > bv) {
+            if (v > bv) {                                 // strict: the lowest index wins a tie inside the subset
                 bv = v;
                 bi = p;
             }
         }
+    };
+    float my_v;
+    int my_i;
+    local_best(my_v, my_i);
+    for (int r = 0; r < kmax; ++r) {
+        float bv = my_v;
+        int bi = my_i;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float ov = __shfl_xor(bv, o, 64);
@@ -98,6 +107,7 @@ __global__ __launch_bounds__(THREADS) void certain_sample_kernel(const float *__
             var[bi] = -2.f;                       // taken (variances are >= 0)
         }
         __syncthreads();
+        if (order[r] % THREADS == tid) local_best(my_v, my_i);      // pixel p belongs to thread p % THREADS
     }
     // ---- group assembly (serial: <= a few hundred integers)
     if (tid == 0) {
