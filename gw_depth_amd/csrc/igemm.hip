@@ -1166,8 +1166,13 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
             return 0;
         }
     }
+    // fewer than two tiles per CU (the 60/120-channel pyramid at 1/8 resolution: 300 tiles of 128 rows = one full round plus
+    // a tail round of 44): quarter tiles give four times as many workgroups
+    const bool quarter = fwd_variant() != 7 && N > 32 && gm * ((N + 127) / 128) < 512;
     if (N % 160 == 0) {                       // 160 / 320 channel pyramids: exact tiles, no padded columns
         igemm_fwd_kernel<T, 128, 160, 4, 1, BK><<<dim3(gm, N / 160), 256, 0, s>>>(*d);
+    } else if (quarter) {
+        igemm_fwd_kernel<T, 64, 64, 2, 2, BK><<<dim3((M + 63) / 64, (N + 63) / 64), 256, 0, s>>>(*d);
     } else if (N > 64) {
         igemm_fwd_kernel<T, 128, 128, 2, 2, BK><<<dim3(gm, (N + 127) / 128), 256, 0, s>>>(*d);
     } else if (N > 32) {
