@@ -29,7 +29,7 @@ ENTRY_POINTS = [
     "gwd_inorm_gelu_forward", "gwd_inorm_gelu_backward", "gwd_weight_prep_batch",
     "gwd_point_sample_forward", "gwd_point_sample_backward", "gwd_act_backward_colsum", "gwd_resample_backward_sep",
     "gwd_softmax_masked_forward", "gwd_softmax_scaled_backward", "gwd_query_workspace", "gwd_eval_accumulate", "gwd_colsum_batch", "gwd_conv_wgrad_batch",
-    "gwd_plane_loss_forward", "gwd_plane_loss_backward", "gwd_collate",
+    "gwd_plane_loss_forward", "gwd_plane_loss_backward", "gwd_collate", "gwd_mha_forward",
 ]
 
 
@@ -134,6 +134,7 @@ class HipLibrary:
         L.gwd_plane_loss_backward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp]
         L.gwd_collate.argtypes = [ctypes.POINTER(ImageJob), i32, i32, i32, ctypes.POINTER(ctypes.c_float),
                                   ctypes.POINTER(ctypes.c_float), vp, vp, vp, vp, i32, vp]
+        L.gwd_mha_forward.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]
         L.gwd_colsum_batch.argtypes = [ctypes.POINTER(ColsumJob), i32, i32, vp]
         L.gwd_layernorm_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
         L.gwd_layernorm_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
@@ -320,6 +321,18 @@ class HipLibrary:
         f3 = ctypes.c_float * 3
         self._check(self.lib.gwd_collate(jobs, len(samples), H, W, f3(*mean), f3(*std), _ptr(images), _ptr(mask), _ptr(depth),
                                          _ptr(seg), dtype_code(images), self._stream(*ts)), "gwd_collate")
+
+    MHA_MAX_KEYS, MHA_HEAD_DIM = 320, 32
+
+    def mha_forward(self, q, k, v, key_padding_mask, mult, P, out, B, H, L, S, scale):
+        """gwd_mha_forward.  q/k/v: (B, tokens, 32 H) tensors or last-dim slices of a packed projection (unit column stride)."""
+        for t in (q, k, v):
+            if t.dim() != 3 or t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
+                raise ValueError("q/k/v must be (B, tokens, E) with unit column stride and dense token rows")
+        self._check(self.lib.gwd_mha_forward(ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(k.data_ptr()), ctypes.c_void_p(v.data_ptr()),
+                                             q.stride(1), k.stride(1), v.stride(1), _ptr(key_padding_mask), _ptr(mult), _ptr(P),
+                                             _ptr(out), B, H, L, S, float(scale), dtype_code(q),
+                                             self._stream(q, k, v, key_padding_mask, mult, P, out)), "gwd_mha_forward")
 
     def silog_sums(self, pred, gt, sums, B, h, w, H, W, log_err):
         self._check(self.lib.gwd_silog_sums(_ptr(pred), _ptr(gt), _ptr(sums), B, h, w, H, W, int(log_err),

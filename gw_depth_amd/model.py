@@ -187,6 +187,9 @@ class MultiheadAttention(nn.Module):
             q = ops.linear(query, W, b, rows=(0, E))
             k = ops.linear(key, W, b, rows=(E, 2 * E))
         v = ops.linear(value, W, b, rows=(2 * E, 3 * E))
+        fused = ops.mha_core(q, k, v, H, key_padding_mask, self.dropout, self.training, float(hd) ** -0.5)
+        if fused is not None:               # head_dim 32, <= 320 keys: one kernel, no head split / merge copies
+            return self.out_proj(fused)
         q = q.reshape(B, L, H, hd).transpose(1, 2)
         k = k.reshape(B, S, H, hd).transpose(1, 2)
         v = v.reshape(B, S, H, hd).transpose(1, 2)

@@ -5,7 +5,10 @@ Layout conventions: feature maps are (B, H, W, C) contiguous ("pixel-major"), to
 Master parameters are fp32; with bf16 activations the kernels read a bf16 copy of the weights
 (the flat shadow maintained by the fused optimizer when present, otherwise made on the fly).
 """
+import os
+
 import torch
+import torch.nn.functional as F
 
 from . import hip
 from .hip import (ACT_ELU, ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, GATHER_CONV, GATHER_TRANSPOSED,
@@ -497,6 +500,61 @@ class _AttnSoftmaxFn(torch.autograd.Function):
 def attention_softmax(scores, key_padding_mask=None, scale=1.0):
     """softmax(scale * scores + key-padding mask) over the last dim; scores (B, H, L, S), mask (B, S) bool (True = pad)."""
     return _AttnSoftmaxFn.apply(scores, key_padding_mask, float(scale))
+
+
+class _MhaFn(torch.autograd.Function):
+    """Attention core of one MultiheadAttention call: fused forward (gwd_mha_forward), backward through the batched-GEMM
+    library and gwd_softmax_scaled_backward (the same arithmetic autograd ran before)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, H, key_padding_mask, mult, scale):
+        lib = _lib()
+        B, L, E = q.shape
+        S = k.shape[1]
+        P = torch.empty((B, H, L, S), dtype=q.dtype, device=q.device)
+        out = torch.empty((B, L, E), dtype=q.dtype, device=q.device)
+        if key_padding_mask is not None:
+            key_padding_mask = key_padding_mask.contiguous().view(torch.uint8) if key_padding_mask.dtype == torch.bool else key_padding_mask.contiguous()
+        lib.mha_forward(q, k, v, key_padding_mask, mult, P, out, B, H, L, S, scale)
+        ctx.save_for_backward(q, k, v, P, mult)
+        ctx.H, ctx.scale = H, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        q, k, v, P, mult = ctx.saved_tensors
+        H, B, L, E = ctx.H, q.shape[0], q.shape[1], q.shape[2]
+        S, hd = k.shape[1], E // ctx.H
+        heads = lambda t, n: t.reshape(B, n, H, hd).transpose(1, 2)
+        goh = heads(go, L)
+        Pd = P if mult is None else P * mult
+        gv = Pd.transpose(-2, -1) @ goh                                   # (B, H, S, hd)
+        gP = goh @ heads(v, S).transpose(-2, -1)                          # (B, H, L, S)
+        if mult is not None:
+            gP = gP * mult
+        gS = torch.empty_like(P)
+        _lib().softmax_scaled_backward(gP.contiguous(), P, gS, P.numel() // S, S, ctx.scale)
+        gq = gS @ heads(k, S)
+        gk = gS.transpose(-2, -1) @ heads(q, L)
+        merge = lambda t, n: t.transpose(1, 2).reshape(B, n, E)
+        return merge(gq, L), merge(gk, S), merge(gv, S), None, None, None, None
+
+
+def mha_core(q, k, v, heads, key_padding_mask, dropout_p, training, scale):
+    """dropout(softmax(scale q k^T + mask)) v, heads merged: q (B,L,E), k/v (B,S,E) (last-dim slices allowed).  Returns None when
+    the fused kernel does not cover the shape (head_dim != 32 or more than 320 keys) or is not enabled: the caller keeps the
+    batched-GEMM path.  OPT-IN (GWD_FUSED_MHA=1): measured on one box the fused forward costs what the seven launches it replaces
+    cost (50 us per call, VALU-bound: 53.3 vs 53.1 ms per step) - see DESIGN.md section 4; it is parity-tested either way."""
+    lib = _lib()
+    E, S = q.shape[-1], k.shape[1]
+    if E // heads != getattr(lib, "MHA_HEAD_DIM", 0) or S > getattr(lib, "MHA_MAX_KEYS", 0) or os.environ.get("GWD_FUSED_MHA", "0") != "1":
+        return None
+    mult = None
+    if training and dropout_p > 0:       # ATen's graph-safe Philox stream decides which probabilities are dropped
+        mult = F.dropout(torch.ones((q.shape[0], heads, q.shape[1], S), dtype=q.dtype, device=q.device), dropout_p, True)
+    fix = lambda t: t if (t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1) and (t.stride(1) * t.element_size()) % 16 == 0
+                          and t.data_ptr() % 16 == 0) else t.contiguous()
+    return _MhaFn.apply(fix(q), fix(k), fix(v), int(heads), key_padding_mask, mult, float(scale))
 
 
 class _SilogFn(torch.autograd.Function):

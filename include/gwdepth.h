@@ -316,6 +316,17 @@ int gwd_plane_loss_backward(const void *depth, const uint8_t *valid, const int64
                             int32_t H, int32_t W, const double *stats, const float *gloss, void *gdepth, int32_t dtype,
                             void *stream);
 
+/* Multi-head attention forward core, head_dim 32, S <= 320 keys (the DETR encoder / decoder attention,
+ * src/models/multi_head_attention.py:329-372): out = dropout(softmax(scale * q k^T + key mask)) v with the heads merged.
+ *   q: row (b, l) at q + (b*L + l)*q_rs, head h in columns [32h, 32h+32) (dtype; q_rs, k_rs, v_rs are ROW strides in
+ *   elements, so slices of a packed in-projection are read in place); k, v likewise with S rows per image;
+ *   key_padding_mask [B][S] uint8 (nonzero = excluded, -inf) or NULL; mult [B][H][L][S] (dtype) dropout multipliers
+ *   (0 or 1/(1-p)) or NULL; P [B][H][L][S] (dtype) OUT: the softmax probabilities BEFORE dropout (saved for the backward
+ *   pass); out [B][L][32 H] (dtype).  Returns -4 for S > 320 (use batched GEMMs), -5 for rows that are not 16-byte aligned. */
+int gwd_mha_forward(const void *q, const void *k, const void *v, int64_t q_rs, int64_t k_rs, int64_t v_rs,
+                    const uint8_t *key_padding_mask, const void *mult, void *P, void *out, int32_t B, int32_t H,
+                    int32_t L, int32_t S, float scale, int32_t dtype, void *stream);
+
 /* Batch assembly from raw decoded images (the tail of the input pipeline): ToTensor + Normalize
  * (src/datasets/transforms_depth.py:618-660; torchvision's to_tensor / normalize: x/255, - mean, / std in fp32), the
  * dataset's depth_mm / 1000 and label > 0 (src/datasets/glassrgbd_norhint.py:277-281) and collate_fn_aux's zero padding

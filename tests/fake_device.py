@@ -183,6 +183,22 @@ class FakeDevice:
         else:
             gdepth.zero_()
 
+    MHA_MAX_KEYS, MHA_HEAD_DIM = 320, 32
+
+    def mha_forward(self, q, k, v, key_padding_mask, mult, P, out, B, H, L, S, scale):
+        """gwd_mha_forward in torch (multi_head_attention.py:329-372)."""
+        hd = q.shape[-1] // H
+        qh = q.float().reshape(B, L, H, hd).transpose(1, 2) * scale
+        kh = k.float().reshape(B, S, H, hd).transpose(1, 2)
+        vh = v.float().reshape(B, S, H, hd).transpose(1, 2)
+        s_ = qh @ kh.transpose(-2, -1)
+        if key_padding_mask is not None:
+            s_ = s_.masked_fill(key_padding_mask.bool().view(B, 1, 1, S), float("-inf"))
+        p = torch.softmax(s_, dim=-1).to(P.dtype)
+        P.copy_(p)
+        pd = p.float() if mult is None else p.float() * mult.float()
+        out.copy_((pd @ vh).transpose(1, 2).reshape(B, L, H * hd))
+
     def collate(self, samples, H, W, mean, std, images, mask, depth, seg):
         """gwd_collate in torch (transforms_depth.py:618-660, glassrgbd_norhint.py:277-281, util/misc.py:273-313)."""
         m, s_ = torch.tensor(mean, dtype=torch.float32), torch.tensor(std, dtype=torch.float32)

@@ -280,3 +280,9 @@ def test_flat_adamw_on_device_matches_torch_adamw():
     assert opt.lrs() == tuple(g["lr"] for g in ref.param_groups)
     worst = max(float((model.get_parameter(n).detach() - p.detach()).abs().max() / (p.detach().abs().max() + 1e-12)) for n, p in named)
     assert worst < 1e-6, worst
+
+
+def test_fused_attention_opt_in_keeps_golden_parity(golden_dir, monkeypatch):
+    """GWD_FUSED_MHA=1: the DETR attention through gwd_mha_forward (ragged batch = key-padding masks) against the reference's vectors."""
+    monkeypatch.setenv("GWD_FUSED_MHA", "1")
+    check_train_step("ragged_b2_96x128", golden_dir, "cuda", tol=1e-3, grad_tol=5e-3)

@@ -600,3 +600,38 @@ def test_conv_wgrad_row_scale(dev, dtype, spec):
     dev.conv_wgrad(x.cuda(), gy.cuda(), dw1, dims, stride=stride, pad=pad, scale=sc.cuda())
     dev.conv_wgrad_batch([(x.cuda(), gy.cuda(), dw2, dims, dict(stride=stride, pad=pad, scale=sc.cuda()))])
     assert rel(dw1, ref) < TOL[dtype] and rel(dw2, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 8, 300, 300, True, True), (2, 8, 100, 300, True, False), (1, 8, 37, 65, False, True),
+                                   (2, 4, 100, 100, False, False), (1, 2, 5, 320, True, True)])
+def test_mha_forward(dev, shape, dtype):
+    """gwd_mha_forward (head_dim 32, <= 320 keys) vs torch math: probabilities, merged output; key-padding mask, dropout
+    multipliers, q / k read in place from a packed (B, L, 2E) projection."""
+    B, H, L, S, masked, drop = shape
+    E = 32 * H
+    fake = FakeDevice()
+    qk = rnd(B, L, 2 * E, dtype=dtype, seed=1) if L == S else None
+    q = qk[..., :E] if qk is not None else rnd(B, L, E, dtype=dtype, seed=1)
+    k = qk[..., E:] if qk is not None else rnd(B, S, E, dtype=dtype, seed=2)
+    v = rnd(B, S, E, dtype=dtype, seed=3)
+    kpm = None
+    if masked:
+        kpm = torch.zeros(B, S, dtype=torch.uint8)
+        kpm[0, S // 2:] = 1
+        kpm[-1, 3] = 1
+    mult = None
+    if drop:
+        g = torch.Generator().manual_seed(4)
+        mult = ((torch.rand(B, H, L, S, generator=g) > 0.1).float() / 0.9).to(dtype)
+    P_r, o_r = torch.empty(B, H, L, S, dtype=dtype), torch.empty(B, L, E, dtype=dtype)
+    fake.mha_forward(q, k, v, kpm, mult, P_r, o_r, B, H, L, S, 32 ** -0.5)
+    cu = lambda t: None if t is None else t.cuda()
+    qc, kc = (qk.cuda()[..., :E], qk.cuda()[..., E:]) if qk is not None else (q.cuda(), k.cuda())
+    P, o = torch.full((B, H, L, S), float("nan"), dtype=dtype).cuda(), torch.full((B, L, E), float("nan"), dtype=dtype).cuda()
+    dev.mha_forward(qc, kc, v.cuda(), cu(kpm), cu(mult), P, o, B, H, L, S, 32 ** -0.5)
+    torch.cuda.synchronize()
+    assert rel(P, P_r) < TOL[dtype] and rel(o, o_r) < TOL[dtype]
+    with pytest.raises(RuntimeError):                                   # 321 keys: not covered, the caller keeps the GEMM path
+        dev.mha_forward(q.cuda().contiguous(), torch.zeros(B, 321, E, dtype=dtype).cuda(), torch.zeros(B, 321, E, dtype=dtype).cuda(), None, None,
+                        torch.empty(B, H, L, 321, dtype=dtype).cuda(), o, B, H, L, 321, 1.0)
