@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GWD_VERSION 4
+#define GWD_VERSION 5
 
 enum { GWD_F32 = 0, GWD_BF16 = 1 };
 enum { GWD_ACT_NONE = 0, GWD_ACT_RELU = 1, GWD_ACT_GELU = 2, GWD_ACT_ELU = 3, GWD_ACT_SIGMOID = 4 };
