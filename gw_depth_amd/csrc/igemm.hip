@@ -1275,7 +1275,7 @@ int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s, WgradCollecto
                 if (d->KH == 1 && d->KW == 1 && d->pad == 0) fast = 2;
                 else if (d->Ho == d->Hi && d->Wo == d->Wi && d->Wo >= 11) fast = 1;
             }
-            if (N % 160 == 0 && K >= 256 && var == 1) WG_LAUNCH(160, 256, 1, 4, 3)
+            if (N % 160 == 0 && K >= 256 && (var == 1 || var == 2)) WG_LAUNCH(160, 256, 1, 4, 3)      // var 2: the wide tile for the 160-wide pyramids only
             else if (N % 160 == 0 && K >= 128 && var != 3) WG_LAUNCH(160, 128, 1, 4, 3)
             else if (N > 64 && K >= 256 && var == 1) WG_LAUNCH(128, 256, 2, 2, 3)
             else if (N > 64 && K > 64) WG_LAUNCH(128, 128, 2, 2, 3)
