@@ -8,7 +8,7 @@
 namespace {
 
 constexpr int MAX_PIX = 36864, MAX_S = 256, MAX_INT = 8, THREADS = 256;
-constexpr int TABLE_BYTES = (5 * MAX_S + 2 * MAX_INT + 2 * (THREADS / 64)) * 4;   // variance map in dynamic LDS: up to 144 KiB (192 x 192)
+constexpr int TABLE_BYTES = (6 * MAX_S + 2 * MAX_INT + 2 * (THREADS / 64) + 4) * 4;   // variance map in dynamic LDS: up to 144 KiB (192 x 192)
 
 __global__ __launch_bounds__(THREADS) void certain_sample_kernel(const float *__restrict__ small, const float *__restrict__ large,
                                                                   float *__restrict__ coords, int hs, int ws, int H, int W,
@@ -21,11 +21,14 @@ __global__ __launch_bounds__(THREADS) void certain_sample_kernel(const float *__
     float *red_v = (float *)(cnt + MAX_INT);  // [THREADS / 64]
     int *red_i = (int *)(red_v + THREADS / 64);
     int *kk = red_i + THREADS / 64;         // [MAX_INT]
-    float *var = (float *)(kk + MAX_INT);   // [H * W]
+    int *sel = kk + MAX_INT;                // [MAX_S] selected pixels, unordered
+    int *ctrs = sel + MAX_S;                // [3] rotating counters of block_count, [3] = list length
+    float *var = (float *)(ctrs + 4);       // [H * W]
     const int b = blockIdx.x, tid = threadIdx.x, HW = H * W;
     const float *sm = small + (size_t)b * hs * ws;
     const float *lg = large + (size_t)b * HW;
     if (tid < MAX_INT) cnt[tid] = 0;
+    if (tid < 4) ctrs[tid] = 0;
     __syncthreads();
     const float sh = H > 1 ? (float)(hs - 1) / (float)(H - 1) : 0.f, sw = W > 1 ? (float)(ws - 1) / (float)(W - 1) : 0.f;
     int local[MAX_INT];
@@ -63,76 +66,80 @@ __global__ __launch_bounds__(THREADS) void certain_sample_kernel(const float *__
         total += kk[i];
     }
     if (total == 0) kmax = S;                     // "sample globally when no interval points found" (:331-339)
-    // ---- top-kmax by repeated arg-max, ties to the lowest pixel index.  Every thread caches the best of ITS strided pixel
-    // subset; a round is one block-wide reduction of the cached values, and only the thread that owned the winner rescans
-    // (19 LDS reads for one thread instead of a full sweep of the map by all of them, per round).
-    auto local_best = [&](float &bv, int &bi) {
-        bv = -1.f;
-        bi = 0x7fffffff;
-        for (int p = tid; p < HW; p += THREADS) {
-            const float v = var[p];
-            if (v > bv) {                                 // strict: the lowest index wins a tie inside the subset
-                bv = v;
-                bi = p;
-            }
+    // ---- the kmax largest variances in descending order, ties to the lowest pixel index - by SELECTION, not by kmax
+    // rounds of arg-max (each round was a dependent sweep of a thread's ~19 LDS values + two barriers: 0.4 ms for S = 80):
+    // (1) bitwise binary search for the bit pattern T of the kmax-th largest value (variances are >= 0, so their bit
+    // patterns order like the values; 31 counting rounds, one barrier each), (2) among the pixels equal to T, the index
+    // threshold I that admits exactly the missing number of them (16 rounds), (3) the kmax selected pixels are appended
+    // to a list and rank-sorted by (value descending, index ascending).  Same set, same order as the arg-max loop.
+    auto block_count = [&](auto pred, int round) -> int {                  // number of pixels satisfying pred; 1 barrier
+        int c = 0;
+        for (int p = tid; p < HW; p += THREADS) c += pred(__float_as_uint(var[p]), p) ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        int *ctr = ctrs + (round % 3);
+        if ((tid & 63) == 0) atomicAdd(ctr, c);
+        if (tid == 0) ctrs[(round + 1) % 3] = 0;                           // last read two rounds ago
+        __syncthreads();
+        return *ctr;
+    };
+    int round = 0;
+    unsigned T = 0;
+    for (int bit = 30; bit >= 0; --bit) {
+        const unsigned cand = T | (1u << bit);
+        if (block_count([&](unsigned v, int) { return v >= cand; }, round++) >= kmax) T = cand;
+    }
+    const int n_gt = block_count([&](unsigned v, int) { return v > T; }, round++);
+    const int need_eq = kmax - n_gt;                                        // >= 1
+    int I = 0;
+    for (int bit = 15; bit >= 0; --bit) {
+        const int cand = I | (1 << bit);
+        if (block_count([&](unsigned v, int p) { return v == T && p < cand; }, round++) < need_eq) I = cand;
+    }
+    for (int p = tid; p < HW; p += THREADS) {
+        const unsigned v = __float_as_uint(var[p]);
+        if (v > T || (v == T && p <= I)) sel[atomicAdd(&ctrs[3], 1)] = p;  // exactly kmax pixels, any order
+    }
+    __syncthreads();
+    for (int a = tid; a < kmax; a += THREADS) {
+        const int pa = sel[a];
+        const unsigned va = __float_as_uint(var[pa]);
+        int rank = 0;
+        for (int c = 0; c < kmax; ++c) {
+            const int pc = sel[c];
+            const unsigned vc = __float_as_uint(var[pc]);
+            rank += (vc > va || (vc == va && pc < pa)) ? 1 : 0;
+        }
+        order[rank] = pa;
+    }
+    __syncthreads();
+    // ---- group assembly.  The ascending-index copies of each interval's best k_i pixels are rank sorts done by all
+    // threads (thread 0 alone spent 130 us in these O(k^2) loops); the list surgery that follows is O(S) and serial.
+    int n_out = 0;
+    int gstart[MAX_INT], gcount[MAX_INT], ng = 0;            // uniform: every thread derives the same bookkeeping
+    auto emit_sorted_prefix = [&](int k, int at) {           // ascending pixel index of the k best (:320,335)
+        for (int a = tid; a < k; a += THREADS) {
+            const int oa = order[a];
+            int rank = 0;
+            for (int c = 0; c < k; ++c) rank += order[c] < oa;
+            outidx[at + rank] = oa;
         }
     };
-    float my_v;
-    int my_i;
-    local_best(my_v, my_i);
-    for (int r = 0; r < kmax; ++r) {
-        float bv = my_v;
-        int bi = my_i;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ov > bv || (ov == bv && oi < bi)) {
-                bv = ov;
-                bi = oi;
+    if (total > 0) {
+        for (int i = 0; i < n_int; ++i)
+            if (kk[i] > 0) {
+                gstart[ng] = n_out;
+                gcount[ng] = kk[i];
+                emit_sorted_prefix(kk[i], n_out);
+                n_out += kk[i];
+                ++ng;
             }
-        }
-        if ((tid & 63) == 0) {
-            red_v[tid >> 6] = bv;
-            red_i[tid >> 6] = bi;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            for (int wv = 1; wv < THREADS / 64; ++wv)
-                if (red_v[wv] > bv || (red_v[wv] == bv && red_i[wv] < bi)) {
-                    bv = red_v[wv];
-                    bi = red_i[wv];
-                }
-            order[r] = bi;
-            var[bi] = -2.f;                       // taken (variances are >= 0)
-        }
-        __syncthreads();
-        if (order[r] % THREADS == tid) local_best(my_v, my_i);      // pixel p belongs to thread p % THREADS
+    } else {
+        emit_sorted_prefix(S, 0);
+        n_out = S;
     }
-    // ---- group assembly (serial: <= a few hundred integers)
+    __syncthreads();
     if (tid == 0) {
-        int n_out = 0;
-        auto emit_sorted_prefix = [&](int k, int at) {      // ascending pixel index of the k best (:320,335)
-            for (int a = 0; a < k; ++a) {
-                int rank = 0;
-                for (int c = 0; c < k; ++c) rank += order[c] < order[a];
-                outidx[at + rank] = order[a];
-            }
-        };
-        int gstart[MAX_INT], gcount[MAX_INT], ng = 0;
-        if (total > 0) {
-            for (int i = 0; i < n_int; ++i)
-                if (kk[i] > 0) {
-                    gstart[ng] = n_out;
-                    gcount[ng] = kk[i];
-                    emit_sorted_prefix(kk[i], n_out);
-                    n_out += kk[i];
-                    ++ng;
-                }
-        } else {
-            emit_sorted_prefix(S, 0);
-            n_out = S;
-        }
         int remain = total > 0 ? S - total : 0;
         const int already = total;
         if (remain > 0 && remain >= already) {              // :343-346 repeat the whole list
@@ -155,12 +162,13 @@ __global__ __launch_bounds__(THREADS) void certain_sample_kernel(const float *__
             for (int a = from; a < n_out; ++a) outidx[a - cut] = outidx[a];
             n_out -= cut;
         }
-        for (int a = 0; a < S; ++a) {
-            const int p = outidx[a];
-            const int row = p / W, col = p - row * W;
-            coords[((size_t)b * S + a) * 2 + 0] = __fdiv_rn((float)col, (float)W) * 2.f - 1.f;
-            coords[((size_t)b * S + a) * 2 + 1] = __fdiv_rn((float)row, (float)H) * 2.f - 1.f;
-        }
+    }
+    __syncthreads();
+    for (int a = tid; a < S; a += THREADS) {
+        const int p = outidx[a];
+        const int row = p / W, col = p - row * W;
+        coords[((size_t)b * S + a) * 2 + 0] = __fdiv_rn((float)col, (float)W) * 2.f - 1.f;
+        coords[((size_t)b * S + a) * 2 + 1] = __fdiv_rn((float)row, (float)H) * 2.f - 1.f;
     }
 }
 
