@@ -109,8 +109,9 @@ class SetCriterion(nn.Module):
         sumT = packed["lines"].shape[0]
         with torch.no_grad():                                                          # matcher.py:52-70
             prob = logits.softmax(-1)
-            cost = self.matcher.cost_line * torch.cdist(lines.reshape(L_ * B, Q, -1), packed["lines"][None].expand(L_ * B, -1, -1), p=1) \
-                + self.matcher.cost_class * (-prob.reshape(L_ * B, Q, -1)[..., packed["labels"]])
+            # L1 distances as one broadcast |a - b| summed over the 6 coordinates (aten::cdist takes 158 us for this 48x100x56 problem)
+            l1 = (lines.reshape(L_ * B, Q, 1, -1) - packed["lines"][None, None]).abs().sum(-1)
+            cost = self.matcher.cost_line * l1 + self.matcher.cost_class * (-prob.reshape(L_ * B, Q, -1)[..., packed["labels"]])
             qot = torch.empty((L_, sumT), dtype=torch.int32, device=logits.device)
             hip.library().lsap(cost.reshape(L_, B, Q, sumT).contiguous(), packed["col_off"], qot, max(packed["sizes"]))
             qi = qot.long()
