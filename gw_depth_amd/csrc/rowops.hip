@@ -119,7 +119,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T *__restrict_
 }
 
 // y = softmax(scale * x + key mask): mask (uint8, [rows / rows_per_mask][L], nonzero = excluded key, -inf) may be NULL
-template <typename T>
+// NPL = elements per lane, a compile-time bound >= ceil(L / 64): with the one-size-fits-all bound of 16 an 80-wide row paid for
+// 16 predicated loads and 16 expf per lane where 2 are live
+template <typename T, int NPL>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const T *__restrict__ x, T *__restrict__ y, int64_t rows, int L,
                                                           float scale = 1.0f, const unsigned char *__restrict__ mask = nullptr,
                                                           int64_t rows_per_mask = 1) {
@@ -129,10 +131,10 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const T *__restrict__ 
     for (int64_t r = wave; r < rows; r += nw) {
         const T *xr = x + r * L;
         const unsigned char *mr = mask ? mask + (r / rows_per_mask) * L : nullptr;
-        float v[SM_PER_LANE];
+        float v[NPL];
         float mx = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < SM_PER_LANE; ++i) {
+        for (int i = 0; i < NPL; ++i) {
             const int c = lane + 64 * i;
             v[i] = (i < per && c < L) ? to_f32(xr[c]) * scale : -INFINITY;
             if (mr && i < per && c < L && mr[c]) v[i] = -INFINITY;
@@ -141,31 +143,31 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const T *__restrict__ 
         mx = wave_max_uniform(mx);
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < SM_PER_LANE; ++i) {
+        for (int i = 0; i < NPL; ++i) {
             v[i] = (v[i] == -INFINITY) ? 0.f : expf(v[i] - mx);
             s += v[i];
         }
         const float inv = 1.0f / wave_sum_uniform(s);
         T *yr = y + r * L;
 #pragma unroll
-        for (int i = 0; i < SM_PER_LANE; ++i) {
+        for (int i = 0; i < NPL; ++i) {
             const int c = lane + 64 * i;
             if (i < per && c < L) yr[c] = from_f32<T>(v[i] * inv);
         }
     }
 }
 
-template <typename T>
+template <typename T, int NPL>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T *__restrict__ gy, const T *__restrict__ y,
                                                           T *__restrict__ gx, int64_t rows, int L, float scale = 1.0f) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
     const int per = (L + 63) / 64;
     for (int64_t r = wave; r < rows; r += nw) {
-        float yv[SM_PER_LANE], gv[SM_PER_LANE];
+        float yv[NPL], gv[NPL];
         float dot = 0.f;
 #pragma unroll
-        for (int i = 0; i < SM_PER_LANE; ++i) {
+        for (int i = 0; i < NPL; ++i) {
             const int c = lane + 64 * i;
             const bool ok = i < per && c < L;
             yv[i] = ok ? to_f32(y[r * L + c]) : 0.f;
@@ -174,11 +176,31 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T *__restrict__ 
         }
         dot = wave_sum_uniform(dot);
 #pragma unroll
-        for (int i = 0; i < SM_PER_LANE; ++i) {
+        for (int i = 0; i < NPL; ++i) {
             const int c = lane + 64 * i;
             if (i < per && c < L) gx[r * L + c] = from_f32<T>(scale * yv[i] * (gv[i] - dot));
         }
     }
+}
+
+inline bool softmax_generic() {              // A/B switch: the one-size kernel (NPL = 16) for every row length
+    static int v = -1;
+    if (v < 0) v = getenv("GWD_SOFTMAX_GENERIC") ? 1 : 0;
+    return v == 1;
+}
+template <typename T>
+void launch_softmax_fwd(int grid, hipStream_t s, const T *x, T *y, int64_t rows, int L, float scale, const unsigned char *mask, int64_t rpm) {
+    const int per = softmax_generic() ? SM_PER_LANE : (L + 63) / 64;
+#define SMF(N) softmax_fwd_kernel<T, N><<<grid, 256, 0, s>>>(x, y, rows, L, scale, mask, rpm)
+    if (per <= 1) SMF(1); else if (per == 2) SMF(2); else if (per == 3) SMF(3); else if (per <= 5) SMF(5); else if (per <= 8) SMF(8); else SMF(SM_PER_LANE);
+#undef SMF
+}
+template <typename T>
+void launch_softmax_bwd(int grid, hipStream_t s, const T *gy, const T *y, T *gx, int64_t rows, int L, float scale) {
+    const int per = softmax_generic() ? SM_PER_LANE : (L + 63) / 64;
+#define SMB(N) softmax_bwd_kernel<T, N><<<grid, 256, 0, s>>>(gy, y, gx, rows, L, scale)
+    if (per <= 1) SMB(1); else if (per == 2) SMB(2); else if (per == 3) SMB(3); else if (per <= 5) SMB(5); else if (per <= 8) SMB(8); else SMB(SM_PER_LANE);
+#undef SMB
 }
 
 // Rows longer than 64 * SM_PER_LANE (the DETR encoder at 960x1280 has 1200 keys): three streaming passes per row
@@ -724,8 +746,8 @@ extern "C" int gwd_softmax_forward(const void *x, void *y, int64_t rows, int32_t
         GWD_CHECK_LAUNCH();
         return 0;
     }
-    DISPATCH_T(dtype, (softmax_fwd_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)x, (__bf16 *)y, rows, L)),
-               (softmax_fwd_kernel<float><<<grid, 256, 0, s>>>((const float *)x, (float *)y, rows, L)));
+    DISPATCH_T(dtype, (launch_softmax_fwd<__bf16>(grid, s, (const __bf16 *)x, (__bf16 *)y, rows, L, 1.0f, nullptr, 1)),
+               (launch_softmax_fwd<float>(grid, s, (const float *)x, (float *)y, rows, L, 1.0f, nullptr, 1)));
     GWD_CHECK_LAUNCH();
     return 0;
 }
@@ -743,8 +765,8 @@ extern "C" int gwd_softmax_backward(const void *gy, const void *y, void *gx, int
         return 0;
     }
     DISPATCH_T(dtype,
-               (softmax_bwd_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)gy, (const __bf16 *)y, (__bf16 *)gx, rows, L)),
-               (softmax_bwd_kernel<float><<<grid, 256, 0, s>>>((const float *)gy, (const float *)y, (float *)gx, rows, L)));
+               (launch_softmax_bwd<__bf16>(grid, s, (const __bf16 *)gy, (const __bf16 *)y, (__bf16 *)gx, rows, L, 1.0f)),
+               (launch_softmax_bwd<float>(grid, s, (const float *)gy, (const float *)y, (float *)gx, rows, L, 1.0f)));
     GWD_CHECK_LAUNCH();
     return 0;
 }
@@ -858,8 +880,8 @@ extern "C" int gwd_softmax_masked_forward(const void *x, const uint8_t *key_mask
         GWD_CHECK_LAUNCH();
         return 0;
     }
-    DISPATCH_T(dtype, (softmax_fwd_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)x, (__bf16 *)y, rows, L, scale, key_mask, rows_per_mask)),
-               (softmax_fwd_kernel<float><<<grid, 256, 0, s>>>((const float *)x, (float *)y, rows, L, scale, key_mask, rows_per_mask)));
+    DISPATCH_T(dtype, (launch_softmax_fwd<__bf16>(grid, s, (const __bf16 *)x, (__bf16 *)y, rows, L, scale, key_mask, rows_per_mask)),
+               (launch_softmax_fwd<float>(grid, s, (const float *)x, (float *)y, rows, L, scale, key_mask, rows_per_mask)));
     GWD_CHECK_LAUNCH();
     return 0;
 }
@@ -877,8 +899,8 @@ extern "C" int gwd_softmax_scaled_backward(const void *gy, const void *y, void *
         return 0;
     }
     DISPATCH_T(dtype,
-               (softmax_bwd_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)gy, (const __bf16 *)y, (__bf16 *)gx, rows, L, scale)),
-               (softmax_bwd_kernel<float><<<grid, 256, 0, s>>>((const float *)gy, (const float *)y, (float *)gx, rows, L, scale)));
+               (launch_softmax_bwd<__bf16>(grid, s, (const __bf16 *)gy, (const __bf16 *)y, (__bf16 *)gx, rows, L, scale)),
+               (launch_softmax_bwd<float>(grid, s, (const float *)gy, (const float *)y, (float *)gx, rows, L, scale)));
     GWD_CHECK_LAUNCH();
     return 0;
 }
