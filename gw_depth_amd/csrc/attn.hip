@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int HD = 32, KPL = 5, MAXS = 64 * KPL, QB = 32;
+constexpr int HD = 32, MAXKPL = 5, MAXS = 64 * MAXKPL, QB = 32;
 
 template <typename T>
 __device__ __forceinline__ void load_row(const T *__restrict__ p, float (&r)[HD]) {
@@ -25,7 +25,8 @@ __device__ __forceinline__ void load_row(const T *__restrict__ p, float (&r)[HD]
     }
 }
 
-template <typename T>
+// KPL = keys per lane, a compile-time bound >= ceil(S / 64): 2 for the decoder's 100 queries, 5 for the 300 encoder tokens
+template <typename T, int KPL>
 __global__ __launch_bounds__(256) void mha_fwd_kernel(const T *__restrict__ q, const T *__restrict__ k, const T *__restrict__ v,
                                                       int64_t q_rs, int64_t k_rs, int64_t v_rs,
                                                       const unsigned char *__restrict__ kpm, const T *__restrict__ mult,
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const T *__restrict__ q, c
     constexpr int VEC = 16 / (int)sizeof(T);
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     T *Ks = (T *)lds_raw;
-    T *Vs = Ks + (size_t)MAXS * ROW;
+    T *Vs = Ks + (size_t)(64 * KPL) * ROW;
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // ---- K and V of this head -> LDS (rows beyond S are never read)
@@ -125,19 +126,20 @@ extern "C" int gwd_mha_forward(const void *q, const void *k, const void *v, int6
         ((uintptr_t)q % 16) || ((uintptr_t)k % 16) || ((uintptr_t)v % 16)) return -5;      // 16-byte row loads
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((L + QB - 1) / QB, B * H);
-    const size_t lds = (size_t)2 * MAXS * (HD + 16 / esz) * esz;
+    const int kpl = S <= 128 ? 2 : MAXKPL;
+    const size_t lds = (size_t)2 * 64 * kpl * (HD + 16 / esz) * esz;
+#define MHA_LAUNCH(T_, K_)                                                                                                     \
+    do {                                                                                                                       \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)mha_fwd_kernel<T_, K_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        mha_fwd_kernel<T_, K_><<<grid, 256, lds, s>>>((const T_ *)q, (const T_ *)k, (const T_ *)v, q_rs, k_rs, v_rs, key_padding_mask, \
+                                                      (const T_ *)mult, (T_ *)P, (T_ *)out, H, L, S, scale);                    \
+    } while (0)
     if (dtype == GWD_BF16) {
-        mha_fwd_kernel<__bf16><<<grid, 256, lds, s>>>((const __bf16 *)q, (const __bf16 *)k, (const __bf16 *)v, q_rs, k_rs, v_rs,
-                                                      key_padding_mask, (const __bf16 *)mult, (__bf16 *)P, (__bf16 *)out, H, L, S, scale);
+        if (kpl == 2) MHA_LAUNCH(__bf16, 2); else MHA_LAUNCH(__bf16, MAXKPL);
     } else {
-        static bool attr_set = false;                          // 92 KB of dynamic LDS has to be requested once
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)mha_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
-        mha_fwd_kernel<float><<<grid, 256, lds, s>>>((const float *)q, (const float *)k, (const float *)v, q_rs, k_rs, v_rs,
-                                                     key_padding_mask, (const float *)mult, (float *)P, (float *)out, H, L, S, scale);
+        if (kpl == 2) MHA_LAUNCH(float, 2); else MHA_LAUNCH(float, MAXKPL);
     }
+#undef MHA_LAUNCH
     GWD_CHECK_LAUNCH();
     return 0;
 }
