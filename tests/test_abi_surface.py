@@ -57,3 +57,7 @@ def test_workspace_query_needs_no_gpu():
     d4 = (ctypes.c_int64 * 4)(8, 120, 10, 160)
     assert lib.gwd_query_workspace(1, d4, 4) == 8 * 120 * 10 * 160 * 4
     assert lib.gwd_query_workspace(1, d3, 3) == -1 and lib.gwd_query_workspace(7, d3, 3) == -1
+    d2 = (ctypes.c_int64 * 2)(8, 480 * 640)                                   # GWD_WS_EVAL: 150 partial records per image
+    assert lib.gwd_query_workspace(2, d2, 2) == 8 * 150 * (10 * 8 + 4 * 8)
+    d2 = (ctypes.c_int64 * 2)(28, 480 * 640)                                  # GWD_WS_PLANE: 128 partial records per plane
+    assert lib.gwd_query_workspace(3, d2, 2) == 28 * 128 * 5 * 8 and lib.gwd_query_workspace(3, (ctypes.c_int64 * 2)(65, 100), 2) == -1
