@@ -185,6 +185,7 @@ class PlaneLoss(nn.Module):
     def __init__(self, num_ref=28, line_score_thresh=0.6, min_plane_area=100):
         super().__init__()
         self.num_ref, self.line_score_thresh, self.min_plane_area = num_ref, line_score_thresh, min_plane_area
+        self._consts = {}
 
     def forward(self, depth_pred, depth_gt, line_pred, line_score, valid_mask):
         if line_score.shape[0] != 1:
@@ -195,9 +196,12 @@ class PlaneLoss(nn.Module):
         n_planes = keep.sum().clamp(max=self.num_ref).to(torch.int32).reshape(1)          # top_num, on the device
         k = min(self.num_ref, logit.shape[0])
         ids = torch.topk(logit, k)[1]                                                     # :402 (raw class-0 logit)
-        scale = torch.tensor([W, H, W, H, W, H], dtype=torch.float32, device=line_pred.device)
+        key = (H, W, str(line_pred.device))
+        if key not in self._consts:          # built once (outside any graph capture: a host list -> device copy is not capturable)
+            self._consts[key] = (torch.tensor([W, H, W, H, W, H], dtype=torch.float32, device=line_pred.device),
+                                 torch.tensor([W - 1, H - 1] * 3, dtype=torch.float32, device=line_pred.device))
+        scale, hi = self._consts[key]
         lines = torch.round(line_pred.detach().float()[0][ids] * scale)                   # :412-414
-        hi = torch.tensor([W - 1, H - 1] * 3, dtype=torch.float32, device=lines.device)
         tri = torch.minimum(lines.clamp(min=0), hi).to(torch.int64).contiguous()          # :415-417, (k, 6)
         valid = valid_mask.reshape(H, W).to(torch.uint8).contiguous()
         return ops.plane_loss(depth_pred.float(), valid, tri, n_planes, self.min_plane_area)

@@ -286,3 +286,31 @@ def test_fused_attention_opt_in_keeps_golden_parity(golden_dir, monkeypatch):
     """GWD_FUSED_MHA=1: the DETR attention through gwd_mha_forward (ragged batch = key-padding masks) against the reference's vectors."""
     monkeypatch.setenv("GWD_FUSED_MHA", "1")
     check_train_step("ragged_b2_96x128", golden_dir, "cuda", tol=1e-3, grad_tol=5e-3)
+
+
+def test_hip_graph_step_with_plane_loss_equals_eager_step(golden_dir):
+    """--with_plane_norm_loss inside the captured step (the triangle count stays a device scalar, no host sync): the
+    graph is captured, its logged loss_plane equals the eager one, and step 1 gives the reference's number (golden case
+    plane_b1_96x128)."""
+    import numpy as np
+    from gw_depth_amd.engine import TrainStep
+    from gw_depth_amd.synth import synth_batch
+    from oracle.make_golden import CASES
+    c = CASES["plane_b1_96x128"]
+    g = np.load(golden_dir + "/plane_b1_96x128.npz")
+    b = to_device(synth_batch(c["batch"], c["height"], c["width"], seed=c["seed"], n_lines=c["n_lines"], sizes=c["sizes"]), "cuda")
+    vals = []
+    for graph in (False, True):
+        cfg, model, crits = build(device="cuda", case=c)
+        step = TrainStep(model, crits, cfg, compute_dtype=torch.float32, graph=graph)
+        per_step = []
+        for _ in range(2):
+            out, total, terms = step(b)
+            torch.cuda.synchronize()
+            per_step.append((float(total), float(terms["loss_plane"])))
+        if graph:
+            assert all(e["graph"] is not None for e in step._graphs.values()), "capture was refused"
+        vals.append(per_step)
+    for (l0, p0), (l1, p1) in zip(vals[0], vals[1]):
+        assert abs(p0 - p1) <= 1e-3 * max(1.0, abs(p0)) and abs(l0 - l1) <= 1e-3 * abs(l0)
+    assert abs(vals[1][0][1] - float(g["stat/loss_plane"])) <= 1e-3 * float(g["stat/loss_plane"])
