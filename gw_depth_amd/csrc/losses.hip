@@ -169,3 +169,92 @@ extern "C" int gwd_seg_ce_backward(const void *logits, const int64_t *target, co
     GWD_CHECK_LAUNCH();
     return 0;
 }
+
+// ----------------------------------------------------------------------------------------------------------------
+// Anchor-weighted depth of PointBasedPred (src/models/points/points_sample.py:277-279): pred[b][p] = sum_r att[b][p][r] *
+// anchor[b][r] over the S point channels - and its gradients.  The batched-GEMM library runs these matrix-VECTOR products
+// (N = 1) at 60-175 us each on a 49 MB operand; they are one streaming pass.
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void anchor_depth_fwd_kernel(const T *__restrict__ att, const float *__restrict__ anchor,
+                                                               float *__restrict__ pred, int64_t P, int R) {
+    const int b = blockIdx.y;
+    extern __shared__ float an[];
+    for (int r = threadIdx.x; r < R; r += 256) an[r] = anchor[(int64_t)b * R + r];
+    __syncthreads();
+    // 16 lanes share one pixel row (coalesced 32-byte steps along the row), four pixels per wave, DPP segment sum
+    const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4, wave = threadIdx.x >> 6;
+    const int64_t per_round = (int64_t)gridDim.x * 16;
+    const int64_t rounds = (P + per_round - 1) / per_round;
+    for (int64_t it = 0; it < rounds; ++it) {
+        const int64_t p = it * per_round + ((int64_t)blockIdx.x * 4 + wave) * 4 + grp;
+        const bool ok = p < P;
+        const T *row = att + ((int64_t)b * P + (ok ? p : 0)) * R;
+        float s = 0.f;
+        for (int r = sub; r < R; r += 16) s += to_f32(row[r]) * an[r];
+        s = segment_sum<16>(s);
+        if (ok && sub == 0) pred[(int64_t)b * P + p] = s;
+    }
+}
+
+// datt[b][p][r] = g[b][p] * anchor[b][r];  danchor[b][r] += sum_p att[b][p][r] * g[b][p]  (block partials, one atomic each)
+template <typename T>
+__global__ __launch_bounds__(256) void anchor_depth_bwd_kernel(const T *__restrict__ att, const float *__restrict__ anchor,
+                                                               const float *__restrict__ g, T *__restrict__ datt,
+                                                               float *__restrict__ danchor, int64_t P, int R) {
+    const int b = blockIdx.y;
+    extern __shared__ float sh[];
+    float *an = sh, *acc = sh + R;                       // [R] anchors, [R] partial sums of this workgroup
+    for (int r = threadIdx.x; r < R; r += 256) {
+        an[r] = anchor[(int64_t)b * R + r];
+        acc[r] = 0.f;
+    }
+    __syncthreads();
+    // thread = (pixel slot, channel r): consecutive threads walk consecutive channels of one pixel row -> coalesced
+    const int rr = threadIdx.x % R, slots = 256 / R, slot = threadIdx.x / R;
+    float mine = 0.f;
+    if (slot < slots) {
+        for (int64_t p = (int64_t)blockIdx.x * slots + slot; p < P; p += (int64_t)gridDim.x * slots) {
+            const int64_t o = ((int64_t)b * P + p) * R + rr;
+            const float gp = g[(int64_t)b * P + p];
+            mine += to_f32(att[o]) * gp;
+            if (datt) datt[o] = from_f32<T>(gp * an[rr]);
+        }
+        atomicAdd(&acc[rr], mine);
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < R; r += 256) unsafeAtomicAdd(danchor + (int64_t)b * R + r, acc[r]);
+}
+
+}  // namespace
+
+extern "C" int gwd_anchor_depth_forward(const void *att, const float *anchor, float *pred, int32_t B, int64_t P, int32_t R,
+                                        int32_t dtype, void *stream) {
+    if (!att || !anchor || !pred || B <= 0 || P <= 0 || R <= 0 || R > 256) return -1;
+    int64_t nb = (P + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    const dim3 grid((unsigned)nb, (unsigned)B);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GWD_BF16) anchor_depth_fwd_kernel<__bf16><<<grid, 256, R * sizeof(float), s>>>((const __bf16 *)att, anchor, pred, P, R);
+    else if (dtype == GWD_F32) anchor_depth_fwd_kernel<float><<<grid, 256, R * sizeof(float), s>>>((const float *)att, anchor, pred, P, R);
+    else return -2;
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gwd_anchor_depth_backward(const void *att, const float *anchor, const float *gpred, void *datt, float *danchor,
+                                         int32_t B, int64_t P, int32_t R, int32_t dtype, void *stream) {
+    if (!att || !anchor || !gpred || !danchor || B <= 0 || P <= 0 || R <= 0 || R > 256) return -1;
+    const int slots = 256 / R;
+    int64_t nb = (P + (int64_t)slots * 16 - 1) / ((int64_t)slots * 16);
+    if (nb > 512) nb = 512;
+    if (nb < 1) nb = 1;
+    const dim3 grid((unsigned)nb, (unsigned)B);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GWD_BF16) anchor_depth_bwd_kernel<__bf16><<<grid, 256, 2 * R * sizeof(float), s>>>((const __bf16 *)att, anchor, gpred, (__bf16 *)datt, danchor, P, R);
+    else if (dtype == GWD_F32) anchor_depth_bwd_kernel<float><<<grid, 256, 2 * R * sizeof(float), s>>>((const float *)att, anchor, gpred, (float *)datt, danchor, P, R);
+    else return -2;
+    GWD_CHECK_LAUNCH();
+    return 0;
+}

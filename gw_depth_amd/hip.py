@@ -30,6 +30,7 @@ ENTRY_POINTS = [
     "gwd_point_sample_forward", "gwd_point_sample_backward", "gwd_act_backward_colsum", "gwd_resample_backward_sep",
     "gwd_softmax_masked_forward", "gwd_softmax_scaled_backward", "gwd_query_workspace", "gwd_eval_accumulate", "gwd_colsum_batch", "gwd_conv_wgrad_batch",
     "gwd_plane_loss_forward", "gwd_plane_loss_backward", "gwd_collate", "gwd_mha_forward",
+    "gwd_anchor_depth_forward", "gwd_anchor_depth_backward",
 ]
 
 
@@ -135,6 +136,8 @@ class HipLibrary:
         L.gwd_collate.argtypes = [ctypes.POINTER(ImageJob), i32, i32, i32, ctypes.POINTER(ctypes.c_float),
                                   ctypes.POINTER(ctypes.c_float), vp, vp, vp, vp, i32, vp]
         L.gwd_mha_forward.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]
+        L.gwd_anchor_depth_forward.argtypes = [vp, vp, vp, i32, i64, i32, i32, vp]
+        L.gwd_anchor_depth_backward.argtypes = [vp, vp, vp, vp, vp, i32, i64, i32, i32, vp]
         L.gwd_colsum_batch.argtypes = [ctypes.POINTER(ColsumJob), i32, i32, vp]
         L.gwd_layernorm_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
         L.gwd_layernorm_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
@@ -333,6 +336,15 @@ class HipLibrary:
                                              q.stride(1), k.stride(1), v.stride(1), _ptr(key_padding_mask), _ptr(mult), _ptr(P),
                                              _ptr(out), B, H, L, S, float(scale), dtype_code(q),
                                              self._stream(q, k, v, key_padding_mask, mult, P, out)), "gwd_mha_forward")
+
+    def anchor_depth_forward(self, att, anchor, pred, B, P, R):
+        self._check(self.lib.gwd_anchor_depth_forward(_ptr(att), _ptr(anchor), _ptr(pred), B, P, R, dtype_code(att),
+                                                      self._stream(att, anchor, pred)), "gwd_anchor_depth_forward")
+
+    def anchor_depth_backward(self, att, anchor, gpred, datt, danchor, B, P, R):
+        self._check(self.lib.gwd_anchor_depth_backward(_ptr(att), _ptr(anchor), _ptr(gpred), _ptr(datt), _ptr(danchor), B, P, R,
+                                                       dtype_code(att), self._stream(att, anchor, gpred, datt, danchor)),
+                    "gwd_anchor_depth_backward")
 
     def silog_sums(self, pred, gt, sums, B, h, w, H, W, log_err):
         self._check(self.lib.gwd_silog_sums(_ptr(pred), _ptr(gt), _ptr(sums), B, h, w, H, W, int(log_err),

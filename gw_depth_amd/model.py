@@ -8,6 +8,7 @@ through gw_depth_amd.ops (hand-written gfx950 kernels behind the C ABI); torch i
 memory, autograd bookkeeping and small index plumbing (pad / roll / gather).
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -568,7 +569,10 @@ class PointBasedPred(nn.Module):
         # NB: when H or W < 16 the pyramid zero-pads its map and the reference keeps the padded size (:94-125)
         att = ops.softmax_lastdim(self.pyramid(rg.view(B, H, W, -1)))
         Ho, Wo, R = att.shape[1], att.shape[2], att.shape[3]
-        pred = torch.bmm(att.float().view(B, Ho * Wo, R), anchor.view(B, R, 1))         # sum_r att * anchor depth
+        if R <= 256 and os.environ.get("GWD_ANCHOR_FUSED", "1") != "0":
+            pred = ops.anchor_depth(att.view(B, Ho * Wo, R), anchor.view(B, R))          # sum_r att * anchor depth, one pass
+        else:
+            pred = torch.bmm(att.float().view(B, Ho * Wo, R), anchor.view(B, R, 1))
         return pred.view(B, 1, Ho, Wo)                                                  # (B,1,H',W') fp32
 
 

@@ -866,6 +866,33 @@ class _InormGeluFn(torch.autograd.Function):
         return gy, du, None
 
 
+class _AnchorDepthFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, att, anchor):
+        B, P, R = att.shape
+        att = att.contiguous()
+        anchor = anchor.float().contiguous()
+        pred = torch.empty((B, P), dtype=torch.float32, device=att.device)
+        _lib().anchor_depth_forward(att, anchor, pred, B, P, R)
+        ctx.save_for_backward(att, anchor)
+        return pred
+
+    @staticmethod
+    def backward(ctx, g):
+        att, anchor = ctx.saved_tensors
+        B, P, R = att.shape
+        datt = torch.empty_like(att) if ctx.needs_input_grad[0] else None
+        danchor = torch.zeros((B, R), dtype=torch.float32, device=att.device)
+        _lib().anchor_depth_backward(att, anchor, g.float().contiguous(), datt, danchor, B, P, R)
+        return datt, danchor
+
+
+def anchor_depth(att, anchor):
+    """sum_r att[b,p,r] * anchor[b,r] (points_sample.py:277-279): att (B,P,R) softmax over the point channels, anchor (B,R) fp32
+    -> (B,P) fp32; one streaming kernel each way instead of matrix-vector products in the batched-GEMM library."""
+    return _AnchorDepthFn.apply(att, anchor)
+
+
 class _PlaneLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, depth, valid, tri, n_planes, min_area):

@@ -164,6 +164,14 @@ int gwd_seg_ce_sum(const void *logits, const int64_t *target, double *sum, int64
 int gwd_seg_ce_backward(const void *logits, const int64_t *target, const float *gloss, float scale,
                         void *glogits, int64_t P, int32_t dtype, void *stream);
 
+/* Anchor-weighted depth of PointBasedPred (src/models/points/points_sample.py:277-279): pred[b][p] = sum_r att[b][p][r] *
+ * anchor[b][r]  (att [B][P][R] dtype = the softmax over the R point channels, anchor [B][R] fp32, pred [B][P] fp32), R <= 256.
+ * backward: datt[b][p][r] = gpred[b][p] * anchor[b][r] (dtype, may be NULL), danchor [B][R] fp32 ACCUMULATED (caller zeroes). */
+int gwd_anchor_depth_forward(const void *att, const float *anchor, float *pred, int32_t B, int64_t P, int32_t R,
+                             int32_t dtype, void *stream);
+int gwd_anchor_depth_backward(const void *att, const float *anchor, const float *gpred, void *datt, float *danchor,
+                              int32_t B, int64_t P, int32_t R, int32_t dtype, void *stream);
+
 /* A (window, token, head, channel) operand: element = p[w*ws + t*ts + h*hs + d], channel stride 1.      */
 typedef struct {
     void *p;

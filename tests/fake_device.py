@@ -199,6 +199,15 @@ class FakeDevice:
         pd = p.float() if mult is None else p.float() * mult.float()
         out.copy_((pd @ vh).transpose(1, 2).reshape(B, L, H * hd))
 
+    def anchor_depth_forward(self, att, anchor, pred, B, P, R):
+        pred.copy_((att.float().reshape(B, P, R) * anchor.reshape(B, 1, R)).sum(-1))
+
+    def anchor_depth_backward(self, att, anchor, gpred, datt, danchor, B, P, R):
+        g = gpred.reshape(B, P, 1).float()
+        if datt is not None:
+            datt.copy_((g * anchor.reshape(B, 1, R)).to(datt.dtype).reshape(datt.shape))
+        danchor.add_((att.float().reshape(B, P, R) * g).sum(1).reshape(danchor.shape))
+
     def collate(self, samples, H, W, mean, std, images, mask, depth, seg):
         """gwd_collate in torch (transforms_depth.py:618-660, glassrgbd_norhint.py:277-281, util/misc.py:273-313)."""
         m, s_ = torch.tensor(mean, dtype=torch.float32), torch.tensor(std, dtype=torch.float32)

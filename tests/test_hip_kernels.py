@@ -635,3 +635,23 @@ def test_mha_forward(dev, shape, dtype):
     with pytest.raises(RuntimeError):                                   # 321 keys: not covered, the caller keeps the GEMM path
         dev.mha_forward(q.cuda().contiguous(), torch.zeros(B, 321, E, dtype=dtype).cuda(), torch.zeros(B, 321, E, dtype=dtype).cuda(), None, None,
                         torch.empty(B, H, L, 321, dtype=dtype).cuda(), o, B, H, L, 321, 1.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(8, 19200, 80), (2, 4800, 30), (1, 37, 7), (3, 1000, 256)])
+def test_anchor_depth(dev, shape, dtype):
+    """gwd_anchor_depth_forward / _backward vs torch math (pred = sum_r att * anchor; datt, accumulated danchor)."""
+    B, P, R = shape
+    fake = FakeDevice()
+    att = torch.softmax(rnd(B, P, R, seed=1), -1).to(dtype)
+    anchor = rnd(B, R, seed=2) + 3.0
+    g = rnd(B, P, seed=3)
+    pred_r, datt_r, dan_r = torch.empty(B, P), torch.empty(B, P, R, dtype=dtype), rnd(B, R, seed=4)
+    dan = dan_r.clone().cuda()
+    fake.anchor_depth_forward(att, anchor, pred_r, B, P, R)
+    fake.anchor_depth_backward(att, anchor, g, datt_r, dan_r, B, P, R)
+    pred, datt = torch.empty(B, P).cuda(), torch.empty(B, P, R, dtype=dtype).cuda()
+    dev.anchor_depth_forward(att.cuda(), anchor.cuda(), pred, B, P, R)
+    dev.anchor_depth_backward(att.cuda(), anchor.cuda(), g.cuda(), datt, dan, B, P, R)
+    torch.cuda.synchronize()
+    assert rel(pred, pred_r) < 2e-5 and rel(datt, datt_r) < TOL[dtype] and rel(dan, dan_r) < 2e-5
