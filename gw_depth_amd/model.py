@@ -331,13 +331,18 @@ def relative_position_index():
 
 
 class WindowAttnBase(nn.Module):
-    def __init__(self, dim):
+    def __init__(self, dim, border=False):
         super().__init__()
         self.dim = dim
         self.scale = (dim // HEADS) ** -0.5
+        # registration order = the reference's (multiscale_transformerr.py:222-247, 401-410): torch.optim state dicts are
+        # positional, so optimizer checkpoints only interchange if named_parameters() enumerates in the same order
         self.diff_mu = nn.Parameter(torch.randn(1, 1, dim))
         self.diff_logsigma = nn.Parameter(torch.zeros(1, 1, dim))
         nn.init.xavier_uniform_(self.diff_logsigma)
+        if border:
+            self.border_mu = nn.Parameter(torch.randn(1, 1, dim))
+            self.border_logsigma = nn.Parameter(torch.zeros(1, 1, dim))
         self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * WS - 1) ** 2, HEADS))
         nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
         self.register_buffer("relative_position_index", relative_position_index())
@@ -387,9 +392,7 @@ class WindowClassAttention(WindowAttnBase):
     group_attention=False).  border_* and proj_seg exist for state-dict parity and never get a gradient."""
 
     def __init__(self, dim, tdim):
-        super().__init__(dim)
-        self.border_mu = nn.Parameter(torch.randn(1, 1, dim))
-        self.border_logsigma = nn.Parameter(torch.zeros(1, 1, dim))
+        super().__init__(dim, border=True)
         self.cls_dth_q, self.cls_seg_q = Linear(tdim, tdim), Linear(tdim, tdim)
         self.global_k, self.global_v = Linear(dim + 2 * tdim, dim + 2 * tdim), Linear(dim + 2 * tdim, dim + 2 * tdim)
         self.proj_dth, self.proj_seg = Linear(tdim, tdim), Linear(tdim, tdim)
@@ -715,13 +718,14 @@ class DensePrediction(nn.Module):
         self.max_depth = max_depth
         self.depth_token_fuse = Mlp(feat + 1 + tdim, None, tdim)
         self.seg_token_fuse = Mlp(feat + tdim, None, tdim)
-        for tag in ("depth", "seg"):
+        for tag in ("depth", "seg"):                      # registration order of dense_upsample.py:131-158
             setattr(self, f"upconv1_{tag}", UpConv(tdim, tdim))
             setattr(self, f"norm_{tag}", LayerNorm(tdim))
             setattr(self, f"conv1_{tag}", Seq(_0=Conv(tdim, tdim, 3)))
             setattr(self, f"upconv2_{tag}", UpConv(tdim, tdim // 2))
             setattr(self, f"conv2_{tag}", Seq(_0=Conv(tdim // 2, tdim // 2, 3)))
-        self.get_depth = Seq(_0=Conv(tdim // 2, 1, 3))
+            if tag == "depth":
+                self.get_depth = Seq(_0=Conv(tdim // 2, 1, 3))
         self.get_seg = Conv(tdim // 2, 2, 3)
 
     def fuse_padded(self, x):

@@ -52,10 +52,34 @@ def _fake_grads(step, seed):
         step.flat_g[o:o + p.numel()].copy_(r[o:o + p.numel()])
 
 
+def reference_parameter_order():
+    """named_parameters() order of the REFERENCE model: its state-dict key order (tests/golden/state_dict_spec.json, dumped from
+    the reference's build_model) restricted to parameters (tests/golden/param_sets.json)."""
+    import json
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = json.load(open(os.path.join(here, "state_dict_spec.json")))
+    sets = json.load(open(os.path.join(here, "param_sets.json")))
+    params, trainable = set(sets["parameters"]), set(sets["trainable"])
+    return [k for k in spec if k in params], [k for k in spec if k in trainable]
+
+
+def test_parameter_registration_order_is_the_references():
+    """torch.optim state dicts are positional: optimizer checkpoints interchange only if named_parameters() enumerates exactly
+    as the reference's model does (border_* before relative_position_bias_table, get_depth before the *_seg modules)."""
+    _, model, _ = build()
+    every, trainable = reference_parameter_order()
+    assert [n for n, _ in model.named_parameters()] == every
+    assert [n for n, p in model.named_parameters() if p.requires_grad] == trainable
+    import json
+    spec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "state_dict_spec.json")))
+    assert list(model.state_dict().keys()) == list(spec.keys())
+
+
 def _reference_adamw(model, cfg):
-    """A real torch.optim.AdamW over reference-layout copies of the parameters, grouped as main_glassrgbd.py:59-66."""
+    """A real torch.optim.AdamW over reference-layout copies of the parameters, grouped as main_glassrgbd.py:59-66 and
+    enumerated in the REFERENCE's parameter order (not the product model's own)."""
     sd = model.state_dict()                                              # reference layout (Cout,Cin,KH,KW)
-    named = [(n, torch.nn.Parameter(sd[n].detach().clone())) for n, p in model.named_parameters() if p.requires_grad]
+    named = [(n, torch.nn.Parameter(sd[n].detach().clone())) for n in reference_parameter_order()[1]]
     groups = [{"params": [p for n, p in named if "backbone" not in n]},
               {"params": [p for n, p in named if "backbone" in n], "lr": cfg.lr_backbone}]
     return named, torch.optim.AdamW(groups, lr=cfg.lr, weight_decay=cfg.weight_decay)
