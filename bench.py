@@ -4,10 +4,17 @@
 fp32 accumulate (BASELINE.json configs[1]).  One process per GPU; prints ONE JSON line on rank 0.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 8] [--dtype bf16|fp32] [--no-cpu-baseline]
+
+`--gpus N` with N > 1 and no launcher environment (WORLD_SIZE unset): this process starts N child ranks of itself
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set, one per GPU, RCCL) BEFORE touching the GPU,
+forwards rank 0's JSON line and exits with the worst child status.  Under `python -m torch.distributed.run` the ranks
+already exist and the environment is used as is.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -17,6 +24,9 @@ sys.path.insert(0, ROOT)
 import torch
 import torch.distributed as dist
 
+# "nccl" is RCCL on ROCm.  GWD_BENCH_BACKEND=gloo is a REHEARSAL switch only: it lets several ranks share one GPU (RCCL refuses
+# two ranks on one device), which is how the launcher / DDP path is exercised on a one-GPU box; never a measurement.
+BACKEND = os.environ.get("GWD_BENCH_BACKEND", "nccl")
 PEAK_MFMA_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBPS = 8000.0
 STEP_GFLOP_PER_IMAGE = 1049.5      # fwd + losses + bwd, conv/mm/addmm/bmm only
@@ -36,8 +46,43 @@ def parse():
     ap.add_argument("--no-graph", dest="graph", action="store_false",
                     help="launch every kernel eagerly instead of replaying zero_grad+forward+losses+backward from one HIP graph")
     ap.add_argument("--cpu-baseline-budget-s", type=float, default=25.0)
-    ap.add_argument("--kernel-timing", action="store_true", default=True)
+    ap.add_argument("--segments", action="store_true",
+                    help="cut the captured step at gradient-bucket boundaries even on one GPU (what N > 1 does for the overlap)")
+    ap.add_argument("--bucket-mb", type=float, default=32.0)
     return ap.parse_args()
+
+
+def launch_ranks(a):
+    """Parent of a `--gpus N` run without a launcher: N children of this very script, one per GPU.  Nothing here initialises
+    the GPU (torch.cuda.device_count() does not, on this image); no exec from a GPU process anywhere."""
+    n = torch.cuda.device_count()
+    if n < a.gpus and BACKEND == "nccl":
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (a.gpus, n))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst, deadline = 0, None
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            rc = p.poll()
+            if rc is None:
+                continue
+            alive.remove(p)
+            if rc != 0:
+                worst = worst or rc
+                deadline = deadline or time.time() + 30.0      # a rank died: the others hang in a collective - give them 30 s
+        if deadline is not None and time.time() > deadline:
+            for p in alive:
+                p.kill()                                       # exact PIDs of our own children
+    raise SystemExit(worst)
 
 
 def cpu_baseline(sd_cpu, cfg, budget_s):
@@ -102,15 +147,23 @@ def depth_rmse_leg(sd_cpu, cfg, dtype):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(a)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and rank == 0:
+        print("[bench] --gpus %d but the launcher started %d rank(s): reporting n_gpus = %d" % (a.gpus, world, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    local = local % torch.cuda.device_count() if BACKEND != "nccl" else local
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if BACKEND == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(BACKEND, rank=rank, world_size=world)
 
     from gw_depth_amd import Config, build_model, hip
     from gw_depth_amd.engine import TrainStep
@@ -125,7 +178,8 @@ def main():
     model.cuda()
     crits[0].cuda()
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    step = TrainStep(model, crits, cfg, compute_dtype=dtype, graph=a.graph)
+    step = TrainStep(model, crits, cfg, compute_dtype=dtype, graph=a.graph, bucket_mb=a.bucket_mb,
+                     segments=True if a.segments else None)
     b = synth_batch(a.batch, a.height, a.width, seed=1 + rank)                                   # data seed 1 + rank
     batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
     batch["targets"] = [{k: v.cuda() for k, v in t.items()} for t in b["targets"]]
@@ -152,6 +206,28 @@ def main():
     el = float(t.item())
     ips = a.batch * world * a.steps / el
 
+    comm = None
+    if world > 1:
+        # exposed communication: the same K steps with the bucket all-reduces switched off (every rank does this together);
+        # outside the timed region, reported beside the number, not part of it
+        try:
+            launch, step._launch = step._launch, (lambda bi: None)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                step(batch)
+            step.flush()
+            barrier()
+            t = torch.tensor([time.perf_counter() - t1], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            step._launch = launch
+            ms_off = 1000 * float(t.item()) / a.steps
+            comm = {"ms_per_step_without_allreduce": round(ms_off, 3), "exposed_allreduce_ms": round(1000 * el / a.steps - ms_off, 3),
+                    "allreduce_mb_per_step": round(step.total * 4 / 1e6, 1), "reduce_dtype": "fp32", "backend": BACKEND,
+                    "overlap": "graph chain cut at bucket boundaries" if a.graph else "post-accumulate hooks"}
+        except Exception as exc:        # never let the side measurement take the bench line down
+            comm = {"error": repr(exc)}
+
     roofline = None
     if rank == 0:
         roofline = dominant_kernel_roofline(lib, dtype)
@@ -165,10 +241,14 @@ def main():
                    "global_batch": a.batch * world, "parallelism": "dp%d" % world,
                    "step_gflop_per_image": STEP_GFLOP_PER_IMAGE,
                    "whole_step_mfma_frac": round(ips / world * STEP_GFLOP_PER_IMAGE / 1000.0 / PEAK_MFMA_BF16_TFLOPS, 5),
-                   "launch": "hipgraph" if a.graph and all(e["graph"] is not None for e in step._graphs.values()) else "eager",
+                   "launch": "hipgraph" if a.graph and step._graphs and all(e["graph"] is not None for e in step._graphs.values()) else "eager",
+                   "graph_segments": max([len(e["graph"]) for e in step._graphs.values() if e["graph"] is not None] or [0]),
+                   "grad_buckets": len(step.buckets),
                    "final_loss": round(float(total), 4)},
         "roofline": roofline,
     }
+    if comm is not None:
+        out["comm"] = comm
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         print("[bench] GPU leg done: %.2f images/s; timing the CPU baseline (oracle) ..." % ips, file=sys.stderr, flush=True)
         out["cpu_baseline"] = cpu_baseline(sd_cpu, cfg, a.cpu_baseline_budget_s)

@@ -99,32 +99,39 @@ class SetCriterion(nn.Module):
     def forward_packed(self, outputs, packed, world=1):
         """Same losses as forward(), with no host round trip: cost matrices of all decoder layers, the device LSAP
         (gwd_lsap) and the 2 x layers loss terms are computed from static-shape device tensors, so the whole step can be
-        captured in a HIP graph.  `packed` comes from pack_targets(); packed["num_items"] must already hold the
-        GLOBAL target count when world > 1 (the caller all-reduces it outside the captured region)."""
+        captured in a HIP graph.  `packed` comes from pack_targets(): the targets of the batch concatenated and PADDED to a
+        fixed capacity, with the per-image column offsets, the image index of every column and the padding mask as DEVICE
+        data - the shapes (and so a captured graph) do not depend on how many lines each image has.  packed["num_items"] must
+        already hold the GLOBAL target count when world > 1 (the caller all-reduces it outside the captured region)."""
         from . import hip
         layers = [outputs] + list(outputs.get("aux_outputs", []))
         logits = torch.stack([o["pred_logits"] for o in layers]).float()               # (L,B,Q,2)
         lines = torch.stack([o["pred_lines"] for o in layers]).float()                 # (L,B,Q,6)
         L_, B, Q, _ = logits.shape
-        sumT = packed["lines"].shape[0]
+        cap = packed["lines"].shape[0]
+        meta = packed["meta"]                                                          # int32: col_off (B+1) | image of column (cap) | valid (cap)
+        col_off, bidx, valid = meta[:B + 1], meta[B + 1:B + 1 + cap].long(), meta[B + 1 + cap:].float()
         with torch.no_grad():                                                          # matcher.py:52-70
             prob = logits.softmax(-1)
             # L1 distances as one broadcast |a - b| summed over the 6 coordinates (aten::cdist takes 158 us for this 48x100x56 problem)
             l1 = (lines.reshape(L_ * B, Q, 1, -1) - packed["lines"][None, None]).abs().sum(-1)
             cost = self.matcher.cost_line * l1 + self.matcher.cost_class * (-prob.reshape(L_ * B, Q, -1)[..., packed["labels"]])
-            qot = torch.empty((L_, sumT), dtype=torch.int32, device=logits.device)
-            hip.library().lsap(cost.reshape(L_, B, Q, sumT).contiguous(), packed["col_off"], qot, max(packed["sizes"]))
+            qot = torch.empty((L_, cap), dtype=torch.int32, device=logits.device)
+            # per-image target counts are read from col_off ON THE DEVICE; padding columns come back as query Q (a dummy slot)
+            hip.library().lsap(cost.reshape(L_, B, Q, cap).contiguous(), col_off, qot, hip.LSAP_MAX_TARGETS)
             qi = qot.long()
         self.last_query_of_target = qi
         li = torch.arange(L_, device=logits.device)[:, None]
-        bi = packed["bidx"][None].expand(L_, -1)
-        tc = torch.full((L_, B, Q), self.num_classes, dtype=torch.int64, device=logits.device)
-        tc[li, bi, qi] = packed["labels"][None].expand(L_, -1)
+        bi = bidx[None].expand(L_, -1)
+        tc = torch.full((L_, B, Q + 1), self.num_classes, dtype=torch.int64, device=logits.device)
+        tc[li, bi, qi] = packed["labels"][None].expand(L_, -1)                         # padding columns land in the dummy slot Q
+        tc = tc[:, :, :Q]
         nll = F.cross_entropy(logits.reshape(L_ * B, Q, -1).transpose(1, 2), tc.reshape(L_ * B, Q), reduction="none")
         w = self.empty_weight[tc.reshape(L_ * B, Q)]
         ce = (nll * w).reshape(L_, -1).sum(1) / w.reshape(L_, -1).sum(1)                  # weighted mean per layer (:168)
         num_items = torch.clamp(packed["num_items"] / world, min=1.0)
-        l1 = (lines[li, bi, qi] - packed["lines"][None]).abs().sum(dim=(1, 2)) / num_items   # (:239-242)
+        diff = (lines[li, bi, qi.clamp(max=Q - 1)] - packed["lines"][None]).abs().sum(-1)  # (L, cap)
+        l1 = (diff * valid[None]).sum(1) / num_items                                       # (:239-242), padding masked out
         losses = {"loss_ce": ce[0], "loss_line": l1[0]}
         for i in range(L_ - 1):
             losses[f"loss_ce_{i}"] = ce[i + 1]
@@ -146,18 +153,77 @@ class SetCriterion(nn.Module):
         return losses
 
 
-def pack_targets(targets, device):
-    """Static device-side form of the per-image target lists for the sync-free criterion: concatenated lines /
-    labels, the image index of every target and the column offsets of each image's block in the cost matrix."""
-    sizes = [int(len(t["labels"])) for t in targets]
-    off = [0]
-    for s in sizes:
-        off.append(off[-1] + s)
-    bidx = torch.cat([torch.full((s,), i, dtype=torch.int64) for i, s in enumerate(sizes)]) if off[-1] else torch.zeros(0, dtype=torch.int64)
-    return {"lines": torch.cat([t["lines"] for t in targets]).to(device).float().contiguous(),
-            "labels": torch.cat([t["labels"] for t in targets]).to(device),
-            "bidx": bidx.to(device), "col_off": torch.tensor(off, dtype=torch.int32, device=device),
-            "sizes": sizes, "num_items": torch.tensor([float(max(off[-1], 0))], device=device)}
+def target_capacity(total):
+    """Padded column count for `total` targets: powers of two from 64 - a handful of distinct static shapes overall."""
+    cap = 64
+    while cap < total:
+        cap *= 2
+    return cap
+
+
+class PackedTargets(dict):
+    """Static-shape device form of a batch's line targets for SetCriterion.forward_packed.
+
+    lines (cap,6) fp32, labels (cap,) int64, meta int32 [col_off (B+1) | image index of every column (cap) | valid (cap)],
+    num_items (1,) fp32.  `cap` depends only on the size class of the batch's TOTAL target count, so a HIP graph captured over
+    these tensors serves every batch of that class whatever the per-image counts are (the reference's dataset has a different
+    number of lines in every image, glassrgbd_norhint.py:184-205).  update() refreshes the contents without a host round
+    trip: device->device copies of the line data, the host-known bookkeeping through a small ring of pinned buffers."""
+    RING = 8
+
+    def __init__(self, batch_size, cap, device):
+        super().__init__()
+        self.B, self.cap, self.device = int(batch_size), int(cap), torch.device(device)
+        self["lines"] = torch.zeros((cap, 6), dtype=torch.float32, device=device)
+        self["labels"] = torch.zeros((cap,), dtype=torch.int64, device=device)
+        self["meta"] = torch.zeros((self.B + 1 + 2 * cap,), dtype=torch.int32, device=device)
+        self["num_items"] = torch.zeros((1,), dtype=torch.float32, device=device)
+        self._ring, self._slot = [], 0
+
+    def _staging(self):
+        if self.device.type != "cuda":
+            return torch.zeros_like(self["meta"], device="cpu"), None
+        if len(self._ring) < self.RING:
+            self._ring.append([torch.zeros(self["meta"].shape, dtype=torch.int32, pin_memory=True), None])
+            ent = self._ring[-1]
+        else:
+            ent = self._ring[self._slot % self.RING]
+            if ent[1] is not None:
+                ent[1].synchronize()               # the copy issued RING updates ago has long finished
+        self._slot += 1
+        return ent[0], ent
+
+    def update(self, targets):
+        sizes = [int(len(t["labels"])) for t in targets]
+        total = sum(sizes)
+        if len(sizes) != self.B or total > self.cap:
+            raise ValueError("PackedTargets(B=%d, cap=%d) cannot hold %r" % (self.B, self.cap, sizes))
+        host, ent = self._staging()
+        B, cap = self.B, self.cap
+        host.zero_()
+        off = 0
+        for i, n in enumerate(sizes):
+            host[i] = off
+            host[B + 1 + off:B + 1 + off + n] = i
+            off += n
+        host[B] = off
+        host[B + 1 + cap:B + 1 + cap + total] = 1
+        self["meta"].copy_(host, non_blocking=True)
+        if ent is not None:
+            ent[1] = torch.cuda.Event()
+            ent[1].record()
+        if total:
+            self["lines"][:total].copy_(torch.cat([t["lines"] for t in targets]).to(self.device), non_blocking=True)
+            self["labels"][:total].copy_(torch.cat([t["labels"] for t in targets]).to(self.device), non_blocking=True)
+        self["num_items"].fill_(float(total))
+        self.sizes = sizes
+        return self
+
+
+def pack_targets(targets, device, cap=None):
+    """PackedTargets of one batch (capacity: target_capacity(total) unless given)."""
+    total = sum(int(len(t["labels"])) for t in targets)
+    return PackedTargets(len(targets), cap if cap is not None else target_capacity(total), device).update(targets)
 
 
 class SilogLoss(nn.Module):

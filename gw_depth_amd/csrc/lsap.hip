@@ -16,7 +16,10 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float *__restrict__ cost
     __shared__ int path[MAXQ], row4col[MAXQ], col4row[MAXT];
     __shared__ unsigned char SC[MAXQ], SR[MAXT];
     const int layer = blockIdx.x / B, b = blockIdx.x % B, lane = threadIdx.x;
-    const int c0 = col_off[b], T = col_off[b + 1] - c0;
+    const int c0 = col_off[b];
+    int T = col_off[b + 1] - c0;
+    if (T > MAXT) T = MAXT;              // the counts are device data: never index past the LDS tables (the host checks them too)
+    if (T < 0) T = 0;
     const float *C = cost + ((size_t)layer * B + b) * Q * sumT + c0;      // element (q, t) at C[q * sumT + t]
     for (int j = lane; j < Q; j += 64) {
         v[j] = 0.0;
@@ -93,6 +96,8 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float *__restrict__ cost
         __syncthreads();
     }
     for (int t = lane; t < T; t += 64) query_of_target[(size_t)layer * sumT + c0 + t] = col4row[t];
+    if (b == B - 1)                      // padding columns of a fixed-capacity target table: the dummy query slot Q
+        for (int t = col_off[B] + lane; t < sumT; t += 64) query_of_target[(size_t)layer * sumT + t] = Q;
 }
 
 }  // namespace

@@ -6,25 +6,45 @@ optimizer / DDP setup of /root/reference/src/main_glassrgbd.py:46-67, re-laid fo
 * all trainable parameters, their gradients and both Adam moments live in four flat fp32 HBM
   buffers (plus a bf16 shadow of the parameters when activations are bf16), so zero_grad is one
   memset, the global-norm is one reduction and clip+AdamW is one streaming kernel per LR group;
-* data parallelism is one process per GPU: the flat gradient buffer is cut into contiguous buckets
-  in (approximate) backward order and each bucket is all-reduced over RCCL as soon as the last of its
-  live parameters has accumulated its gradient, overlapping with the rest of backward; the 54
-  parameters that never receive a gradient are learned on the first step and simply
-  stay zero — no find_unused_parameters graph walk, no buffer broadcasts.
+* data parallelism is one process per GPU: rank 0's parameters and buffers are broadcast at construction
+  (as DistributedDataParallel does, main_glassrgbd.py:46); the flat gradient buffer is cut into
+  contiguous buckets in (approximate) backward order and EVERY rank all-reduces EVERY bucket exactly
+  once per step in bucket-index order - a bucket leaves as soon as it and all buckets before it are
+  complete, overlapping with the rest of backward.  The collective sequence of a step is therefore the
+  same on every rank whatever its data, launch mode (eager / HIP graph / refused capture) or cache
+  state.  The 54 parameters that never receive a gradient sit at the end of their LR
+  group, where nothing waits for them - no find_unused_parameters graph walk.
+* HIP-graph mode captures zero_grad + forward + 17 losses + backward as a CHAIN of graphs cut at bucket
+  boundaries: after graph k has been enqueued its buckets go to the communication stream while graph
+  k+1 runs, so the gradient all-reduce overlaps with backward in the replayed step as well.
 """
+import gc
 import math
+import os
 import warnings
+from collections import OrderedDict
 
 import torch
 import torch.distributed as dist
 
 from . import hip, ops
-from .criteria import pack_targets
+from .criteria import PackedTargets, target_capacity
 from .model import NestedTensor
 
 FORWARD_ORDER = ["backbone", "input_proj", "query_embed", "transformer", "class_embed", "lines_embed",
                  "dense_input_proj", "dense_encoder", "depth_decoder"]
 ALIGN = 8   # elements: keeps every bf16 shadow slice 16-byte aligned
+# trainable tensors no forward ever touches (SURVEY.md §3.5, 54 tensors; tests/test_product_wiring.py checks the list against
+# the reference's own backward): they are laid out behind the live parameters of their LR group so that no bucket waits for them
+NEVER_USED = ("border_mu", "border_logsigma", ".proj_seg.", ".pyramid.layer4.", ".pre_depth_pred.", ".depth_pred4.", ".depth_pred32.")
+
+
+def never_used(name):
+    """True for the trainable tensors that receive no gradient in any step (dead code of the reference kept for state-dict
+    parity: glassrgbd.py / multiscale_transformerr.py build them, no forward reads them; the 1/32 depth map feeds only the
+    gradient-free CertainSample).  A wrong answer here costs overlap, never correctness: see TrainStep._bucket_ready."""
+    return any(k in name for k in NEVER_USED) or ("class_transformer" in name and (".diff_mu" in name or ".diff_logsigma" in name))
+MAX_GRAPHS = 6          # captured batch signatures kept (least recently used goes first); all share one memory pool
 
 
 def _align(n):
@@ -33,16 +53,17 @@ def _align(n):
 
 class TrainStep:
     def __init__(self, model, criterions, cfg, compute_dtype=torch.float32, bucket_mb=32.0, process_group=None,
-                 check_finite=True, data_parallel=True, graph=False):
+                 check_finite=True, data_parallel=True, graph=False, segments=None):
         self.model, self.cfg = model, cfg
         self.criterion, self.criterion_depth, self.criterion_seg, self.criterion_plane = criterions
         self.compute_dtype = compute_dtype
         model.compute_dtype = compute_dtype
         self.check_finite = check_finite
         self.device_matcher = True        # gwd_lsap + sync-free criterion (taps / teacher-forced tests use the host matcher)
-        self._pack_cache = {}
-        self.use_graph = bool(graph)      # capture zero_grad+forward+losses+backward of a batch signature in one HIP graph
-        self._graphs = {}
+        self._packs = {}                  # (batch size, capacity) -> PackedTargets of the eager path
+        self.use_graph = bool(graph)      # capture zero_grad+forward+losses+backward of a batch signature as a chain of HIP graphs
+        self._graphs = OrderedDict()
+        self._pool = None
         self._gstream = None
         self._pending_checks = []
         self.weights = None           # built after the parameters moved into the flat buffer
@@ -50,6 +71,8 @@ class TrainStep:
         self.world = dist.get_world_size(process_group) if (data_parallel and dist.is_available() and dist.is_initialized()) else 1
         # the line-loss normaliser is the GLOBAL target count / world whenever a process group exists (glassrgbd.py:323-326)
         self.norm_world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        # cut the captured step at bucket boundaries (needed for the overlap when world > 1; may be forced for measurements)
+        self.segments = (self.world > 1) if segments is None else bool(segments)
         self.step_count = 0
 
         named = dict(model.named_parameters())
@@ -58,9 +81,12 @@ class TrainStep:
             order += [n for n in named if n.split(".")[0] == top and named[n].requires_grad]
         assert len(order) == sum(p.requires_grad for p in named.values()), "FORWARD_ORDER misses a top-level module"
         order.reverse()                                   # ~ the order in which backward produces gradients
-        head = [n for n in order if "backbone" not in n]  # LR group 0 (main_glassrgbd.py:59-64)
-        tail = [n for n in order if "backbone" in n]      # LR group 1: lr_backbone
+        live = [n for n in order if not never_used(n)]
+        idle = [n for n in order if never_used(n)]
+        head = [n for n in live if "backbone" not in n] + [n for n in idle if "backbone" not in n]   # LR group 0 (main_glassrgbd.py:59-64)
+        tail = [n for n in live if "backbone" in n] + [n for n in idle if "backbone" in n]           # LR group 1: lr_backbone
         self.names = head + tail
+        self.idle = set(idle)
         offs, off = {}, 0
         for n in self.names:
             offs[n] = off
@@ -85,13 +111,15 @@ class TrainStep:
             p._gwd_grad = p.grad          # kernels accumulate weight/bias/LN gradients straight into the flat buffer
             p._gwd_hook = None
             self.params[n] = p
+        if self.world > 1:
+            self._broadcast_from_rank0()
         if self.flat_p16 is not None:
             self.flat_p16.copy_(self.flat_p)
         spans = [(self.flat_p.data_ptr(), self.flat_p.data_ptr() + self.flat_p.numel() * 4)]
         spans += [(p.data_ptr(), p.data_ptr() + p.numel() * p.element_size()) for p in model.parameters() if not p.requires_grad]
         self.weights = ops.WeightCache(spans)
 
-        # ---- bucket plan: contiguous flat ranges of ~bucket_mb
+        # ---- bucket plan: contiguous flat ranges of ~bucket_mb, in backward order
         per = max(int(bucket_mb * (1 << 20) / 4), 1)
         self.buckets, start, members = [], 0, []
         for n in self.names:
@@ -102,10 +130,11 @@ class TrainStep:
                 start, members = end, []
         if members:
             self.buckets.append((start, off, members))
-        self.live = None            # learned on the first step
-        self._pending, self._works = None, []
-        self._expect = {}           # gradient contributions per parameter and step (a shared weight fires once per use)
-        if self.world > 1:
+        self._expect = None         # hook firings per parameter and step (a shared weight fires once per use): counted on step 1
+        self._state = None          # per-backward bookkeeping of the bucket hooks
+        self._works = []
+        self._cut = None            # graph capture: called with the bucket ids that just became ready
+        if self.world > 1 or self.segments:
             for bi, (_, _, mem) in enumerate(self.buckets):
                 for n in mem:
                     hook = self._make_hook(bi, n)
@@ -113,72 +142,107 @@ class TrainStep:
                     self.params[n]._gwd_hook = (lambda h=hook: h(None))          # gradients accumulated by the kernels
 
     # ------------------------------------------------------------------ DDP
+    def _broadcast_from_rank0(self):
+        """What DistributedDataParallel's constructor does for the reference (main_glassrgbd.py:46 - its ranks are seeded
+        seed + rank, :36, and rely on it): every rank starts from rank 0's parameters and buffers.  Also the communicator's
+        first collectives, so its set-up (allocations, helper threads) is over before any graph capture."""
+        dist.broadcast(self.flat_p, 0, group=self.pg)
+        rest = [p.data for p in self.model.parameters() if not p.requires_grad]
+        rest += [b for b in self.model.buffers() if b.is_floating_point()]
+        if rest:
+            flat = torch.cat([t.reshape(-1).float() for t in rest])
+            dist.broadcast(flat, 0, group=self.pg)
+            o = 0
+            for t in rest:
+                t.copy_(flat[o:o + t.numel()].view(t.shape))
+                o += t.numel()
+        chk = torch.stack([self.flat_p.double().sum(), self.flat_p.double().abs().sum()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.pg)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.pg)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("gw_depth_amd: ranks hold different parameters after the rank-0 broadcast")
+
     def _make_hook(self, bi, name):
         def hook(_p):
-            if self._pending is None:
+            st = self._state
+            if st is None:
                 return
-            self._got[name] = self._got.get(name, 0) + 1
-            if self.live is None:
-                self._seen.add(name)
-            elif name not in self.live:            # a parameter that was dead on step 1 woke up
-                self.live.add(name)
-                self._late.append(name)
-            elif self._got[name] == self._expect.get(name, 1):
-                self._pending[bi] -= 1
-                if self._pending[bi] == 0:
-                    self._launch(self.buckets[bi][0], self.buckets[bi][1])
-                    self._launched.add(bi)
+            st["got"][name] = st["got"].get(name, 0) + 1
+            if st["expect"] is None or name in self.idle:
+                return
+            if st["got"][name] == st["expect"].get(name, 1):
+                st["pending"][bi] -= 1
+                if st["pending"][bi] == 0:
+                    self._bucket_ready()
         return hook
 
-    def _launch(self, s, e):
-        self._works.append(dist.all_reduce(self.flat_g[s:e], group=self.pg, async_op=True))
+    def _bucket_ready(self):
+        """Buckets leave strictly in index order, each exactly once per step, on every rank: bucket i goes as soon as all of
+        its expected parameters and buckets 0..i-1 are done; whatever is left (a parameter that got no gradient this step,
+        the never-used tensors at the end of each group) goes at the end of backward.  No data-dependent collective exists."""
+        st = self._state
+        ready = []
+        while st["next"] < len(self.buckets) and st["pending"][st["next"]] == 0:
+            ready.append(st["next"])
+            st["next"] += 1
+        if ready:
+            self._dispatch(ready)
+
+    def _dispatch(self, bucket_ids, final=False):
+        if self._cut is not None:                     # capturing: end this graph segment here, its buckets go after its replay
+            self._cut(bucket_ids, final)
+        else:
+            for bi in bucket_ids:
+                self._launch(bi)
+
+    def _launch(self, bi):
+        if self.world > 1:
+            s, e, _ = self.buckets[bi]
+            self._works.append(dist.all_reduce(self.flat_g[s:e], group=self.pg, async_op=True))
 
     def _begin_backward(self):
-        if self.world == 1:
+        if self.world == 1 and not self.segments:
             return
-        self._works, self._late, self._launched, self._got = [], [], set(), {}
-        if self.live is None:
-            self._seen, self._pending = set(), [0] * len(self.buckets)
-        else:
-            self._pending = [sum(n in self.live for n in mem) for _, _, mem in self.buckets]
+        self._works = []
+        exp = self._expect
+        pending = None if exp is None else [sum(1 for n in mem if n not in self.idle) for _, _, mem in self.buckets]
+        self._state = {"got": {}, "expect": exp, "pending": pending, "next": 0}
+        if pending is not None and pending[0] == 0:
+            self._bucket_ready()
 
     def _finish_backward(self):
-        if self.world == 1:
+        st = self._state
+        if st is None:
             return
-        if self.live is None:                      # first step: no overlap, learn the live set
-            self.live = set(self._seen)
-            self._expect = dict(self._got)
-            for s, e, _ in self.buckets:
-                self._launch(s, e)
-        else:
-            for bi, left in enumerate(self._pending):
-                if left > 0 and bi not in self._launched:     # a live parameter got no gradient this step
-                    self._launch(self.buckets[bi][0], self.buckets[bi][1])
-            for n in self._late:
-                bi = next(i for i, b in enumerate(self.buckets) if n in b[2])
-                if bi in self._launched:           # its bucket already went out without it: reduce the slice alone
-                    o = self.offsets[n]
-                    self._launch(o, o + self.params[n].numel())
+        self._state = None
+        if st["expect"] is None:                   # first pass: count the firings per parameter (structural, the same on every rank)
+            self._expect = {n: max(1, c) for n, c in st["got"].items()}
+        rest = list(range(st["next"], len(self.buckets)))
+        if rest:
+            self._dispatch(rest, final=True)
+        self._wait_works()
+
+    def _wait_works(self):
         for w in self._works:
             w.wait()
-        self._pending = None
+        self._works = []
 
-    def _packed(self, targets):
-        """Static-shape device form of the targets for the sync-free criterion; the index scaffolding is cached per
-        tuple of target counts, only the line coordinates / labels are gathered each step (two small device ops)."""
-        sizes = tuple(int(len(t["labels"])) for t in targets)
-        if sum(sizes) == 0 or max(sizes) > 64:
-            return None                                # device LSAP limits; fall back to the host matcher
-        ent = self._pack_cache.get(sizes)
-        if ent is None:
-            ent = self._pack_cache[sizes] = pack_targets(targets, self.flat_p.device)
-        p = dict(ent)
-        p["lines"] = torch.cat([t["lines"] for t in targets]).float()
-        p["labels"] = torch.cat([t["labels"] for t in targets])
+    def _packed(self, targets, store=None):
+        """Static-shape device form of the targets for the sync-free criterion (criteria.PackedTargets, one per capacity
+        class); None when the device LSAP cannot take the batch (no targets at all, or more than 64 in one image): the
+        caller then uses the host matcher."""
+        sizes = [int(len(t["labels"])) for t in targets]
+        if sum(sizes) == 0 or max(sizes) > hip.LSAP_MAX_TARGETS:
+            return None
+        store = self._packs if store is None else store
+        key = (len(sizes), target_capacity(sum(sizes)))
+        p = store.get(key)
+        if p is None:
+            p = store[key] = PackedTargets(key[0], key[1], self.flat_p.device)
+        p.update(targets)
         if self.norm_world > 1:                         # global target count (glassrgbd.py:323-326), stays on the device
-            n = ent["num_items"].clone()
-            dist.all_reduce(n, group=self.pg)
-            p["num_items"] = n
+            dist.all_reduce(p["num_items"], group=self.pg)
         return p
 
     # ------------------------------------------------------------------ losses (engine_glassrgbd.py:62-115)
@@ -249,8 +313,12 @@ class TrainStep:
             total, terms = self.losses(out, batch["depth"], batch["seg"], batch["targets"], packed=packed)
             self.zero_grad()
             self._begin_backward()
-            with ops.COLSUMS, ops.WGRADS:               # bias / weight gradients of small layers run as grouped launches
-                total.backward()
+            try:
+                with ops.COLSUMS, ops.WGRADS:               # bias / weight gradients of small layers run as grouped launches
+                    total.backward()
+            except BaseException:
+                self._state = None
+                raise
             self._finish_backward()
         finally:
             if weights is not None:
@@ -260,7 +328,7 @@ class TrainStep:
     # ------------------------------------------------------------------ HIP-graph path (no host sync inside)
     def _sync_free_fb(self, st):
         """zero_grad + forward + 17 losses + backward on the static tensors `st`; contains no host round trip
-        (device LSAP, device CertainSample, fused losses), hence capturable."""
+        (device LSAP, device CertainSample, fused losses) and no collective, hence capturable."""
         self.model.train()
         weights = self.weights if (self.compute_dtype == torch.bfloat16 and st["images"].is_cuda) else None
         if weights is not None:
@@ -269,8 +337,14 @@ class TrainStep:
             out = self.model(NestedTensor(st["images"], st["pad_mask"]), taps=st.get("taps"))
             total, terms = self.losses(out, st["depth"], st["seg"], None, packed=st["packed"])
             self.flat_g.zero_()
-            with ops.COLSUMS, ops.WGRADS:
-                total.backward()
+            self._begin_backward()
+            try:
+                with ops.COLSUMS, ops.WGRADS:
+                    total.backward()
+            except BaseException:
+                self._state = None
+                raise
+            self._finish_backward()
         finally:
             if weights is not None:
                 weights.end_pass()
@@ -295,56 +369,105 @@ class TrainStep:
             return sum(1 for e in prof.events() if e.name == "hipMemsetAsync")
         except Exception as exc:                     # no tracer on this host: without the audit there is no capture
             warnings.warn("gw_depth_amd: capture audit unavailable (%s)" % exc)
+            self._state = None
             self._sync_free_fb(st)
             return -1
 
+    def _capture(self, st):
+        """Capture one sync-free pass as a chain of HIP graphs on the graph stream -> [(graph, bucket ids to all-reduce once
+        it has been enqueued)].  With bucket hooks installed (world > 1) the chain is cut whenever buckets become ready:
+        the hook ends the running capture and begins the next one on the same stream and memory pool, in the middle of
+        backward (autograd runs single-threaded here, so begin and end happen on one thread, which thread-local capture
+        mode requires).  Without hooks it is one graph."""
+        side = self._graph_stream()
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()
+        chain, cur = [], [None]
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            # thread_local: RCCL's watchdog / proxy threads may touch the runtime while this thread captures
+            g.capture_begin(pool=self._pool, capture_error_mode="thread_local")
+            cur[0] = g
+
+        def cut(bucket_ids, final):
+            cur[0].capture_end()
+            chain.append((cur[0], list(bucket_ids)))
+            cur[0] = None
+            if not final:                              # the last buckets close the step: nothing is enqueued after them
+                begin()
+
+        torch.cuda.synchronize()
+        gc.collect()
+        res = None
+        try:
+            with torch.cuda.stream(side), torch.autograd.set_multithreading_enabled(False):
+                begin()
+                self._cut = cut
+                try:
+                    res = self._sync_free_fb(st)
+                finally:
+                    self._cut = None
+                    if cur[0] is not None:
+                        cur[0].capture_end()
+                        chain.append((cur[0], []))
+                        cur[0] = None
+        finally:
+            self._works = []
+        return chain, res
+
     def _graph_entry(self, batch):
-        sizes = tuple(int(len(t["labels"])) for t in batch["targets"])
-        key = (tuple(batch["images"].shape), sizes)
+        sizes = [int(len(t["labels"])) for t in batch["targets"]]
+        if sum(sizes) == 0 or max(sizes) > hip.LSAP_MAX_TARGETS:
+            return None                                # device LSAP limits: this batch runs eagerly with the host matcher
+        key = (tuple(batch["images"].shape), target_capacity(sum(sizes)))
         ent = self._graphs.get(key)
         if ent is not None:
+            self._graphs.move_to_end(key)
             return ent
+        while len(self._graphs) >= MAX_GRAPHS:          # bounded cache; the executables go, the shared pool keeps the memory
+            self._graphs.popitem(last=False)
         dev = self.flat_p.device
         st = {k: batch[k].clone() for k in ("images", "pad_mask", "depth", "seg")}
-        st["packed"] = pack_targets(batch["targets"], dev)
+        st["packed"] = PackedTargets(len(sizes), key[1], dev).update(batch["targets"])
         side = self._graph_stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), warnings.catch_warnings(record=True) as caught:
-            warnings.simplefilter("always")
-            self._sync_free_fb(st)                     # allocator / lazily built caches / AccumulateGrad nodes
-            memsets = self._count_memsets(st)          # second warm-up pass, audited
-        torch.cuda.current_stream().wait_stream(side)
-        reason = None
-        if any("AccumulateGrad node's stream does not match" in str(w.message) for w in caught):
-            reason = ("an autograd graph built on another stream is still alive (e.g. the outputs of an eager step): its "
-                      "AccumulateGrad nodes would be captured on a forked stream")
-        elif memsets < 0:
-            reason = "the capture audit (torch.profiler runtime-call trace) is not available on this host"
-        elif memsets:
-            reason = ("%d hipMemsetAsync call(s) in the step (ATen multi-block reductions zero their semaphores that way); "
-                      "memset nodes do not replay correctly in HIP graphs on this ROCm" % memsets)
-        if reason is not None:
-            warnings.warn("gw_depth_amd: HIP-graph capture refused for batch signature %r, running eager: %s" % (key, reason))
-            ent = self._graphs[key] = {"graph": None, "reason": reason}
-            return ent
-        if self.norm_world > 1:                     # communicator set-up (allocations, helper threads) finishes before capture
-            dist.all_reduce(torch.zeros(1, device=dev), group=self.pg)
-            torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        # thread_local: RCCL's watchdog / proxy threads may touch the runtime while this thread captures
+        launch, self._launch = self._launch, (lambda bi: None)     # warm-up passes and capture issue NO collective
         try:
-            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-                res = self._sync_free_fb(st)
-        except RuntimeError as e:                   # capture invalidated: keep training, eagerly, and say so
-            torch.cuda.synchronize()
-            warnings.warn("gw_depth_amd: HIP-graph capture failed for batch signature %r, running eager: %s" % (key, e))
-            ent = self._graphs[key] = {"graph": None, "reason": str(e)}
-            return ent
-        ent = self._graphs[key] = {"graph": g, "static": st, "result": res}
+            with torch.cuda.stream(side), warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                self._sync_free_fb(st)                     # allocator / lazily built caches / AccumulateGrad nodes / hook counts
+                memsets = self._count_memsets(st)          # second warm-up pass, audited
+            torch.cuda.current_stream().wait_stream(side)
+            reason = None
+            if any("AccumulateGrad node's stream does not match" in str(w.message) for w in caught):
+                reason = ("an autograd graph built on another stream is still alive (e.g. the outputs of an eager step): its "
+                          "AccumulateGrad nodes would be captured on a forked stream")
+            elif memsets < 0:
+                reason = "the capture audit (torch.profiler runtime-call trace) is not available on this host"
+            elif memsets:
+                reason = ("%d hipMemsetAsync call(s) in the step (ATen multi-block reductions zero their semaphores that way); "
+                          "memset nodes do not replay correctly in HIP graphs on this ROCm" % memsets)
+            if reason is not None:
+                warnings.warn("gw_depth_amd: HIP-graph capture refused for batch signature %r, running eager: %s" % (key, reason))
+                ent = self._graphs[key] = {"graph": None, "reason": reason}
+                return ent
+            try:
+                chain, res = self._capture(st)
+            except RuntimeError as e:                   # capture invalidated: keep training, eagerly, and say so
+                torch.cuda.synchronize()
+                self._state = None
+                warnings.warn("gw_depth_amd: HIP-graph capture failed for batch signature %r, running eager: %s" % (key, e))
+                ent = self._graphs[key] = {"graph": None, "reason": str(e)}
+                return ent
+        finally:
+            self._launch = launch
+        ent = self._graphs[key] = {"graph": chain, "static": st, "result": res}
         return ent
 
     def _on_graph_stream(self, batch, taps):
-        """Eager forward/backward of a graph-mode TrainStep: same stream as the captures (see _graph_stream)."""
+        """Eager forward/backward of a graph-mode TrainStep: same stream as the captures (see _graph_stream), and the same
+        collective sequence as a replayed step (one num_items all-reduce, then every bucket once, in index order)."""
         side = self._graph_stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -354,23 +477,20 @@ class TrainStep:
 
     def _graph_step(self, batch):
         ent = self._graph_entry(batch)
-        if ent["graph"] is None:
+        if ent is None or ent["graph"] is None:
             return self._on_graph_stream(batch, None)
         st = ent["static"]
         for k in ("images", "pad_mask", "depth", "seg"):
             st[k].copy_(batch[k], non_blocking=True)
-        lines = torch.cat([t["lines"] for t in batch["targets"]])
-        st["packed"]["lines"].copy_(lines, non_blocking=True)
-        st["packed"]["labels"].copy_(torch.cat([t["labels"] for t in batch["targets"]]), non_blocking=True)
-        n = st["packed"]["num_items"]
-        n.fill_(float(lines.shape[0]))
+        st["packed"].update(batch["targets"])
         if self.norm_world > 1:                     # global target count, outside the captured region
-            dist.all_reduce(n, group=self.pg)
-        ent["graph"].replay()
-        if self.world > 1:                          # gradients: bucketed all-reduce after the replay (no overlap in graph mode)
-            works = [dist.all_reduce(self.flat_g[s:e], group=self.pg, async_op=True) for s, e, _ in self.buckets]
-            for w in works:
-                w.wait()
+            dist.all_reduce(st["packed"]["num_items"], group=self.pg)
+        self._works = []
+        for g, bucket_ids in ent["graph"]:
+            g.replay()
+            for bi in bucket_ids:                   # the communication stream picks the bucket up behind this segment and
+                self._launch(bi)                    # reduces it while the next segment runs
+        self._wait_works()
         return ent["result"]
 
     def __call__(self, batch, taps=None):

@@ -60,6 +60,7 @@ class ColsumJob(ctypes.Structure):
 
 
 COLSUM_BATCH = 16
+LSAP_MAX_TARGETS = 64     # gwd_lsap: targets per image (MAXT in csrc/lsap.hip)
 COLLATE_BATCH = 16
 
 
@@ -424,7 +425,9 @@ class HipLibrary:
                     "gwd_certain_sample")
 
     def lsap(self, cost, col_offsets, out, max_targets):
-        """cost (layers,B,Q,sumT) fp32; col_offsets (B+1,) int32; out (layers,sumT) int32."""
+        """cost (layers,B,Q,sumT) fp32; col_offsets (B+1,) int32 DEVICE data (image b owns columns [off[b], off[b+1]),
+        at most max_targets <= 64 of them; columns from off[B] on are padding); out (layers,sumT) int32: the query
+        assigned to every target column, Q for padding columns."""
         L_, B, Q, sumT = cost.shape
         self._check(self.lib.gwd_lsap(_ptr(cost), _ptr(col_offsets), _ptr(out), L_, B, Q, sumT, max_targets,
                                       self._stream(cost, col_offsets, out)), "gwd_lsap")

@@ -20,6 +20,7 @@ from .ops import ACT_ELU, ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID
 
 WS = 7
 HEADS = 16
+DEFAULT_FP32_STAGES = ()
 
 
 class NestedTensor:
@@ -647,10 +648,12 @@ class ReferTransformer(nn.Module):
         self.class_transformer3 = BasicLayer(D // 8, cfg.class_trans_layers[2], T)
         self.depth_pred4 = Seq(_0=Linear(D // 8 + T, T), _1=Linear(T, 1))      # never executed (:1288-1292)
 
-    def forward(self, top, feats, masks, pred_lines, pred_logits, taps=None):
+    def forward(self, top, feats, masks, pred_lines, pred_logits, taps=None, cast=None):
         cfg = self.cfg
         B, H, W, C = top.shape
         dt = top.dtype
+        cast = cast or (lambda stage, *ts: ts if len(ts) > 1 else ts[0])       # GlassRGBD.stage_cast: per-stage storage precision
+        top = cast("dense32", top)
         ids = torch.topk(pred_logits[:, :, 0].float(), cfg.num_ref, dim=-1)[1]                  # :1166 (raw logit)
         pts = torch.gather(pred_lines.float(), 1, ids[..., None].expand(-1, -1, pred_lines.shape[-1]))
         pts = (pts.reshape(B, cfg.num_ref, -1, 2) * 2 - 1.0)[:, :, :2]                          # :1175-1179
@@ -663,9 +666,10 @@ class ReferTransformer(nn.Module):
             up = nearest_up_tokens(x_prev, Hs, Ws, (Hn, Wn))
             return proj(up) + proj_bb(feat).flatten(1, 2), Hn, Wn
 
-        x1, H1, W1 = stage(x, H, W, feats[2], self.proj_class1, self.proj_backbn1)
-        dtok = ops.broadcast_rows(self.depth_token, B, H1 * W1, dt)
-        stok = ops.broadcast_rows(self.seg_token, B, H1 * W1, dt)
+        x, f2 = cast("class1", x, feats[2])
+        x1, H1, W1 = stage(x, H, W, f2, self.proj_class1, self.proj_backbn1)
+        dtok = ops.broadcast_rows(self.depth_token, B, H1 * W1, x1.dtype)
+        stok = ops.broadcast_rows(self.seg_token, B, H1 * W1, x1.dtype)
         x1, dtok, stok = self.class_transformer1(x1, H1, W1, dtok=dtok, stok=stok)
         depth1 = sig_head(torch.cat([x1, dtok], dim=-1), self.depth_pred16).float().view(B, 1, H1, W1)
         md = cfg.min_depth_eval / cfg.max_depth_eval
@@ -674,23 +678,27 @@ class ReferTransformer(nn.Module):
             taps["points1"] = pts1
             pts1 = taps.get("force_points1", pts1)     # teacher forcing for parity tests (identical index operands)
 
-        x2, H2, W2 = stage(x1, H1, W1, feats[1], self.proj_class2, self.proj_backbn2)
+        x1, dtok, stok, f1 = cast("class2", x1, dtok, stok, feats[1])
+        x2, H2, W2 = stage(x1, H1, W1, f1, self.proj_class2, self.proj_backbn2)
         pos2 = pos_sine(masks[1], cfg.dense_trans_dim // 8, False)
         dtok = self.old_depth_token_proj8(nearest_up_tokens(dtok, H1, W1, (H2, W2)))
         stok = self.old_seg_token_proj8(nearest_up_tokens(stok, H1, W1, (H2, W2)))
         x2, dtok, stok = self.class_transformer2(x2, H2, W2, dtok=dtok, stok=stok)
-        depth2 = self.point_based_pred1(x2, dtok, depth1, pts1, H2, W2, pos2)
+        px, pd = cast("pbp1", x2, dtok)
+        depth2 = self.point_based_pred1(px, pd, depth1, pts1, H2, W2, pos2)
         pts2 = certain_sample(depth1, depth2, cfg.depth_interval, cfg.interval_sample_num[1], md)
         if taps is not None:
             taps["points2"] = pts2
             pts2 = taps.get("force_points2", pts2)
 
-        x3, H3, W3 = stage(x2, H2, W2, feats[0], self.proj_class3, self.proj_backbn3)
+        x2, dtok, stok, f0 = cast("class3", x2, dtok, stok, feats[0])
+        x3, H3, W3 = stage(x2, H2, W2, f0, self.proj_class3, self.proj_backbn3)
         pos3 = pos_sine(masks[0], cfg.dense_trans_dim // 16, False)
         dtok = self.old_depth_token_proj4(nearest_up_tokens(dtok, H2, W2, (H3, W3)))
         stok = self.old_seg_token_proj4(nearest_up_tokens(stok, H2, W2, (H3, W3)))
         x3, dtok, stok = self.class_transformer3(x3, H3, W3, dtok=dtok, stok=stok)
-        depth3 = self.point_based_pred2(x3, dtok, depth2, pts2, H3, W3, pos3)
+        px, pd = cast("pbp2", x3, dtok)
+        depth3 = self.point_based_pred2(px, pd, depth2, pts2, H3, W3, pos3)
         if taps is not None:
             taps["topk_ids"] = ids
             taps.update(dbg_x32=x, dbg_depth0=depth0, dbg_x1=x1, dbg_depth1=depth1, dbg_x2=x2, dbg_depth2=depth2, dbg_x3=x3,
@@ -778,17 +786,28 @@ class GlassRGBD(nn.Module):
         self.dense_encoder = ReferTransformer(cfg)
         self.depth_decoder = DensePrediction(cfg.max_depth, cfg.class_token_dim)
         self.compute_dtype = torch.float32
+        # stages kept in fp32 storage when compute_dtype is bf16 (names: backbone detr dense32 class1 pbp1 class2 pbp2 class3
+        # decoder); the shipped set is chosen from measurements (tools/bf16_taps.py, DESIGN.md "precision policy")
+        self.fp32_stages = set(DEFAULT_FP32_STAGES)
+
+    def stage_cast(self, stage, *ts):
+        """Storage precision of a stage's inputs: fp32 for the stages listed in fp32_stages, compute_dtype otherwise."""
+        dt = torch.float32 if stage in self.fp32_stages else self.compute_dtype
+        out = tuple(t if t.dtype == dt else t.to(dt) for t in ts)
+        return out if len(out) > 1 else out[0]
 
     def forward(self, samples, reflc_points=None, reflc_mat=None, img_name=None, taps=None, match=None):
         if isinstance(samples, (list, torch.Tensor)):
             samples = nested_tensor_from_tensor_list(samples)
         images, pad_mask = samples.decompose()
         H, W = images.shape[-2:]
-        x = to_pixel_major(images).to(self.compute_dtype)
+        cast = self.stage_cast
+        x = cast("backbone", to_pixel_major(images))
         feats, masks = self.backbone(x, pad_mask)
         src, mask = feats[3], masks[3]
         pos = pos_sine(mask, self.cfg.hidden_dim // 2, True)
-        hs = self.transformer(ops.conv2d(src, self.input_proj.weight, self.input_proj.bias), mask,
+        src_d = cast("detr", src)
+        hs = self.transformer(ops.conv2d(src_d, self.input_proj.weight, self.input_proj.bias), mask,
                               self.query_embed.weight, pos)
         logits = self.class_embed(hs).float()
         lines = torch.sigmoid(self.lines_embed(hs).float())
@@ -798,10 +817,13 @@ class GlassRGBD(nn.Module):
         if match is not None:      # (matcher, targets): start the Hungarian hand-off now, consume it in the criterion
             matcher, targets = match
             out["_match_prefetch"] = matcher.prefetch([out] + out.get("aux_outputs", []), targets)
-        dense_in = ops.conv2d(src, self.dense_input_proj.weight, self.dense_input_proj.bias)
+        dense_in = ops.conv2d(cast("dense32", src), self.dense_input_proj.weight, self.dense_input_proj.bias)
         if taps is not None:
             taps.update(dbg_feats=feats, dbg_dense_in=dense_in, dbg_src=src)
-        feat4, dtok, stok, depths = self.dense_encoder(dense_in, feats, masks, out["pred_lines"], out["pred_logits"], taps)
+        feat4, dtok, stok, depths = self.dense_encoder(dense_in, feats, masks, out["pred_lines"], out["pred_logits"], taps, cast)
+        feat4, dtok, stok = cast("decoder", feat4, dtok, stok)
+        if taps is not None:
+            taps.update(dbg_feat4=feat4, dbg_dtok=dtok, dbg_stok=stok)
         depth, seg = self.depth_decoder(feat4, depths[-1], dtok, stok, (H, W))
         out["pred_depth"] = depths + [depth]
         out["pred_seg"] = seg

@@ -211,7 +211,10 @@ int gwd_certain_sample(const float *pred_small, const float *pred_large, float *
 /* Linear sum assignment of the line matcher on the device (replaces scipy.optimize.linear_sum_assignment at
  * src/models/matcher.py:74 and its 6 host syncs per step).  cost [layers][B][Q][sum_targets] fp32 is the block
  * cost matrix of matcher.py:52-70; image b owns columns col_offsets[b] .. col_offsets[b+1]-1 (int32 [B+1]).
- * query_of_target [layers][sum_targets] int32 receives the query matched to every target (targets <= Q, <= 64). */
+ * query_of_target [layers][sum_targets] int32 receives the query matched to every target (targets <= Q, <= 64).
+ * The offsets are DEVICE data: sum_targets may be a fixed capacity larger than col_offsets[B]; the padding columns
+ * col_offsets[B] .. sum_targets-1 are never read and receive the dummy query index Q, so one captured launch serves
+ * batches with any per-image target counts (max_targets is the host's bound on them, <= 64).                    */
 int gwd_lsap(const float *cost, const int32_t *col_offsets, int32_t *query_of_target, int32_t layers, int32_t B,
              int32_t Q, int32_t sum_targets, int32_t max_targets, void *stream);
 

@@ -428,6 +428,7 @@ class FakeDevice:
                 qi, ti = linear_sum_assignment(c)
                 for q, t in zip(qi, ti):
                     out[l, off[b] + t] = int(q)
+            out[l, off[B]:] = Q                      # padding columns -> the dummy query slot
 
     def window_map(self, src, dst, B, H, W, C, shift, gather, residual=None):
         Hp, Wp = (H + 6) // 7 * 7, (W + 6) // 7 * 7

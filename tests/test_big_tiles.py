@@ -1,0 +1,177 @@
+"""Parity of the implicit-GEMM kernels AT THE TILE SHAPES THE STEP DISPATCHES TO.
+
+csrc/igemm.hip picks its tiles from the problem size: `big = M >= 256*512` selects igemm_dma_kernel<256,160,8,1,3,*> and
+<256,128,4,2,3,*>, the weight-gradient split count follows M, and tests/test_hip_kernels.py only has M <= ~2 000.  Every case
+here is a layer of the real step at batch 8, 480x640 (M = 153 600 ... 2 457 600 output pixels), forward + data gradient +
+weight gradient through the C ABI, against plain fp32 torch.nn.functional.conv2d arithmetic on the CPU (NOT against this
+library's own fp32 kernels).  Inputs are bf16-rounded, so the only differences are the bf16 rounding of the outputs
+(relative rms 2^-8/sqrt(12) = 1.1e-3) and fp32 summation order.
+
+Tolerances: bf16 outputs 3e-3 relative L2 and 2 % of the largest reference magnitude element-wise (a misplaced tile or a
+dropped tail row is 100 % off); fp32 weight gradients 3e-4 relative L2.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gw_depth_amd import hip
+
+pytestmark = pytest.mark.gpu
+TOL_BF16, TOL_WGRAD, TOL_F32 = 3e-3, 3e-4, 3e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    hip.set_library(None)
+    torch.set_num_threads(16)
+    return hip.library()
+
+
+def rnd(*shape, seed, scale=1.0, dtype=torch.bfloat16):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def nchw(t):
+    return t.float().permute(0, 3, 1, 2).contiguous()
+
+
+def close(got, want, tol, what):
+    got, want = got.float().cpu(), want.float()
+    err = float((got.double() - want.double()).norm() / (want.double().norm() + 1e-30))
+    assert err < tol, "%s: relative L2 error %.3e >= %.1e" % (what, err, tol)
+    worst = float((got - want).abs().max() / (want.abs().max() + 1e-30))
+    assert worst < (0.02 if tol >= 1e-3 else 50 * tol), "%s: worst element off by %.3e of the largest magnitude" % (what, worst)
+
+
+def act_ref(v, act, act_scale):
+    if act == hip.ACT_RELU:
+        return torch.relu(v)
+    if act == hip.ACT_GELU:
+        return F.gelu(v)
+    if act == hip.ACT_ELU:
+        return F.elu(v)
+    if act == hip.ACT_SIGMOID:
+        return torch.sigmoid(v) * act_scale
+    return v
+
+
+# name, (B, Hi, Wi), Cin, Cout, K, stride, pad, upsample_to, extras, tiles the dispatcher picks (documentation)
+CASES = [
+    ("pyramid2_layer_160_160_3x3", (8, 120, 160), 160, 160, 3, 1, 1, None, {},
+     "fwd igemm_dma<256,160,8,1,3,0>, dgrad <256,160,..,1>, wgrad_dma<160,128,1,4,3,1>: THE roofline kernel of bench.py"),
+    ("pyramid2_lastconv_800_320_3x3", (8, 120, 160), 800, 320, 3, 1, 1, None, {},
+     "fwd <256,160> two column tiles, K = 7200; dgrad 320->800 <256,160,..,1>; wgrad<160,128> 2 x 57 tiles"),
+    ("pyramid2_firstconv_80_160_3x3", (8, 120, 160), 80, 160, 3, 1, 1, None, {},
+     "Cin % 32 != 0: register-staged igemm_fwd_kernel<bf16,128,160>; dgrad 160->80 <256,128,4,2,3,1>; wgrad_dma<160,128>"),
+    ("pyramid2_lastconv_320_80_1x1", (8, 120, 160), 320, 80, 1, 1, 0, None, {},
+     "fwd <256,128,4,2,3,0> with 80 of 128 columns; dgrad 80->320 register-staged; wgrad <128,128> plain GEMM"),
+    ("class3_mlp_fc1_64_128_gelu", (8, 120, 160), 64, 128, 1, 1, 0, None, dict(shift=True, act=hip.ACT_GELU, z=True),
+     "fwd <256,128,4,2,3,0> + GELU epilogue with pre-activation copy; dgrad 128->64 <128,64,2,2,4,1>; wgrad <64,64> plain"),
+    ("class3_qkv_64_192_ragged", (1, 414 * 8, 49), 64, 192, 1, 1, 0, None, dict(shift=True),
+     "M = 162 288 (not a multiple of 256): <256,128> with a half-empty second column tile and a ragged last row tile"),
+    ("layer1_conv3_64_256_1x1_bn_res_relu", (8, 120, 160), 64, 256, 1, 1, 0, None, dict(shift=True, scale=True, residual=True, act=hip.ACT_RELU),
+     "backbone Bottleneck conv3: folded FrozenBN scale/shift + residual + ReLU in the <256,128> epilogue"),
+    ("layer1_conv2_64_64_3x3_bn_relu", (8, 120, 160), 64, 64, 3, 1, 1, None, dict(shift=True, scale=True, act=hip.ACT_RELU),
+     "fwd <128,64,2,2,4,0> at M = 153 600; wgrad <64,64,2,2,4,1>"),
+    ("layer2_conv2_128_128_3x3_s2", (8, 120, 160), 128, 128, 3, 2, 1, None, dict(shift=True, act=hip.ACT_RELU),
+     "stride 2: forward gather 0, data gradient through the general gather (mode 2) at M = 153 600 input pixels"),
+    ("decoder_upconv1_64_64_up2_elu", (8, 120, 160), 64, 64, 3, 1, 1, (240, 320), dict(act=hip.ACT_ELU),
+     "nearest-upsample fused into the gather (mode 2), M = 614 400; dgrad at the virtual size + footprint sum"),
+    ("decoder_upconv2_64_32_up2_elu", (4, 240, 320), 64, 32, 3, 1, 1, (480, 640), dict(act=hip.ACT_ELU),
+     "fwd <128,32,4,1,4,2>, M = 1 228 800; wgrad <32,128,1,4,4,0>"),
+    ("decoder_conv2_32_32_3x3_elu", (4, 480, 640), 32, 32, 3, 1, 1, None, dict(act=hip.ACT_ELU),
+     "fwd <128,32,4,1,4,0>, dgrad <..,1>, wgrad <32,128,1,4,4,1> at full resolution"),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_dispatch_size_conv_against_fp32_torch(dev, case):
+    name, (B, Hi, Wi), Cin, Cout, K, s, p, virt, ex, _ = case
+    x = rnd(B, Hi, Wi, Cin, seed=11)
+    w = rnd(Cout, K, K, Cin, seed=12, scale=(K * K * Cin) ** -0.5)
+    scale = (torch.rand(Cout, generator=torch.Generator().manual_seed(13)) + 0.5) if ex.get("scale") else None
+    shift = rnd(Cout, seed=14, dtype=torch.float32) if ex.get("shift") else None
+    act, act_scale = ex.get("act", hip.ACT_NONE), ex.get("act_scale", 1.0)
+    if virt is None:
+        Ho, Wo = (Hi + 2 * p - K) // s + 1, (Wi + 2 * p - K) // s + 1
+        gather, vv = hip.GATHER_CONV, (0, 0)
+    else:
+        Ho, Wo = virt
+        gather, vv = hip.GATHER_UPSAMPLED, virt
+    res = rnd(B, Ho, Wo, Cout, seed=15) if ex.get("residual") else None
+    dims = (B, Hi, Wi, Cin, Ho, Wo, Cout, K, K)
+
+    # ---- fp32 torch reference (the reference's own arithmetic: nn.Conv2d / F.interpolate(nearest) / FrozenBN affine)
+    wk = w.float() if scale is None else (w.float() * scale[:, None, None, None]).to(torch.bfloat16).float()   # gwd_weight_prep folds, then rounds
+    xin = nchw(x)
+    if virt is not None:
+        xin = F.interpolate(xin, size=virt, mode="nearest")
+    pre = F.conv2d(xin, wk.permute(0, 3, 1, 2), None, stride=s, padding=p)
+    if shift is not None:
+        pre = pre + shift[None, :, None, None]
+    if res is not None:
+        pre = pre + nchw(res)
+    y_ref = act_ref(pre, act, act_scale).permute(0, 2, 3, 1)
+
+    cu = lambda t: None if t is None else t.cuda()
+    wdev = torch.empty(Cout, K, K, Cin, dtype=torch.bfloat16, device="cuda")
+    wt = torch.empty(Cin, K, K, Cout, dtype=torch.bfloat16, device="cuda")
+    dev.weight_prep(w.float().cuda(), cu(scale), wdev, wt, Cout, K * K, Cin, hip.BF16)
+    y = torch.full((B, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    z = torch.full_like(y, float("nan")) if ex.get("z") else None
+    dev.conv_forward(x.cuda(), wdev, y, dims, z=z, shift=cu(shift), residual=cu(res), stride=s, pad=p, gather=gather, virt=vv,
+                     act=act, act_scale=act_scale)
+    torch.cuda.synchronize()
+    close(y, y_ref, TOL_BF16, name + " forward")
+    if z is not None:
+        close(z, pre.permute(0, 2, 3, 1), TOL_BF16, name + " pre-activation copy")
+    del y, z, pre
+
+    # ---- data gradient: conv_transpose of the reference == the transposed-gather launch ops._ConvFn.backward makes
+    gy = rnd(B, Ho, Wo, Cout, seed=16)
+    Hd, Wd = (Hi, Wi) if virt is None else virt
+    gx_ref = torch.nn.grad.conv2d_input((B, Cin, Hd, Wd), wk.permute(0, 3, 1, 2), nchw(gy), stride=s, padding=p).permute(0, 2, 3, 1)
+    gx = torch.full((B, Hd, Wd, Cin), float("nan"), dtype=torch.bfloat16, device="cuda")
+    dev.conv_forward(gy.cuda(), wt, gx, (B, Ho, Wo, Cout, Hd, Wd, Cin, K, K), stride=s, pad=p, gather=hip.GATHER_TRANSPOSED)
+    torch.cuda.synchronize()
+    close(gx, gx_ref, TOL_BF16, name + " data gradient")
+    del gx, gx_ref
+
+    # ---- weight gradient (fp32 atomics into a zeroed buffer, real split count for this M; the FrozenBN scale multiplies it)
+    dw_ref = torch.nn.grad.conv2d_weight(xin, (Cout, Cin, K, K), nchw(gy), stride=s, padding=p).permute(0, 2, 3, 1)
+    if scale is not None:
+        dw_ref = dw_ref * scale[:, None, None, None]
+    dw = torch.zeros(Cout, K, K, Cin, device="cuda")
+    dev.conv_wgrad(x.cuda(), gy.cuda(), dw, dims, stride=s, pad=p, gather=gather, virt=vv, scale=cu(scale))
+    torch.cuda.synchronize()
+    close(dw, dw_ref, TOL_WGRAD, name + " weight gradient")
+
+
+def test_grouped_wgrad_launch_at_dispatch_sizes(dev):
+    """gwd_conv_wgrad_batch: the plain-GEMM weight gradients of the step travel 32 to a call and run as grouped launches
+    (igemm_wgrad_group_kernel<128,128> / <64,64>); here four real token-GEMM shapes of the 1/4-resolution stage in one call."""
+    shapes = [(153600, 64, 128), (153600, 128, 64), (162288, 64, 192), (153600, 320, 80)]
+    jobs, refs = [], []
+    for i, (M, Kc, N) in enumerate(shapes):
+        x, gy = rnd(M, 1, 1, Kc, seed=30 + i), rnd(M, 1, 1, N, seed=40 + i)
+        dw = torch.zeros(N, 1, 1, Kc, device="cuda")
+        jobs.append((x.cuda(), gy.cuda(), dw, (M, 1, 1, Kc, 1, 1, N, 1, 1), {}))
+        refs.append(gy.float().view(M, N).t() @ x.float().view(M, Kc))
+    dev.conv_wgrad_batch(jobs)
+    torch.cuda.synchronize()
+    for (M, Kc, N), job, ref in zip(shapes, jobs, refs):
+        close(job[2].view(N, Kc), ref, TOL_WGRAD, "grouped wgrad %dx%dx%d" % (M, Kc, N))
+
+
+def test_dominant_kernel_in_exact_fp32_mode(dev):
+    """The fp32 parity mode at the same dispatch size (igemm_fwd_kernel<float,128,160>, v_mfma_f32_32x32x2_f32)."""
+    B, H, W, C = 8, 120, 160, 160
+    x, w = rnd(B, H, W, C, seed=21, dtype=torch.float32), rnd(C, 3, 3, C, seed=22, scale=(9 * C) ** -0.5, dtype=torch.float32)
+    y_ref = F.conv2d(nchw(x), w.permute(0, 3, 1, 2), None, padding=1).permute(0, 2, 3, 1)
+    y = torch.full((B, H, W, C), float("nan"), device="cuda")
+    dev.conv_forward(x.cuda(), w.cuda(), y, (B, H, W, C, H, W, C, 3, 3), stride=1, pad=1)
+    torch.cuda.synchronize()
+    close(y, y_ref, TOL_F32, "fp32 160->160 forward")
