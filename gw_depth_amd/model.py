@@ -655,6 +655,9 @@ class ReferTransformer(nn.Module):
         cast = cast or (lambda stage, *ts: ts if len(ts) > 1 else ts[0])       # GlassRGBD.stage_cast: per-stage storage precision
         top = cast("dense32", top)
         ids = torch.topk(pred_logits[:, :, 0].float(), cfg.num_ref, dim=-1)[1]                  # :1166 (raw logit)
+        if taps is not None and "force_topk_ids" in taps:       # parity tests: identical index operands downstream (the ORDER of
+            taps["own_topk_ids"] = ids                          # the reference points matters: a 3x3 conv runs over that axis)
+            ids = taps["force_topk_ids"]
         pts = torch.gather(pred_lines.float(), 1, ids[..., None].expand(-1, -1, pred_lines.shape[-1]))
         pts = (pts.reshape(B, cfg.num_ref, -1, 2) * 2 - 1.0)[:, :, :2]                          # :1175-1179
         pos = pos_sine(masks[3], cfg.dense_trans_dim // 2, False)
@@ -748,20 +751,23 @@ class DensePrediction(nn.Module):
         h = ops.linear(xp, F.pad(fc1.weight, (0, pad, 0, pad)), F.pad(fc1.bias, (0, pad)), ACT_GELU)
         return ops.linear(h, F.pad(fc2.weight, (0, pad)), fc2.bias)
 
-    def branch(self, fuse_in, tag, fuse, size):
+    def branch(self, fuse_in, tag, fuse, size, cast):
         B, H, W, _ = fuse_in.shape
-        f = fuse(fuse_in)
+        f = fuse(cast("decoder_fuse", fuse_in))
+        f = cast("decoder_up1", f)
         u1 = getattr(self, f"norm_{tag}")(getattr(self, f"upconv1_{tag}")(f, (2 * H, 2 * W)))
         c1 = ops.conv2d(u1, getattr(self, f"conv1_{tag}")[0].weight, pad=1, act=ACT_ELU)
+        c1 = cast("decoder_up2", c1)
         u2 = getattr(self, f"upconv2_{tag}")(c1, size)
-        return ops.conv2d(u2, getattr(self, f"conv2_{tag}")[0].weight, pad=1, act=ACT_ELU)
+        return cast("decoder_head", ops.conv2d(u2, getattr(self, f"conv2_{tag}")[0].weight, pad=1, act=ACT_ELU))
 
-    def forward(self, feat, depth3, dtok, stok, size):
+    def forward(self, feat, depth3, dtok, stok, size, cast=None):
+        cast = cast or (lambda stage, t: t)
         B, H, W, _ = feat.shape
         d3 = depth3.view(B, H, W, 1).to(feat.dtype)
-        d = self.branch(torch.cat([feat, d3, dtok], dim=-1), "depth", self.fuse_padded, size)
+        d = self.branch(torch.cat([feat, d3, dtok], dim=-1), "depth", self.fuse_padded, size, cast)
         depth = ops.conv2d(d, self.get_depth[0].weight, pad=1, act=ACT_SIGMOID, act_scale=float(self.max_depth))
-        s = self.branch(torch.cat([feat, stok], dim=-1), "seg", self.seg_token_fuse, size)
+        s = self.branch(torch.cat([feat, stok], dim=-1), "seg", self.seg_token_fuse, size, cast)
         seg = ops.conv2d(s, self.get_seg.weight, pad=1)
         return depth.float().view(B, 1, size[0], size[1]), seg.permute(0, 3, 1, 2)
 
@@ -796,6 +802,11 @@ class GlassRGBD(nn.Module):
         out = tuple(t if t.dtype == dt else t.to(dt) for t in ts)
         return out if len(out) > 1 else out[0]
 
+    def decoder_cast(self, stage, t):
+        """The decoder's sub-stages (decoder_fuse / _up1 / _up2 / _head); naming "decoder" keeps all four in fp32."""
+        dt = torch.float32 if (stage in self.fp32_stages or "decoder" in self.fp32_stages) else self.compute_dtype
+        return t if t.dtype == dt else t.to(dt)
+
     def forward(self, samples, reflc_points=None, reflc_mat=None, img_name=None, taps=None, match=None):
         if isinstance(samples, (list, torch.Tensor)):
             samples = nested_tensor_from_tensor_list(samples)
@@ -821,10 +832,9 @@ class GlassRGBD(nn.Module):
         if taps is not None:
             taps.update(dbg_feats=feats, dbg_dense_in=dense_in, dbg_src=src)
         feat4, dtok, stok, depths = self.dense_encoder(dense_in, feats, masks, out["pred_lines"], out["pred_logits"], taps, cast)
-        feat4, dtok, stok = cast("decoder", feat4, dtok, stok)
         if taps is not None:
             taps.update(dbg_feat4=feat4, dbg_dtok=dtok, dbg_stok=stok)
-        depth, seg = self.depth_decoder(feat4, depths[-1], dtok, stok, (H, W))
+        depth, seg = self.depth_decoder(feat4, depths[-1], dtok, stok, (H, W), self.decoder_cast)
         out["pred_depth"] = depths + [depth]
         out["pred_seg"] = seg
         return out

@@ -59,10 +59,14 @@ def run_config(batch_size, seed):
 
     # fp32 parity mode, eager, sample points teacher-forced from the oracle (identical index operands downstream)
     step = TrainStep(model, crits, cfg, compute_dtype=torch.float32)
-    taps = {"force_points1": otaps["points1"].cuda(), "force_points2": otaps["points2"].cuda()}
+    taps = {"force_points1": otaps["points1"].cuda(), "force_points2": otaps["points2"].cuda(), "force_topk_ids": otaps["topk_ids"].cuda()}
     out, total, terms = step(b, taps=taps)
     torch.cuda.synchronize()
-    assert torch.equal(taps["topk_ids"].cpu(), otaps["topk_ids"])
+    # the product's own top-k of the line logits: identical to the oracle's except where two logits tie to float noise
+    own, want, lg = taps["own_topk_ids"].cpu(), otaps["topk_ids"], ref["pred_logits"][:, :, 0]
+    for bi, pos in (own != want).nonzero().tolist():
+        a, r = float(lg[bi, own[bi, pos]]), float(lg[bi, want[bi, pos]])
+        assert abs(a - r) <= 2e-5 * max(1.0, abs(r)), (bi, pos, a, r)
     check_outputs(out, ref, 1e-3)
     for k, v in terms.items():
         want = float(ref_terms[k])
@@ -75,10 +79,12 @@ def run_config(batch_size, seed):
     # the timed mode: bf16 storage, HIP-graph launch, three steps (two replays)
     cfg2, model2, crits2 = build(device="cuda")
     gstep = TrainStep(model2, crits2, cfg2, compute_dtype=torch.bfloat16, graph=True)
-    losses = []
+    losses, first = [], None
     for _ in range(3):
         gout, gtotal, gterms = gstep(b)
         losses.append(float(gtotal))
+        if first is None:                                                   # static output tensors: the next replay overwrites them
+            first = {"pred_lines": gout["pred_lines"].float().clone(), "depth": gout["pred_depth"][-1].float().clone()}
     gstep.flush()
     torch.cuda.synchronize()
     assert gstep._graphs and all(e["graph"] is not None for e in gstep._graphs.values()), "capture was refused"
@@ -86,7 +92,8 @@ def run_config(batch_size, seed):
     assert abs(losses[0] - fp32_total) <= 0.03 * abs(fp32_total), (losses, fp32_total)
     assert losses[2] < losses[0]                                            # AdamW on a fixed batch: the loss goes down
     # tensors in front of the first index op (top-k of the line logits): bf16 storage through 6 + 6 transformer layers
-    assert rel(gout["pred_lines"].float(), ref["pred_lines"]) < 6e-2 and torch.isfinite(gout["pred_depth"][-1]).all()
+    assert rel(first["pred_lines"], ref["pred_lines"]) < 3e-2 and torch.isfinite(first["depth"]).all()
+    assert rel(first["depth"], ref["pred_depth"][-1]) < 1e-1
     assert torch.isfinite(gstep.flat_p).all()
 
 
