@@ -129,6 +129,14 @@ def depth_rmse_leg(sd_cpu, cfg, dtype):
                         R.Cfg(dropout=cfg.dropout, log_depth_error=cfg.log_depth_error), training=False)
     per_image, _ = eval_ref.evaluate_dense(ref["pred_depth"][-1].numpy(), b["depth"].numpy(), ref["pred_seg"].numpy(), b["seg"].numpy())
     out = {"oracle_fp32": float(per_image[0, 3]), "sample": "1 image 480x640, weight seed 0, data seed 1, eval mode"}
+    # what bf16 STORAGE OF THE WEIGHTS alone costs with the reference's own fp32 arithmetic (the CPU oracle, weight matrices
+    # rounded to bf16, everything else fp32): the floor of any bf16 mode on this sample - DESIGN.md "precision policy"
+    with torch.no_grad():
+        sd_r = {k: (v.bfloat16().float() if (v.is_floating_point() and v.dim() >= 2) else v.clone()) for k, v in sd_cpu.items()}
+        ref_r = R.forward(sd_r, b["images"], b["pad_mask"], R.Cfg(dropout=cfg.dropout, log_depth_error=cfg.log_depth_error), training=False)
+    per_r, _ = eval_ref.evaluate_dense(ref_r["pred_depth"][-1].numpy(), b["depth"].numpy(), ref_r["pred_seg"].numpy(), b["seg"].numpy())
+    out["oracle_fp32_arithmetic_bf16_weights"] = float(per_r[0, 3])
+    out["abs_diff_oracle_bf16_weights"] = abs(float(per_r[0, 3]) - out["oracle_fp32"])
     model, _, _ = build_model(cfg)
     model.load_state_dict(sd_cpu)
     model.cuda().eval()

@@ -11,6 +11,7 @@
 // across all windows the wave visits, then reduced through LDS and flushed with 2401 atomics per workgroup.
 // head_dim <= 32 and FLOPs are tiny (9.6 kFLOP * hd per problem): this is a latency/HBM kernel, VALU math.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -321,6 +322,20 @@ int dispatch_hd(int hd, bool backward, const Args &a, const float *bias, float *
 
 }  // namespace
 
+// mfattn.hip: the same problem on the matrix cores (bf16); 0 = launched, 1 = not covered (fall through to the kernels above)
+int gwd_mfattn_window(bool backward, const gwd_strided *q, const gwd_strided *k, const gwd_strided *v, const gwd_strided *o_or_go,
+                      const gwd_strided *gq, const gwd_strided *gk, const gwd_strided *gv, const float *bias, float *dbias,
+                      const int32_t *region, int64_t n_windows, int32_t wpi, int32_t heads, int32_t head_dim, float scale, hipStream_t s);
+
+static bool mfma_window_enabled() {          // A/B switch (GWD_MFMA_WINATTN=0: the lane-per-row VALU kernels for bf16 as well)
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GWD_MFMA_WINATTN");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 extern "C" int gwd_winattn_forward(const gwd_strided *q, const gwd_strided *k, const gwd_strided *v, const gwd_strided *o,
                                    const float *bias, const int32_t *region, int64_t n_windows, int32_t windows_per_image,
                                    int32_t heads, int32_t head_dim, float scale, int32_t dtype, void *stream) {
@@ -331,6 +346,14 @@ extern "C" int gwd_winattn_forward(const gwd_strided *q, const gwd_strided *k, c
     a.k = {k->p, k->ws, k->ts, k->hs};
     a.v = {v->p, v->ws, v->ts, v->hs};
     a.o = {o->p, o->ws, o->ts, o->hs};
+    if (dtype == GWD_BF16 && mfma_window_enabled()) {
+        const int rc = gwd_mfattn_window(false, q, k, v, o, nullptr, nullptr, nullptr, bias, nullptr, region, n_windows, windows_per_image,
+                                         heads, head_dim, scale, (hipStream_t)stream);
+        if (rc <= 0) {
+            if (rc == 0) GWD_CHECK_LAUNCH();
+            return rc;
+        }
+    }
     if (dtype == GWD_BF16) return dispatch_hd<__bf16>(head_dim, false, a, bias, nullptr, region, n_windows, windows_per_image, heads, scale, (hipStream_t)stream);
     if (dtype == GWD_F32) return dispatch_hd<float>(head_dim, false, a, bias, nullptr, region, n_windows, windows_per_image, heads, scale, (hipStream_t)stream);
     return -2;
@@ -351,6 +374,14 @@ extern "C" int gwd_winattn_backward(const gwd_strided *q, const gwd_strided *k, 
     a.gq = {gq->p, gq->ws, gq->ts, gq->hs};
     a.gk = {gk->p, gk->ws, gk->ts, gk->hs};
     a.gv = {gv->p, gv->ws, gv->ts, gv->hs};
+    if (dtype == GWD_BF16 && mfma_window_enabled()) {
+        const int rc = gwd_mfattn_window(true, q, k, v, go, gq, gk, gv, bias, dbias, region, n_windows, windows_per_image, heads, head_dim,
+                                         scale, (hipStream_t)stream);
+        if (rc <= 0) {
+            if (rc == 0) GWD_CHECK_LAUNCH();
+            return rc;
+        }
+    }
     if (dtype == GWD_BF16) return dispatch_hd<__bf16>(head_dim, true, a, bias, dbias, region, n_windows, windows_per_image, heads, scale, (hipStream_t)stream);
     if (dtype == GWD_F32) return dispatch_hd<float>(head_dim, true, a, bias, dbias, region, n_windows, windows_per_image, heads, scale, (hipStream_t)stream);
     return -2;

@@ -186,6 +186,12 @@ class TrainStep:
         while st["next"] < len(self.buckets) and st["pending"][st["next"]] == 0:
             ready.append(st["next"])
             st["next"] += 1
+        if ready and st["next"] == len(self.buckets):
+            # the last bucket closes the step: leave it (and what became ready with it) to _finish_backward, so that a captured
+            # chain does not end in an empty graph
+            st["next"] -= len(ready)
+            st["pending"][st["next"]] = -1              # never "ready" again from a hook
+            return
         if ready:
             self._dispatch(ready)
 

@@ -29,8 +29,8 @@ ENTRY_POINTS = [
     "gwd_inorm_gelu_forward", "gwd_inorm_gelu_backward", "gwd_weight_prep_batch",
     "gwd_point_sample_forward", "gwd_point_sample_backward", "gwd_act_backward_colsum", "gwd_resample_backward_sep",
     "gwd_softmax_masked_forward", "gwd_softmax_scaled_backward", "gwd_query_workspace", "gwd_eval_accumulate", "gwd_colsum_batch", "gwd_conv_wgrad_batch",
-    "gwd_plane_loss_forward", "gwd_plane_loss_backward", "gwd_collate", "gwd_mha_forward",
-    "gwd_anchor_depth_forward", "gwd_anchor_depth_backward",
+    "gwd_plane_loss_forward", "gwd_plane_loss_backward", "gwd_collate",
+    "gwd_anchor_depth_forward", "gwd_anchor_depth_backward", "gwd_mha_flash_forward", "gwd_mha_flash_backward",
 ]
 
 
@@ -136,7 +136,8 @@ class HipLibrary:
         L.gwd_plane_loss_backward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp]
         L.gwd_collate.argtypes = [ctypes.POINTER(ImageJob), i32, i32, i32, ctypes.POINTER(ctypes.c_float),
                                   ctypes.POINTER(ctypes.c_float), vp, vp, vp, vp, i32, vp]
-        L.gwd_mha_forward.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]
+        L.gwd_mha_flash_forward.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp, vp, i64, vp, i32, i32, i32, i32, f32, i32, vp]
+        L.gwd_mha_flash_backward.argtypes = [vp] * 5 + [i64] * 5 + [vp] * 7 + [i64] * 3 + [i32, i32, i32, i32, f32, i32, vp]
         L.gwd_anchor_depth_forward.argtypes = [vp, vp, vp, i32, i64, i32, i32, vp]
         L.gwd_anchor_depth_backward.argtypes = [vp, vp, vp, vp, vp, i32, i64, i32, i32, vp]
         L.gwd_colsum_batch.argtypes = [ctypes.POINTER(ColsumJob), i32, i32, vp]
@@ -326,17 +327,30 @@ class HipLibrary:
         self._check(self.lib.gwd_collate(jobs, len(samples), H, W, f3(*mean), f3(*std), _ptr(images), _ptr(mask), _ptr(depth),
                                          _ptr(seg), dtype_code(images), self._stream(*ts)), "gwd_collate")
 
-    MHA_MAX_KEYS, MHA_HEAD_DIM = 320, 32
+    @staticmethod
+    def _tok(t):
+        """(B, tokens, E) tensor or last-dim slice: raw pointer + token stride; dense batches, unit channel stride."""
+        if t.dim() != 3 or t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
+            raise ValueError("attention operand must be (B, tokens, E) with unit channel stride and dense token rows")
+        return ctypes.c_void_p(t.data_ptr()), t.stride(1)
 
-    def mha_forward(self, q, k, v, key_padding_mask, mult, P, out, B, H, L, S, scale):
-        """gwd_mha_forward.  q/k/v: (B, tokens, 32 H) tensors or last-dim slices of a packed projection (unit column stride)."""
-        for t in (q, k, v):
-            if t.dim() != 3 or t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
-                raise ValueError("q/k/v must be (B, tokens, E) with unit column stride and dense token rows")
-        self._check(self.lib.gwd_mha_forward(ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(k.data_ptr()), ctypes.c_void_p(v.data_ptr()),
-                                             q.stride(1), k.stride(1), v.stride(1), _ptr(key_padding_mask), _ptr(mult), _ptr(P),
-                                             _ptr(out), B, H, L, S, float(scale), dtype_code(q),
-                                             self._stream(q, k, v, key_padding_mask, mult, P, out)), "gwd_mha_forward")
+    def mha_flash_forward(self, q, k, v, key_padding_mask, mult, out, lse, H, scale):
+        """gwd_mha_flash_forward: q (B,L,32H), k / v (B,S,32H) bf16 tensors or channel slices of a packed projection."""
+        B, L, S = q.shape[0], q.shape[1], k.shape[1]
+        (qp, qs), (kp, ks), (vp_, vs), (op, os_) = self._tok(q), self._tok(k), self._tok(v), self._tok(out)
+        self._check(self.lib.gwd_mha_flash_forward(qp, kp, vp_, qs, ks, vs, _ptr(key_padding_mask), _ptr(mult), op, os_, _ptr(lse),
+                                                   B, H, L, S, float(scale), dtype_code(q),
+                                                   self._stream(q, k, v, key_padding_mask, mult, out, lse)), "gwd_mha_flash_forward")
+
+    def mha_flash_backward(self, q, k, v, go, out, key_padding_mask, mult, lse, delta, gq, gk, gv, H, scale):
+        B, L, S = q.shape[0], q.shape[1], k.shape[1]
+        ts = [self._tok(t) for t in (q, k, v, go, out, gq, gk, gv)]
+        self._check(self.lib.gwd_mha_flash_backward(ts[0][0], ts[1][0], ts[2][0], ts[3][0], ts[4][0], ts[0][1], ts[1][1], ts[2][1],
+                                                    ts[3][1], ts[4][1], _ptr(key_padding_mask), _ptr(mult), _ptr(lse), _ptr(delta),
+                                                    ts[5][0], ts[6][0], ts[7][0], ts[5][1], ts[6][1], ts[7][1], B, H, L, S,
+                                                    float(scale), dtype_code(q),
+                                                    self._stream(q, k, v, go, out, key_padding_mask, mult, lse, delta, gq, gk, gv)),
+                    "gwd_mha_flash_backward")
 
     def anchor_depth_forward(self, att, anchor, pred, B, P, R):
         self._check(self.lib.gwd_anchor_depth_forward(_ptr(att), _ptr(anchor), _ptr(pred), B, P, R, dtype_code(att),

@@ -182,16 +182,20 @@ class MultiheadAttention(nn.Module):
         S = key.shape[1]
         H, hd = self.heads, E // self.heads
         W, b = self.in_proj_weight, self.in_proj_bias
+        scale = float(hd) ** -0.5
         if query is key:
             qk = ops.linear(query, W, b, rows=(0, 2 * E))
+            v = ops.linear(value, W, b, rows=(2 * E, 3 * E))
+            fused = ops.mha_core(qk, None, v, H, key_padding_mask, self.dropout, self.training, scale)
             q, k = qk[..., :E], qk[..., E:]
         else:
             q = ops.linear(query, W, b, rows=(0, E))
             k = ops.linear(key, W, b, rows=(E, 2 * E))
-        v = ops.linear(value, W, b, rows=(2 * E, 3 * E))
-        fused = ops.mha_core(q, k, v, H, key_padding_mask, self.dropout, self.training, float(hd) ** -0.5)
-        if fused is not None:               # head_dim 32, <= 320 keys: one kernel, no head split / merge copies
+            v = ops.linear(value, W, b, rows=(2 * E, 3 * E))
+            fused = ops.mha_core(q, k, v, H, key_padding_mask, self.dropout, self.training, scale)
+        if fused is not None:               # bf16: one matrix-core kernel each way, no L x S tensor, no head split / merge copies
             return self.out_proj(fused)
+        # fp32 parity mode: the unfused arithmetic of the reference
         q = q.reshape(B, L, H, hd).transpose(1, 2)
         k = k.reshape(B, S, H, hd).transpose(1, 2)
         v = v.reshape(B, S, H, hd).transpose(1, 2)

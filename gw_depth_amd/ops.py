@@ -502,59 +502,66 @@ def attention_softmax(scores, key_padding_mask=None, scale=1.0):
     return _AttnSoftmaxFn.apply(scores, key_padding_mask, float(scale))
 
 
-class _MhaFn(torch.autograd.Function):
-    """Attention core of one MultiheadAttention call: fused forward (gwd_mha_forward), backward through the batched-GEMM
-    library and gwd_softmax_scaled_backward (the same arithmetic autograd ran before)."""
+class _MhaFlashFn(torch.autograd.Function):
+    """dropout(softmax(scale q k^T + key mask)) v with the heads merged, on the matrix cores (gwd_mha_flash_forward /
+    _backward, csrc/mfattn.hip): only the merged output and one log-sum-exp per (image, head, query) are saved.
+    `qk` is either one packed (B, L, 2E) projection (self-attention: q = [..., :E], k = [..., E:], ONE gradient tensor, no
+    slice-backward zero-fill + add) or a (q, k) pair."""
 
     @staticmethod
-    def forward(ctx, q, k, v, H, key_padding_mask, mult, scale):
+    def forward(ctx, qk, k_sep, v, H, key_padding_mask, mult, scale):
         lib = _lib()
-        B, L, E = q.shape
-        S = k.shape[1]
-        P = torch.empty((B, H, L, S), dtype=q.dtype, device=q.device)
+        packed = k_sep is None
+        E = v.shape[-1]
+        q, k = (qk[..., :E], qk[..., E:]) if packed else (qk, k_sep)
+        B, L, S = q.shape[0], q.shape[1], k.shape[1]
         out = torch.empty((B, L, E), dtype=q.dtype, device=q.device)
+        lse = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
         if key_padding_mask is not None:
             key_padding_mask = key_padding_mask.contiguous().view(torch.uint8) if key_padding_mask.dtype == torch.bool else key_padding_mask.contiguous()
-        lib.mha_forward(q, k, v, key_padding_mask, mult, P, out, B, H, L, S, scale)
-        ctx.save_for_backward(q, k, v, P, mult)
-        ctx.H, ctx.scale = H, scale
+        lib.mha_flash_forward(q, k, v, key_padding_mask, mult, out, lse, H, scale)
+        ctx.save_for_backward(qk, k_sep, v, key_padding_mask, mult, out, lse)
+        ctx.cfg = (H, scale, packed)
         return out
 
     @staticmethod
     def backward(ctx, go):
-        q, k, v, P, mult = ctx.saved_tensors
-        H, B, L, E = ctx.H, q.shape[0], q.shape[1], q.shape[2]
-        S, hd = k.shape[1], E // ctx.H
-        heads = lambda t, n: t.reshape(B, n, H, hd).transpose(1, 2)
-        goh = heads(go, L)
-        Pd = P if mult is None else P * mult
-        gv = Pd.transpose(-2, -1) @ goh                                   # (B, H, S, hd)
-        gP = goh @ heads(v, S).transpose(-2, -1)                          # (B, H, L, S)
-        if mult is not None:
-            gP = gP * mult
-        gS = torch.empty_like(P)
-        _lib().softmax_scaled_backward(gP.contiguous(), P, gS, P.numel() // S, S, ctx.scale)
-        gq = gS @ heads(k, S)
-        gk = gS.transpose(-2, -1) @ heads(q, L)
-        merge = lambda t, n: t.transpose(1, 2).reshape(B, n, E)
-        return merge(gq, L), merge(gk, S), merge(gv, S), None, None, None, None
+        qk, k_sep, v, kpm, mult, out, lse = ctx.saved_tensors
+        H, scale, packed = ctx.cfg
+        E = v.shape[-1]
+        q, k = (qk[..., :E], qk[..., E:]) if packed else (qk, k_sep)
+        go = go.contiguous()
+        gqk = torch.empty_like(qk)
+        gk_sep = None if packed else torch.empty_like(k_sep)
+        gq, gk = (gqk[..., :E], gqk[..., E:]) if packed else (gqk, gk_sep)
+        gv = torch.empty_like(v)
+        delta = torch.empty_like(lse)
+        _lib().mha_flash_backward(q, k, v, go, out, kpm, mult, lse, delta, gq, gk, gv, H, scale)
+        return gqk, gk_sep, gv, None, None, None, None
 
 
-def mha_core(q, k, v, heads, key_padding_mask, dropout_p, training, scale):
-    """dropout(softmax(scale q k^T + mask)) v, heads merged: q (B,L,E), k/v (B,S,E) (last-dim slices allowed).  Returns None when
-    the fused kernel does not cover the shape (head_dim != 32 or more than 320 keys) or is not enabled: the caller keeps the
-    batched-GEMM path.  OPT-IN (GWD_FUSED_MHA=1): measured on one box the fused forward costs what the seven launches it replaces
-    cost (50 us per call, VALU-bound: 53.3 vs 53.1 ms per step) - see DESIGN.md section 4; it is parity-tested either way."""
-    lib = _lib()
-    E, S = q.shape[-1], k.shape[1]
-    if E // heads != getattr(lib, "MHA_HEAD_DIM", 0) or S > getattr(lib, "MHA_MAX_KEYS", 0) or os.environ.get("GWD_FUSED_MHA", "0") != "1":
+def _dense_rows(t):
+    """(B, tokens, C) view acceptable to the attention kernels: unit channel stride, dense token rows, 16-byte aligned rows."""
+    ok = (t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1) and (t.stride(1) * t.element_size()) % 16 == 0
+          and t.data_ptr() % 16 == 0)
+    return t if ok else t.contiguous()
+
+
+def mha_core(qk, k, v, heads, key_padding_mask, dropout_p, training, scale):
+    """Attention core of one MultiheadAttention call (multi_head_attention.py:329-375) as ONE kernel each way.  qk: the packed
+    (B, L, 2E) q|k projection with k=None, or q with a separate k (B, S, E); v (B, S, E).  Returns the merged (B, L, E) output,
+    or None when the kernels do not cover the call (not bf16 on a HIP device, head_dim != 32): the caller keeps the unfused
+    path (the fp32 parity mode)."""
+    E = v.shape[-1]
+    if not v.is_cuda or v.dtype != torch.bfloat16 or E // heads != 32 or os.environ.get("GWD_FLASH_MHA", "1") == "0":
         return None
+    B, L = qk.shape[0], qk.shape[1]
+    S = v.shape[1]
     mult = None
     if training and dropout_p > 0:       # ATen's graph-safe Philox stream decides which probabilities are dropped
-        mult = F.dropout(torch.ones((q.shape[0], heads, q.shape[1], S), dtype=q.dtype, device=q.device), dropout_p, True)
-    fix = lambda t: t if (t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1) and (t.stride(1) * t.element_size()) % 16 == 0
-                          and t.data_ptr() % 16 == 0) else t.contiguous()
-    return _MhaFn.apply(fix(q), fix(k), fix(v), int(heads), key_padding_mask, mult, float(scale))
+        mult = F.dropout(torch.ones((B, heads, L, S), dtype=v.dtype, device=v.device), dropout_p, True)
+    return _MhaFlashFn.apply(_dense_rows(qk), None if k is None else _dense_rows(k), _dense_rows(v), int(heads), key_padding_mask,
+                             mult, float(scale))
 
 
 class _SilogFn(torch.autograd.Function):
@@ -736,27 +743,9 @@ def window_attention_packed(qkv, bias, region, windows_per_image, scale):
     return _WinAttnPackedFn.apply(qkv, bias, region, int(windows_per_image), float(scale))
 
 
-_REGION_MASKS = {}
-
-
-def _window_attention_matmul(q, k, v, bias, region, windows_per_image, scale):
-    """head_dim 32 (the 72-window 1/32 stage): 49x49x32 batched GEMMs are MFMA-sized and the lane-per-row kernel
-    spills at this width, so scores / PV go through the batched-GEMM library and the softmax through gwd_softmax."""
-    W, N, H, D = q.shape
-    s = torch.matmul((q * scale).permute(0, 2, 1, 3), k.permute(0, 2, 3, 1)) + bias.to(q.dtype)      # (W, H, N, N)
-    if region is not None:
-        key = (region.data_ptr(), tuple(region.shape), q.dtype)
-        m = _REGION_MASKS.get(key)
-        if m is None:
-            m = _REGION_MASKS[key] = ((region[:, :, None] != region[:, None, :]).to(q.dtype) * -100.0).unsqueeze(1)   # (wpi,1,N,N)
-        s = (s.view(W // windows_per_image, windows_per_image, H, N, N) + m).view(W, H, N, N)
-    p = softmax_lastdim(s)
-    return torch.matmul(p, v.permute(0, 2, 1, 3)).permute(0, 2, 1, 3).reshape(W, N, H * D)
-
-
 def window_attention(q, k, v, bias, region, windows_per_image, scale):
-    if q.shape[-1] >= 32 and q.is_cuda:
-        return _window_attention_matmul(q, k, v, bias, region, int(windows_per_image), float(scale))
+    """Separate q / k / v operands (W, 49, H, D): bf16 on the matrix cores (csrc/mfattn.hip, head_dim 4..32), fp32 on the
+    lane-per-row kernels (csrc/winattn.hip)."""
     return _WinAttnFn.apply(q, k, v, bias, region, int(windows_per_image), float(scale))
 
 

@@ -327,16 +327,26 @@ int gwd_plane_loss_backward(const void *depth, const uint8_t *valid, const int64
                             int32_t H, int32_t W, const double *stats, const float *gloss, void *gdepth, int32_t dtype,
                             void *stream);
 
-/* Multi-head attention forward core, head_dim 32, S <= 320 keys (the DETR encoder / decoder attention,
- * src/models/multi_head_attention.py:329-372): out = dropout(softmax(scale * q k^T + key mask)) v with the heads merged.
- *   q: row (b, l) at q + (b*L + l)*q_rs, head h in columns [32h, 32h+32) (dtype; q_rs, k_rs, v_rs are ROW strides in
- *   elements, so slices of a packed in-projection are read in place); k, v likewise with S rows per image;
- *   key_padding_mask [B][S] uint8 (nonzero = excluded, -inf) or NULL; mult [B][H][L][S] (dtype) dropout multipliers
- *   (0 or 1/(1-p)) or NULL; P [B][H][L][S] (dtype) OUT: the softmax probabilities BEFORE dropout (saved for the backward
- *   pass); out [B][L][32 H] (dtype).  Returns -4 for S > 320 (use batched GEMMs), -5 for rows that are not 16-byte aligned. */
-int gwd_mha_forward(const void *q, const void *k, const void *v, int64_t q_rs, int64_t k_rs, int64_t v_rs,
-                    const uint8_t *key_padding_mask, const void *mult, void *P, void *out, int32_t B, int32_t H,
-                    int32_t L, int32_t S, float scale, int32_t dtype, void *stream);
+/* Multi-head attention core on the matrix cores, flash style (csrc/mfattn.hip): head_dim 32, bf16, ANY L and S; no L x S
+ * matrix reaches memory (replaces q*scaling, bmm, masked_fill, softmax, dropout, bmm and the head split / merge copies of
+ * src/models/multi_head_attention.py:329-375, and their autograd backward).
+ *   q: row (b, l) at q + (b*L + l)*q_ts, head h in channels [32h, 32h+32); q_ts, k_ts, ... are TOKEN strides in elements
+ *   (multiples of 8, 16-byte aligned bases), so slices of a packed in-projection are read - and their gradients written -
+ *   in place; k, v likewise with S tokens per image.  key_padding_mask [B][S] uint8 (nonzero = excluded) or NULL;
+ *   mult [B][H][L][S] bf16 dropout multipliers (0 or 1/(1-p)) or NULL.
+ *   forward:  out (b, l) rows with token stride o_ts, heads merged; lse [B][H][L] fp32 = log-sum-exp of the scaled, masked
+ *             scores of every query (saved for the backward pass).
+ *   backward: go -> gq, gk, gv (same addressing); out / lse from the forward; delta [B][H][L] fp32 is scratch.  Every output
+ *             row is written by exactly one wave (no atomics): bit-reproducible.
+ * Returns -2 for a dtype other than GWD_BF16 (the fp32 parity mode keeps the unfused path).                               */
+int gwd_mha_flash_forward(const void *q, const void *k, const void *v, int64_t q_ts, int64_t k_ts, int64_t v_ts,
+                          const uint8_t *key_padding_mask, const void *mult, void *out, int64_t o_ts, float *lse, int32_t B,
+                          int32_t H, int32_t L, int32_t S, float scale, int32_t dtype, void *stream);
+int gwd_mha_flash_backward(const void *q, const void *k, const void *v, const void *go, const void *out, int64_t q_ts,
+                           int64_t k_ts, int64_t v_ts, int64_t go_ts, int64_t o_ts, const uint8_t *key_padding_mask,
+                           const void *mult, const float *lse, float *delta, void *gq, void *gk, void *gv, int64_t gq_ts,
+                           int64_t gk_ts, int64_t gv_ts, int32_t B, int32_t H, int32_t L, int32_t S, float scale, int32_t dtype,
+                           void *stream);
 
 /* Batch assembly from raw decoded images (the tail of the input pipeline): ToTensor + Normalize
  * (src/datasets/transforms_depth.py:618-660; torchvision's to_tensor / normalize: x/255, - mean, / std in fp32), the

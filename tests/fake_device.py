@@ -183,21 +183,33 @@ class FakeDevice:
         else:
             gdepth.zero_()
 
-    MHA_MAX_KEYS, MHA_HEAD_DIM = 320, 32
-
-    def mha_forward(self, q, k, v, key_padding_mask, mult, P, out, B, H, L, S, scale):
-        """gwd_mha_forward in torch (multi_head_attention.py:329-372)."""
-        hd = q.shape[-1] // H
+    @staticmethod
+    def _mha_ref(q, k, v, key_padding_mask, mult, H, scale):
+        """multi_head_attention.py:329-375 in fp32 torch: merged output and log-sum-exp of the scaled, masked scores."""
+        B, L, S, hd = q.shape[0], q.shape[1], k.shape[1], q.shape[-1] // H
         qh = q.float().reshape(B, L, H, hd).transpose(1, 2) * scale
         kh = k.float().reshape(B, S, H, hd).transpose(1, 2)
         vh = v.float().reshape(B, S, H, hd).transpose(1, 2)
         s_ = qh @ kh.transpose(-2, -1)
         if key_padding_mask is not None:
             s_ = s_.masked_fill(key_padding_mask.bool().view(B, 1, 1, S), float("-inf"))
-        p = torch.softmax(s_, dim=-1).to(P.dtype)
-        P.copy_(p)
-        pd = p.float() if mult is None else p.float() * mult.float()
-        out.copy_((pd @ vh).transpose(1, 2).reshape(B, L, H * hd))
+        p = torch.softmax(s_, dim=-1)
+        pd = p if mult is None else p * mult.float()
+        return (pd @ vh).transpose(1, 2).reshape(B, L, H * hd), torch.logsumexp(s_, -1)
+
+    def mha_flash_forward(self, q, k, v, key_padding_mask, mult, out, lse, H, scale):
+        o, l = self._mha_ref(q, k, v, key_padding_mask, mult, H, scale)
+        out.copy_(o)
+        lse.copy_(l)
+
+    def mha_flash_backward(self, q, k, v, go, out, key_padding_mask, mult, lse, delta, gq, gk, gv, H, scale):
+        qf, kf, vf = (t.detach().float().clone().requires_grad_(True) for t in (q, k, v))
+        with torch.enable_grad():
+            o, _ = self._mha_ref(qf, kf, vf, key_padding_mask, mult, H, scale)
+            g = torch.autograd.grad(o, [qf, kf, vf], go.float())
+        gq.copy_(g[0])
+        gk.copy_(g[1])
+        gv.copy_(g[2])
 
     def anchor_depth_forward(self, att, anchor, pred, B, P, R):
         pred.copy_((att.float().reshape(B, P, R) * anchor.reshape(B, 1, R)).sum(-1))

@@ -602,19 +602,31 @@ def test_conv_wgrad_row_scale(dev, dtype, spec):
     assert rel(dw1, ref) < TOL[dtype] and rel(dw2, ref) < TOL[dtype]
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(2, 8, 300, 300, True, True), (2, 8, 100, 300, True, False), (1, 8, 37, 65, False, True),
-                                   (2, 4, 100, 100, False, False), (1, 2, 5, 320, True, True)])
-def test_mha_forward(dev, shape, dtype):
-    """gwd_mha_forward (head_dim 32, <= 320 keys) vs torch math: probabilities, merged output; key-padding mask, dropout
-    multipliers, q / k read in place from a packed (B, L, 2E) projection."""
-    B, H, L, S, masked, drop = shape
-    E = 32 * H
-    fake = FakeDevice()
-    qk = rnd(B, L, 2 * E, dtype=dtype, seed=1) if L == S else None
-    q = qk[..., :E] if qk is not None else rnd(B, L, E, dtype=dtype, seed=1)
-    k = qk[..., E:] if qk is not None else rnd(B, S, E, dtype=dtype, seed=2)
-    v = rnd(B, S, E, dtype=dtype, seed=3)
+MHA_SHAPES = [
+    # B, H, L, S, key mask, dropout multipliers, packed q|k projection
+    (2, 8, 300, 300, True, True, True),       # DETR encoder self-attention (C2: 15 x 20 tokens)
+    (2, 8, 100, 100, False, True, True),      # decoder self-attention
+    (2, 8, 100, 300, True, True, False),      # decoder cross-attention
+    (1, 8, 37, 65, True, False, False),       # ragged tiles, S not a multiple of 4
+    (2, 4, 12, 12, False, False, True),       # 96 x 128 golden cases: 3 x 4 tokens
+    (1, 2, 5, 321, True, True, False),        # odd S with dropout (scalar multiplier loads)
+    (1, 8, 100, 1200, True, False, False),    # C5: 960 x 1280 -> 30 x 40 keys
+]
+
+
+@pytest.mark.parametrize("shape", MHA_SHAPES, ids=["%dx%dx%dx%d%s%s%s" % (s[0], s[1], s[2], s[3], "m" * s[4], "d" * s[5], "p" * s[6]) for s in MHA_SHAPES])
+def test_mha_flash_forward_backward(dev, shape):
+    """gwd_mha_flash_forward / _backward (bf16, matrix cores, no L x S tensor) vs fp32 torch math of
+    multi_head_attention.py:329-375 on the same bf16-rounded operands: merged output, log-sum-exp, dq / dk / dv; key-padding
+    masks, dropout multipliers, q | k read (and their gradients written) in place in a packed (B, L, 2E) projection."""
+    B, H, L, S, masked, drop, packed = shape
+    E, dt = 32 * H, torch.bfloat16
+    scale = 32 ** -0.5
+    qk = rnd(B, L, 2 * E, dtype=dt, seed=1) if packed else None
+    q = qk[..., :E] if packed else rnd(B, L, E, dtype=dt, seed=1)
+    k = qk[..., E:] if packed else rnd(B, S, E, dtype=dt, seed=2)
+    v = rnd(B, S, E, dtype=dt, seed=3)
+    go = rnd(B, L, E, dtype=dt, seed=5)
     kpm = None
     if masked:
         kpm = torch.zeros(B, S, dtype=torch.uint8)
@@ -623,18 +635,41 @@ def test_mha_forward(dev, shape, dtype):
     mult = None
     if drop:
         g = torch.Generator().manual_seed(4)
-        mult = ((torch.rand(B, H, L, S, generator=g) > 0.1).float() / 0.9).to(dtype)
-    P_r, o_r = torch.empty(B, H, L, S, dtype=dtype), torch.empty(B, L, E, dtype=dtype)
-    fake.mha_forward(q, k, v, kpm, mult, P_r, o_r, B, H, L, S, 32 ** -0.5)
+        mult = ((torch.rand(B, H, L, S, generator=g) > 0.1).float() / 0.9).to(dt)
+    # reference, fp32 autograd
+    qf, kf, vf = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    heads = lambda t, n: t.reshape(B, n, H, 32).transpose(1, 2)
+    sc = heads(qf, L) @ heads(kf, S).transpose(-2, -1) * scale
+    if kpm is not None:
+        sc = sc.masked_fill(kpm.bool()[:, None, None, :], float("-inf"))
+    P = sc.softmax(-1)
+    lse_r = torch.logsumexp(sc, -1)
+    o_r = ((P * mult.float() if mult is not None else P) @ heads(vf, S)).transpose(1, 2).reshape(B, L, E)
+    o_r.backward(go.float())
     cu = lambda t: None if t is None else t.cuda()
-    qc, kc = (qk.cuda()[..., :E], qk.cuda()[..., E:]) if qk is not None else (q.cuda(), k.cuda())
-    P, o = torch.full((B, H, L, S), float("nan"), dtype=dtype).cuda(), torch.full((B, L, E), float("nan"), dtype=dtype).cuda()
-    dev.mha_forward(qc, kc, v.cuda(), cu(kpm), cu(mult), P, o, B, H, L, S, 32 ** -0.5)
+    if packed:
+        QK = qk.cuda()
+        qc, kc = QK[..., :E], QK[..., E:]
+        GQK = torch.full_like(QK, float("nan"))
+        gq, gk = GQK[..., :E], GQK[..., E:]
+    else:
+        qc, kc = q.cuda(), k.cuda()
+        gq, gk = torch.full_like(qc, float("nan")), torch.full_like(kc, float("nan"))
+    vc = v.cuda()
+    out = torch.full((B, L, E), float("nan"), dtype=dt, device="cuda")
+    lse = torch.full((B, H, L), float("nan"), device="cuda")
+    dev.mha_flash_forward(qc, kc, vc, cu(kpm), cu(mult), out, lse, H, scale)
+    gv, delta = torch.full_like(vc, float("nan")), torch.empty_like(lse)
+    dev.mha_flash_backward(qc, kc, vc, go.cuda(), out, cu(kpm), cu(mult), lse, delta, gq, gk, gv, H, scale)
     torch.cuda.synchronize()
-    assert rel(P, P_r) < TOL[dtype] and rel(o, o_r) < TOL[dtype]
-    with pytest.raises(RuntimeError):                                   # 321 keys: not covered, the caller keeps the GEMM path
-        dev.mha_forward(q.cuda().contiguous(), torch.zeros(B, 321, E, dtype=dtype).cuda(), torch.zeros(B, 321, E, dtype=dtype).cuda(), None, None,
-                        torch.empty(B, H, L, 321, dtype=dtype).cuda(), o, B, H, L, 321, 1.0)
+    tol = TOL[dt]
+    assert rel(out, o_r.detach()) < tol, "forward"
+    assert float((lse.cpu() - lse_r.detach()).abs().max()) < 2e-2, "log-sum-exp"
+    assert rel(gq, qf.grad) < tol, "dq"
+    assert rel(gk, kf.grad) < tol, "dk"
+    assert rel(gv, vf.grad) < tol, "dv"
+    with pytest.raises(RuntimeError):                                   # fp32: not covered, the caller keeps the unfused path
+        dev.mha_flash_forward(qc.float().contiguous(), kc.float().contiguous(), vc.float(), None, None, out.float(), lse, H, scale)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -87,9 +87,3 @@ def test_sync_free_criterion_equals_reference_criterion(fake):
     assert set(want) == set(got)
     for k in want:
         assert abs(float(want[k]) - float(got[k])) <= 1e-5 * max(1.0, abs(float(want[k]))), k
-
-
-def test_train_step_wiring_with_fused_attention_opt_in(fake, golden_dir, monkeypatch):
-    """GWD_FUSED_MHA=1 routes the DETR attention through gwd_mha_forward + the hand-written backward: same golden parity."""
-    monkeypatch.setenv("GWD_FUSED_MHA", "1")
-    check_train_step("tiny_b2_96x128", golden_dir, "cpu", tol=FP_TOL, grad_tol=3e-3)
