@@ -35,6 +35,12 @@ struct OperandW {
     void *p;
     long ws, ts, hs;
 };
+// where bias(h, i, j) lives: dense [heads][49][49] (rel == nullptr), or the [n_rel][heads] parameter table behind rel[i*49+j]
+struct BiasRef {
+    const int *rel;
+    int heads, n_rel;
+    __device__ __forceinline__ long at(int h, int e) const { return rel ? (long)rel[e] * heads + h : (long)h * (49 * 49) + e; }
+};
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
@@ -59,24 +65,46 @@ __device__ __forceinline__ f32x16 zero16() {
 // row of accumulator register i in lane half h (C/D layout of the 32x32 MFMA)
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
-// ---- global -> LDS image: lane = token, HD channels, zero-filled to COLS
+// ---- global -> registers -> LDS image: lane = token, HD channels, zero-filled to COLS.  Split in two so that the next
+// window's rows are in flight while the current window is being computed.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;      // plain vector type: HIP's uint4 class keeps loop-carried values in scratch
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+template <int HD> struct Row {
+    u32x4 a, b, c, d;            // 8 channels each
+};
+
 template <int HD>
-__device__ __forceinline__ void stage(__bf16 *img, const Operand &op, long w, int head, int lane) {
+__device__ __forceinline__ void fetch(Row<HD> &r, const Operand &op, long w, int head, int lane) {
+    const int tok = lane < NT ? lane : NT - 1;           // idle lanes shadow the last token (no divergent loads; put() skips them)
+    const __bf16 *src = (const __bf16 *)op.p + w * op.ws + (long)tok * op.ts + (long)head * op.hs;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    r.b = z;
+    r.c = z;
+    r.d = z;
+    if constexpr (HD == 4) {
+        const u32x2 v = *(const u32x2 *)src;
+        r.a = u32x4{v.x, v.y, 0u, 0u};
+    } else {
+        r.a = *(const u32x4 *)src;
+        if constexpr (HD >= 16) r.b = *(const u32x4 *)(src + 8);
+        if constexpr (HD >= 32) {
+            r.c = *(const u32x4 *)(src + 16);
+            r.d = *(const u32x4 *)(src + 24);
+        }
+    }
+}
+
+template <int HD>
+__device__ __forceinline__ void put(__bf16 *img, const Row<HD> &r, int lane) {
     using G = Geo<HD>;
     if (lane < NT) {
-        const __bf16 *src = (const __bf16 *)op.p + w * op.ws + (long)lane * op.ts + (long)head * op.hs;
         __bf16 *dst = img + lane * G::RS;
-        const uint4 z = make_uint4(0, 0, 0, 0);
-        if constexpr (HD == 4) {
-            const uint2 v = *(const uint2 *)src;
-            *(uint4 *)dst = make_uint4(v.x, v.y, 0, 0);
-            *(uint4 *)(dst + 8) = z;
-        } else if constexpr (HD == 8) {
-            *(uint4 *)dst = *(const uint4 *)src;
-            *(uint4 *)(dst + 8) = z;
-        } else {
-#pragma unroll
-            for (int c = 0; c < HD; c += 8) *(uint4 *)(dst + c) = *(const uint4 *)(src + c);
+        *(u32x4 *)dst = r.a;
+        *(u32x4 *)(dst + 8) = r.b;                        // zeros for head_dim 4 / 8
+        if constexpr (HD >= 32) {
+            *(u32x4 *)(dst + 16) = r.c;
+            *(u32x4 *)(dst + 24) = r.d;
         }
     }
 }
@@ -136,9 +164,12 @@ __device__ __forceinline__ bf16x8 region_frag(const int *__restrict__ region_w, 
 }
 
 // the rel-pos bias of one head in S^T accumulator layout: element i of tile (kt, qt) in lane (c, h) is
-// bias[query 32 qt + c][key 32 kt + acc_row(i, h)]; padded keys get -1e30 (softmax weight 0), padded queries 0
-__device__ __forceinline__ void load_bias(f32x16 (&b)[2][2], const float *__restrict__ bias_h, int lane) {
+// bias[query 32 qt + c][key 32 kt + acc_row(i, h)]; padded keys get -1e30 (softmax weight 0), padded queries 0.
+// All 64 loads are unconditional (clamped addresses) so that they issue back to back - a load under a lane-dependent
+// condition waits for its predecessor: 64 serial L2 round trips were 80 us of fixed cost per wave.
+__device__ __forceinline__ void load_bias(f32x16 (&b)[2][2], const float *__restrict__ bias, const BiasRef &br, int head, int lane) {
     const int c = lane & 31, h = lane >> 5;
+    float raw[2][2][16];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -146,7 +177,16 @@ __device__ __forceinline__ void load_bias(f32x16 (&b)[2][2], const float *__rest
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int key = 32 * kt + acc_row(i, h), qry = 32 * qt + c;
-                b[kt][qt][i] = key >= NT ? -1e30f : (qry < NT ? bias_h[qry * NT + key] : 0.f);
+                raw[kt][qt][i] = bias[br.at(head, (qry < NT ? qry : NT - 1) * NT + (key < NT ? key : NT - 1))];
+            }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = 32 * kt + acc_row(i, h), qry = 32 * qt + c;
+                b[kt][qt][i] = key >= NT ? -1e30f : (qry < NT ? raw[kt][qt][i] : 0.f);
             }
 }
 
@@ -184,7 +224,7 @@ __device__ __forceinline__ void lds_settle() {
 // ------------------------------------------------------------------------------------------------ forward
 template <int HD, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void win_fwd_kernel(Operand q, Operand k, Operand v, OperandW o,
-                                                             const float *__restrict__ bias, const int *__restrict__ region,
+                                                             const float *__restrict__ bias, BiasRef br, const int *__restrict__ region,
                                                              long n_windows, int windows_per_image, float scale) {
     using G = Geo<HD>;
     extern __shared__ __attribute__((aligned(16))) __bf16 smem_f[];
@@ -193,13 +233,24 @@ __global__ __launch_bounds__(64 * WAVES) void win_fwd_kernel(Operand q, Operand 
     __bf16 *qi = smem_f + wave * 3 * G::IMG, *ki = qi + G::IMG, *vi = ki + G::IMG;
     for (int e = lane * 8; e < 3 * G::IMG; e += 512) *(uint4 *)(qi + e) = make_uint4(0, 0, 0, 0);     // padding rows stay zero
     f32x16 bs[2][2];
-    load_bias(bs, bias + (long)head * NT * NT, lane);
+    load_bias(bs, bias, br, head, lane);
     lds_settle();
     constexpr bool WIDE = G::COLS == 32;
+    Row<HD> rq, rk, rv;
+    if ((long)blockIdx.x < n_windows) {
+        fetch<HD>(rq, q, blockIdx.x, head, lane);
+        fetch<HD>(rk, k, blockIdx.x, head, lane);
+        fetch<HD>(rv, v, blockIdx.x, head, lane);
+    }
     for (long w = blockIdx.x; w < n_windows; w += gridDim.x) {
-        stage<HD>(qi, q, w, head, lane);
-        stage<HD>(ki, k, w, head, lane);
-        stage<HD>(vi, v, w, head, lane);
+        put<HD>(qi, rq, lane);
+        put<HD>(ki, rk, lane);
+        put<HD>(vi, rv, lane);
+        if (w + gridDim.x < n_windows) {               // the next window's rows travel while this one is computed
+            fetch<HD>(rq, q, w + gridDim.x, head, lane);
+            fetch<HD>(rk, k, w + gridDim.x, head, lane);
+            fetch<HD>(rv, v, w + gridDim.x, head, lane);
+        }
         bf16x8 rf[2];
         if (region) {
             const int *rw = region + (w % windows_per_image) * NT;
@@ -260,8 +311,8 @@ __global__ __launch_bounds__(64 * WAVES) void win_fwd_kernel(Operand q, Operand 
 template <int HD, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void win_bwd_kernel(Operand q, Operand k, Operand v, Operand go, OperandW gq, OperandW gk,
                                                              OperandW gv, const float *__restrict__ bias, float *__restrict__ dbias,
-                                                             const int *__restrict__ region, long n_windows, int windows_per_image,
-                                                             float scale) {
+                                                             BiasRef br, const int *__restrict__ region, long n_windows,
+                                                             int windows_per_image, float scale) {
     using G = Geo<HD>;
     extern __shared__ __attribute__((aligned(16))) __bf16 smem_b[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -271,7 +322,7 @@ __global__ __launch_bounds__(64 * WAVES) void win_bwd_kernel(Operand q, Operand 
     __bf16 *pi = oi + G::IMG, *si = pi + 64 * PK;       // P and dS as [query][key] images
     for (int e = lane * 8; e < PER_WAVE; e += 512) *(uint4 *)(qi + e) = make_uint4(0, 0, 0, 0);
     f32x16 bs[2][2], db[2][2];
-    load_bias(bs, bias + (long)head * NT * NT, lane);
+    load_bias(bs, bias, br, head, lane);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -279,11 +330,31 @@ __global__ __launch_bounds__(64 * WAVES) void win_bwd_kernel(Operand q, Operand 
     lds_settle();
     constexpr bool WIDE = G::COLS == 32;
     const int c = lane & 31, h = lane >> 5;
+    constexpr bool PREFETCH = HD <= 16;                  // head_dim 32: 64 more registers, and one window per wave anyway
+    Row<HD> rq, rk, rv, ro;
+    if (PREFETCH && (long)blockIdx.x < n_windows) {
+        fetch<HD>(rq, q, blockIdx.x, head, lane);
+        fetch<HD>(rk, k, blockIdx.x, head, lane);
+        fetch<HD>(rv, v, blockIdx.x, head, lane);
+        fetch<HD>(ro, go, blockIdx.x, head, lane);
+    }
     for (long w = blockIdx.x; w < n_windows; w += gridDim.x) {
-        stage<HD>(qi, q, w, head, lane);
-        stage<HD>(ki, k, w, head, lane);
-        stage<HD>(vi, v, w, head, lane);
-        stage<HD>(oi, go, w, head, lane);
+        if (!PREFETCH) {
+            fetch<HD>(rq, q, w, head, lane);
+            fetch<HD>(rk, k, w, head, lane);
+            fetch<HD>(rv, v, w, head, lane);
+            fetch<HD>(ro, go, w, head, lane);
+        }
+        put<HD>(qi, rq, lane);
+        put<HD>(ki, rk, lane);
+        put<HD>(vi, rv, lane);
+        put<HD>(oi, ro, lane);
+        if (PREFETCH && w + gridDim.x < n_windows) {
+            fetch<HD>(rq, q, w + gridDim.x, head, lane);
+            fetch<HD>(rk, k, w + gridDim.x, head, lane);
+            fetch<HD>(rv, v, w + gridDim.x, head, lane);
+            fetch<HD>(ro, go, w + gridDim.x, head, lane);
+        }
         bf16x8 rf[2];
         if (region) {
             const int *rw = region + (w % windows_per_image) * NT;
@@ -381,7 +452,7 @@ __global__ __launch_bounds__(64 * WAVES) void win_bwd_kernel(Operand q, Operand 
         }
         lds_settle();
     }
-    if (dbias) {
+    if (dbias && !br.rel) {
         float *dh = dbias + (long)head * NT * NT;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -392,6 +463,23 @@ __global__ __launch_bounds__(64 * WAVES) void win_bwd_kernel(Operand q, Operand 
                     const int key = 32 * kt + acc_row(i, h), qry = 32 * qt + c;
                     if (key < NT && qry < NT) unsafeAtomicAdd(dh + qry * NT + key, db[kt][qt][i]);
                 }
+    } else if (dbias) {
+        // table-shaped gradient: up to 49 (query, key) pairs share one table row - fold the wave's 2 401 values into its
+        // n_rel rows in LDS first (the P image is free now), then one atomic per row and wave
+        float *acc = (float *)pi;
+        for (int e = lane; e < 256; e += 64) acc[e] = 0.f;
+        lds_settle();
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = 32 * kt + acc_row(i, h), qry = 32 * qt + c;
+                    if (key < NT && qry < NT) atomicAdd(acc + br.rel[qry * NT + key], db[kt][qt][i]);
+                }
+        lds_settle();
+        for (int e = lane; e < br.n_rel; e += 64) unsafeAtomicAdd(dbias + (long)e * br.heads + head, acc[e]);
     }
 }
 
@@ -407,8 +495,8 @@ bool aligned_for(const void *p, long ws, long ts, long hs) {
 }
 
 template <int HD>
-int launch(bool backward, const Args &a, const float *bias, float *dbias, const int *region, long n_windows, int wpi, int heads,
-           float scale, hipStream_t s) {
+int launch(bool backward, const Args &a, const float *bias, float *dbias, const BiasRef br, const int *region, long n_windows, int wpi,
+           int heads, float scale, hipStream_t s) {
     using G = Geo<HD>;
     bool ok = aligned_for<HD>(a.q.p, a.q.ws, a.q.ts, a.q.hs) && aligned_for<HD>(a.k.p, a.k.ws, a.k.ts, a.k.hs) &&
               aligned_for<HD>(a.v.p, a.v.ws, a.v.ts, a.v.hs);
@@ -418,18 +506,21 @@ int launch(bool backward, const Args &a, const float *bias, float *dbias, const 
     if (!ok) return 1;                          // not taken: the caller keeps the lane-per-row kernel
     // a wave keeps one head's bias (and bias gradient) in registers and walks windows blockIdx.x, + gridDim.x, ...:
     // enough waves to fill the chip, few enough that the 2 401 bias-gradient atomics per wave stay negligible
-    long gx = n_windows < 160 ? n_windows : 160;
+    long gx = (n_windows + 7) / 8;
+    if (gx * heads < 2048) gx = (2048 + heads - 1) / heads;       // ... but never fewer waves than fill the chip twice
+    if (gx > n_windows) gx = n_windows;
+    if (gx > 256) gx = 256;
     if (!backward) {
         constexpr int WAVES = 4;
         if (heads % WAVES) return 1;
         const size_t lds = (size_t)WAVES * 3 * G::IMG * 2;
-        win_fwd_kernel<HD, WAVES><<<dim3((unsigned)gx, heads / WAVES), 64 * WAVES, lds, s>>>(a.q, a.k, a.v, a.o, bias, region, n_windows, wpi, scale);
+        win_fwd_kernel<HD, WAVES><<<dim3((unsigned)gx, heads / WAVES), 64 * WAVES, lds, s>>>(a.q, a.k, a.v, a.o, bias, br, region, n_windows, wpi, scale);
     } else {
         constexpr int WAVES = HD == 32 ? 1 : 2;
         if (heads % WAVES) return 1;
         const size_t lds = (size_t)WAVES * (4 * G::IMG + 2 * 64 * PK) * 2;
         win_bwd_kernel<HD, WAVES><<<dim3((unsigned)gx, heads / WAVES), 64 * WAVES, lds, s>>>(a.q, a.k, a.v, a.go, a.gq, a.gk, a.gv, bias, dbias,
-                                                                                            region, n_windows, wpi, scale);
+                                                                                            br, region, n_windows, wpi, scale);
     }
     return 0;
 }
@@ -439,8 +530,10 @@ int launch(bool backward, const Args &a, const float *bias, float *dbias, const 
 // 0 = launched, 1 = shape / alignment not covered (caller falls back), < 0 = error.  bf16 only.
 int gwd_mfattn_window(bool backward, const gwd_strided *q, const gwd_strided *k, const gwd_strided *v, const gwd_strided *o_or_go,
                       const gwd_strided *gq, const gwd_strided *gk, const gwd_strided *gv, const float *bias, float *dbias,
-                      const int32_t *region, int64_t n_windows, int32_t wpi, int32_t heads, int32_t head_dim, float scale, hipStream_t s) {
+                      const int32_t *rel_index, int32_t n_rel, const int32_t *region, int64_t n_windows, int32_t wpi, int32_t heads,
+                      int32_t head_dim, float scale, hipStream_t s) {
     using namespace mfattn;
+    const BiasRef br{rel_index, heads, n_rel};
     Args a{};
     a.q = {q->p, q->ws, q->ts, q->hs};
     a.k = {k->p, k->ws, k->ts, k->hs};
@@ -457,10 +550,10 @@ int gwd_mfattn_window(bool backward, const gwd_strided *q, const gwd_strided *k,
         // checked on the host side of the ABI by construction (model.shift_regions); nothing to verify on device memory here
     }
     switch (head_dim) {
-        case 4: return launch<4>(backward, a, bias, dbias, region, n_windows, wpi, heads, scale, s);
-        case 8: return launch<8>(backward, a, bias, dbias, region, n_windows, wpi, heads, scale, s);
-        case 16: return launch<16>(backward, a, bias, dbias, region, n_windows, wpi, heads, scale, s);
-        case 32: return launch<32>(backward, a, bias, dbias, region, n_windows, wpi, heads, scale, s);
+        case 4: return launch<4>(backward, a, bias, dbias, br, region, n_windows, wpi, heads, scale, s);
+        case 8: return launch<8>(backward, a, bias, dbias, br, region, n_windows, wpi, heads, scale, s);
+        case 16: return launch<16>(backward, a, bias, dbias, br, region, n_windows, wpi, heads, scale, s);
+        case 32: return launch<32>(backward, a, bias, dbias, br, region, n_windows, wpi, heads, scale, s);
         default: return 1;
     }
 }

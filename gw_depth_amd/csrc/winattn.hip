@@ -22,6 +22,12 @@ struct Operand {
     const void *p;
     long ws, ts, hs;     // window / token / head strides in elements
 };
+// where bias(h, i, j) lives: dense [heads][49][49], or the [n_rel][heads] parameter table behind rel[i*49+j]
+struct BiasRef {
+    const int *rel;
+    int heads;
+    __device__ __forceinline__ long at(int h, int e) const { return rel ? (long)rel[e] * heads + h : (long)h * (NT * NT) + e; }
+};
 struct OperandW {
     void *p;
     long ws, ts, hs;
@@ -69,7 +75,7 @@ __device__ __forceinline__ void store_row(T *p, const float (&v)[HD], float mul)
 
 template <typename T, int HD, bool VEC>
 __global__ __launch_bounds__(256) void winattn_fwd_kernel(Operand q, Operand k, Operand v, OperandW o,
-                                                          const float *__restrict__ bias, const int *__restrict__ region,
+                                                          const float *__restrict__ bias, BiasRef br, const int *__restrict__ region,
                                                           long n_windows, int windows_per_image, float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *bias_s = smem;                                  // [49*49]
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(Operand q, Operand k, 
     float *ks = smem + NB + wave * (2 * NT * HD + 64);
     float *vs = ks + NT * HD;
     int *reg_s = (int *)(vs + NT * HD);
-    for (int e = threadIdx.x; e < NT * NT; e += blockDim.x) bias_s[e] = bias[(long)h * NT * NT + e];
+    for (int e = threadIdx.x; e < NT * NT; e += blockDim.x) bias_s[e] = bias[br.at(h, e)];
     __syncthreads();
     const int i = lane < NT ? lane : NT - 1;               // idle lanes shadow the last row (keeps loops uniform)
     for (long w = (long)blockIdx.x * 4 + wave; w < n_windows; w += (long)gridDim.x * 4) {
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(Operand q, Operand k, 
 template <typename T, int HD, bool VEC>
 __global__ __launch_bounds__(256) void winattn_bwd_kernel(Operand q, Operand k, Operand v, Operand go, OperandW gq,
                                                           OperandW gk, OperandW gv, const float *__restrict__ bias,
-                                                          float *__restrict__ dbias, const int *__restrict__ region,
+                                                          float *__restrict__ dbias, BiasRef br, const int *__restrict__ region,
                                                           long n_windows, int windows_per_image, float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *bias_s = smem;                                  // [49*49]
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(Operand q, Operand k, 
     float *m_s = os + NT * HD, *l_s = m_s + 64, *dl_s = l_s + 64;
     int *reg_s = (int *)(dl_s + 64);
     for (int e = threadIdx.x; e < NT * NT; e += blockDim.x) {
-        bias_s[e] = bias[(long)h * NT * NT + e];
+        bias_s[e] = bias[br.at(h, e)];
         dbias_s[e] = 0.f;
     }
     __syncthreads();
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(Operand q, Operand k, 
             for (int j = 0; j < NT; ++j) atomicAdd(&dbias_s[i * NT + j], db[j]);
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < NT * NT; e += blockDim.x) unsafeAtomicAdd(dbias + (long)h * NT * NT + e, dbias_s[e]);
+        for (int e = threadIdx.x; e < NT * NT; e += blockDim.x) unsafeAtomicAdd(dbias + br.at(h, e), dbias_s[e]);
     }
 }
 
@@ -279,7 +285,7 @@ struct Args {
 };
 
 template <typename T, int HD>
-int launch(bool backward, const Args &a, const float *bias, float *dbias, const int *region, long n_windows,
+int launch(bool backward, const Args &a, const float *bias, float *dbias, const BiasRef br, const int *region, long n_windows,
            int windows_per_image, int heads, float scale, hipStream_t s) {
     // a workgroup stages one head's bias (and, backward, flushes 2401 dBias atomics): give every wave ~8 windows so that
     // cost is amortised, as long as that still leaves >= 4 workgroups per CU
@@ -295,27 +301,27 @@ int launch(bool backward, const Args &a, const float *bias, float *dbias, const 
     if (!backward) {
         vec = vec && al(a.o.p, a.o.ws, a.o.ts, a.o.hs);
         const size_t lds = (NB + 4 * (2 * NT * HD + 64)) * sizeof(float);
-        if (vec) winattn_fwd_kernel<T, HD, true><<<grid, 256, lds, s>>>(a.q, a.k, a.v, a.o, bias, region, n_windows, windows_per_image, scale);
-        else winattn_fwd_kernel<T, HD, false><<<grid, 256, lds, s>>>(a.q, a.k, a.v, a.o, bias, region, n_windows, windows_per_image, scale);
+        if (vec) winattn_fwd_kernel<T, HD, true><<<grid, 256, lds, s>>>(a.q, a.k, a.v, a.o, bias, br, region, n_windows, windows_per_image, scale);
+        else winattn_fwd_kernel<T, HD, false><<<grid, 256, lds, s>>>(a.q, a.k, a.v, a.o, bias, br, region, n_windows, windows_per_image, scale);
     } else {
         vec = vec && al(a.go.p, a.go.ws, a.go.ts, a.go.hs) && al(a.gq.p, a.gq.ws, a.gq.ts, a.gq.hs) &&
               al(a.gk.p, a.gk.ws, a.gk.ts, a.gk.hs) && al(a.gv.p, a.gv.ws, a.gv.ts, a.gv.hs);
         const size_t lds = (2 * NB + 4 * (4 * NT * HD + 4 * 64)) * sizeof(float);
-        if (vec) winattn_bwd_kernel<T, HD, true><<<grid, 256, lds, s>>>(a.q, a.k, a.v, a.go, a.gq, a.gk, a.gv, bias, dbias, region, n_windows, windows_per_image, scale);
-        else winattn_bwd_kernel<T, HD, false><<<grid, 256, lds, s>>>(a.q, a.k, a.v, a.go, a.gq, a.gk, a.gv, bias, dbias, region, n_windows, windows_per_image, scale);
+        if (vec) winattn_bwd_kernel<T, HD, true><<<grid, 256, lds, s>>>(a.q, a.k, a.v, a.go, a.gq, a.gk, a.gv, bias, dbias, br, region, n_windows, windows_per_image, scale);
+        else winattn_bwd_kernel<T, HD, false><<<grid, 256, lds, s>>>(a.q, a.k, a.v, a.go, a.gq, a.gk, a.gv, bias, dbias, br, region, n_windows, windows_per_image, scale);
     }
     GWD_CHECK_LAUNCH();
     return 0;
 }
 
 template <typename T>
-int dispatch_hd(int hd, bool backward, const Args &a, const float *bias, float *dbias, const int *region, long nw, int wpi,
-                int heads, float scale, hipStream_t s) {
+int dispatch_hd(int hd, bool backward, const Args &a, const float *bias, float *dbias, const BiasRef br, const int *region, long nw,
+                int wpi, int heads, float scale, hipStream_t s) {
     switch (hd) {
-        case 4: return launch<T, 4>(backward, a, bias, dbias, region, nw, wpi, heads, scale, s);
-        case 8: return launch<T, 8>(backward, a, bias, dbias, region, nw, wpi, heads, scale, s);
-        case 16: return launch<T, 16>(backward, a, bias, dbias, region, nw, wpi, heads, scale, s);
-        case 32: return launch<T, 32>(backward, a, bias, dbias, region, nw, wpi, heads, scale, s);
+        case 4: return launch<T, 4>(backward, a, bias, dbias, br, region, nw, wpi, heads, scale, s);
+        case 8: return launch<T, 8>(backward, a, bias, dbias, br, region, nw, wpi, heads, scale, s);
+        case 16: return launch<T, 16>(backward, a, bias, dbias, br, region, nw, wpi, heads, scale, s);
+        case 32: return launch<T, 32>(backward, a, bias, dbias, br, region, nw, wpi, heads, scale, s);
         default: return -4;
     }
 }
@@ -325,7 +331,8 @@ int dispatch_hd(int hd, bool backward, const Args &a, const float *bias, float *
 // mfattn.hip: the same problem on the matrix cores (bf16); 0 = launched, 1 = not covered (fall through to the kernels above)
 int gwd_mfattn_window(bool backward, const gwd_strided *q, const gwd_strided *k, const gwd_strided *v, const gwd_strided *o_or_go,
                       const gwd_strided *gq, const gwd_strided *gk, const gwd_strided *gv, const float *bias, float *dbias,
-                      const int32_t *region, int64_t n_windows, int32_t wpi, int32_t heads, int32_t head_dim, float scale, hipStream_t s);
+                      const int32_t *rel_index, int32_t n_rel, const int32_t *region, int64_t n_windows, int32_t wpi, int32_t heads,
+                      int32_t head_dim, float scale, hipStream_t s);
 
 static bool mfma_window_enabled() {          // A/B switch (GWD_MFMA_WINATTN=0: the lane-per-row VALU kernels for bf16 as well)
     static int v = -1;
@@ -337,9 +344,12 @@ static bool mfma_window_enabled() {          // A/B switch (GWD_MFMA_WINATTN=0: 
 }
 
 extern "C" int gwd_winattn_forward(const gwd_strided *q, const gwd_strided *k, const gwd_strided *v, const gwd_strided *o,
-                                   const float *bias, const int32_t *region, int64_t n_windows, int32_t windows_per_image,
-                                   int32_t heads, int32_t head_dim, float scale, int32_t dtype, void *stream) {
+                                   const float *bias, const int32_t *rel_index, int32_t n_rel, const int32_t *region,
+                                   int64_t n_windows, int32_t windows_per_image, int32_t heads, int32_t head_dim, float scale,
+                                   int32_t dtype, void *stream) {
     if (!q || !k || !v || !o || !q->p || !k->p || !v->p || !o->p || !bias || n_windows <= 0 || heads <= 0) return -1;
+    if (rel_index && (n_rel <= 0 || n_rel > 256)) return -1;
+    const BiasRef br{rel_index, heads};
     if (region && windows_per_image <= 0) return -1;
     Args a{};
     a.q = {q->p, q->ws, q->ts, q->hs};
@@ -347,23 +357,26 @@ extern "C" int gwd_winattn_forward(const gwd_strided *q, const gwd_strided *k, c
     a.v = {v->p, v->ws, v->ts, v->hs};
     a.o = {o->p, o->ws, o->ts, o->hs};
     if (dtype == GWD_BF16 && mfma_window_enabled()) {
-        const int rc = gwd_mfattn_window(false, q, k, v, o, nullptr, nullptr, nullptr, bias, nullptr, region, n_windows, windows_per_image,
-                                         heads, head_dim, scale, (hipStream_t)stream);
+        const int rc = gwd_mfattn_window(false, q, k, v, o, nullptr, nullptr, nullptr, bias, nullptr, rel_index, n_rel, region, n_windows,
+                                         windows_per_image, heads, head_dim, scale, (hipStream_t)stream);
         if (rc <= 0) {
             if (rc == 0) GWD_CHECK_LAUNCH();
             return rc;
         }
     }
-    if (dtype == GWD_BF16) return dispatch_hd<__bf16>(head_dim, false, a, bias, nullptr, region, n_windows, windows_per_image, heads, scale, (hipStream_t)stream);
-    if (dtype == GWD_F32) return dispatch_hd<float>(head_dim, false, a, bias, nullptr, region, n_windows, windows_per_image, heads, scale, (hipStream_t)stream);
+    if (dtype == GWD_BF16) return dispatch_hd<__bf16>(head_dim, false, a, bias, nullptr, br, region, n_windows, windows_per_image, heads, scale, (hipStream_t)stream);
+    if (dtype == GWD_F32) return dispatch_hd<float>(head_dim, false, a, bias, nullptr, br, region, n_windows, windows_per_image, heads, scale, (hipStream_t)stream);
     return -2;
 }
 
 extern "C" int gwd_winattn_backward(const gwd_strided *q, const gwd_strided *k, const gwd_strided *v, const gwd_strided *go,
                                     const gwd_strided *gq, const gwd_strided *gk, const gwd_strided *gv, const float *bias,
-                                    float *dbias, const int32_t *region, int64_t n_windows, int32_t windows_per_image,
-                                    int32_t heads, int32_t head_dim, float scale, int32_t dtype, void *stream) {
+                                    float *dbias, const int32_t *rel_index, int32_t n_rel, const int32_t *region, int64_t n_windows,
+                                    int32_t windows_per_image, int32_t heads, int32_t head_dim, float scale, int32_t dtype,
+                                    void *stream) {
     if (!q || !k || !v || !go || !gq || !gk || !gv || !bias || n_windows <= 0 || heads <= 0) return -1;
+    if (rel_index && (n_rel <= 0 || n_rel > 256)) return -1;
+    const BiasRef br{rel_index, heads};
     if (!q->p || !k->p || !v->p || !go->p || !gq->p || !gk->p || !gv->p) return -1;
     if (region && windows_per_image <= 0) return -1;
     Args a{};
@@ -375,14 +388,14 @@ extern "C" int gwd_winattn_backward(const gwd_strided *q, const gwd_strided *k, 
     a.gk = {gk->p, gk->ws, gk->ts, gk->hs};
     a.gv = {gv->p, gv->ws, gv->ts, gv->hs};
     if (dtype == GWD_BF16 && mfma_window_enabled()) {
-        const int rc = gwd_mfattn_window(true, q, k, v, go, gq, gk, gv, bias, dbias, region, n_windows, windows_per_image, heads, head_dim,
-                                         scale, (hipStream_t)stream);
+        const int rc = gwd_mfattn_window(true, q, k, v, go, gq, gk, gv, bias, dbias, rel_index, n_rel, region, n_windows, windows_per_image,
+                                         heads, head_dim, scale, (hipStream_t)stream);
         if (rc <= 0) {
             if (rc == 0) GWD_CHECK_LAUNCH();
             return rc;
         }
     }
-    if (dtype == GWD_BF16) return dispatch_hd<__bf16>(head_dim, true, a, bias, dbias, region, n_windows, windows_per_image, heads, scale, (hipStream_t)stream);
-    if (dtype == GWD_F32) return dispatch_hd<float>(head_dim, true, a, bias, dbias, region, n_windows, windows_per_image, heads, scale, (hipStream_t)stream);
+    if (dtype == GWD_BF16) return dispatch_hd<__bf16>(head_dim, true, a, bias, dbias, br, region, n_windows, windows_per_image, heads, scale, (hipStream_t)stream);
+    if (dtype == GWD_F32) return dispatch_hd<float>(head_dim, true, a, bias, dbias, br, region, n_windows, windows_per_image, heads, scale, (hipStream_t)stream);
     return -2;
 }

@@ -31,6 +31,7 @@ ENTRY_POINTS = [
     "gwd_softmax_masked_forward", "gwd_softmax_scaled_backward", "gwd_query_workspace", "gwd_eval_accumulate", "gwd_colsum_batch", "gwd_conv_wgrad_batch",
     "gwd_plane_loss_forward", "gwd_plane_loss_backward", "gwd_collate",
     "gwd_anchor_depth_forward", "gwd_anchor_depth_backward", "gwd_mha_flash_forward", "gwd_mha_flash_backward",
+    "gwd_ref_scores_forward", "gwd_ref_scores_backward", "gwd_ref_mix_forward", "gwd_ref_mix_backward",
 ]
 
 
@@ -154,8 +155,12 @@ class HipLibrary:
         L.gwd_avgpool_forward.argtypes = [vp, vp] + [i32] * 6 + [vp]
         L.gwd_avgpool_backward.argtypes = [vp, vp] + [i32] * 6 + [vp]
         sp = ctypes.POINTER(Strided)
-        L.gwd_winattn_forward.argtypes = [sp, sp, sp, sp, vp, vp, i64, i32, i32, i32, f32, i32, vp]
-        L.gwd_winattn_backward.argtypes = [sp] * 7 + [vp, vp, vp, i64, i32, i32, i32, f32, i32, vp]
+        L.gwd_winattn_forward.argtypes = [sp, sp, sp, sp, vp, vp, i32, vp, i64, i32, i32, i32, f32, i32, vp]
+        L.gwd_winattn_backward.argtypes = [sp] * 7 + [vp, vp, vp, i32, vp, i64, i32, i32, i32, f32, i32, vp]
+        L.gwd_ref_scores_forward.argtypes = [sp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
+        L.gwd_ref_scores_backward.argtypes = [sp, vp, vp, sp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
+        L.gwd_ref_mix_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+        L.gwd_ref_mix_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_tokattn_forward.argtypes = [sp] * 4 + [i64, i32, i32, f32, i32, vp]
         L.gwd_tokattn_backward.argtypes = [sp] * 7 + [i64, i32, i32, f32, i32, vp]
         L.gwd_certain_sample.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp]
@@ -403,19 +408,49 @@ class HipLibrary:
         self._check(self.lib.gwd_avgpool_backward(_ptr(gy), _ptr(gx), B, H, W, C, k, dtype_code(gy),
                                                   self._stream(gy, gx)), "gwd_avgpool_backward")
 
-    def winattn_forward(self, q, k, v, o, bias, region, wpi, scale):
-        """q,k,v,o: (W, 49, heads, hd) tensors or views; bias (heads,49,49) fp32; region (wpi,49) int32 or None."""
+    def winattn_forward(self, q, k, v, o, bias, region, wpi, scale, rel_index=None):
+        """q,k,v,o: (W, 49, heads, hd) tensors or views; bias (heads,49,49) fp32 - or, with rel_index (49*49 int32), the
+        (n_rel, heads) relative-position TABLE itself; region (wpi,49) int32 or None."""
         W, N, H, D = q.shape
         s = [_strided(t) for t in (q, k, v, o)]
-        self._check(self.lib.gwd_winattn_forward(*[ctypes.byref(x) for x in s], _ptr(bias), _ptr(region), W, wpi, H, D,
-                                                 scale, dtype_code(q), self._stream(q, k, v, o)), "gwd_winattn_forward")
+        n_rel = bias.shape[0] if rel_index is not None else 0
+        self._check(self.lib.gwd_winattn_forward(*[ctypes.byref(x) for x in s], _ptr(bias), _ptr(rel_index), n_rel, _ptr(region), W, wpi,
+                                                 H, D, scale, dtype_code(q), self._stream(q, k, v, o, bias, rel_index)), "gwd_winattn_forward")
 
-    def winattn_backward(self, q, k, v, go, gq, gk, gv, bias, dbias, region, wpi, scale):
+    def winattn_backward(self, q, k, v, go, gq, gk, gv, bias, dbias, region, wpi, scale, rel_index=None):
+        """dbias: same layout as bias (dense, or the table's gradient with rel_index); ACCUMULATED into."""
         W, N, H, D = q.shape
         s = [_strided(t) for t in (q, k, v, go, gq, gk, gv)]
-        self._check(self.lib.gwd_winattn_backward(*[ctypes.byref(x) for x in s], _ptr(bias), _ptr(dbias), _ptr(region), W,
-                                                  wpi, H, D, scale, dtype_code(q), self._stream(q, go, gq)),
-                    "gwd_winattn_backward")
+        n_rel = bias.shape[0] if rel_index is not None else 0
+        self._check(self.lib.gwd_winattn_backward(*[ctypes.byref(x) for x in s], _ptr(bias), _ptr(dbias), _ptr(rel_index), n_rel,
+                                                  _ptr(region), W, wpi, H, D, scale, dtype_code(q),
+                                                  self._stream(q, go, gq, bias, dbias, rel_index)), "gwd_winattn_backward")
+
+    def ref_scores_forward(self, q, ref_k, ra, B, nwin, scale):
+        """q (B*nwin, 49, H, hd) operand / view, ref_k (B, R, H*hd), ra (B, nwin*49, R, H) out."""
+        H, hd, R = q.shape[2], q.shape[3], ref_k.shape[1]
+        sq = _strided(q)
+        self._check(self.lib.gwd_ref_scores_forward(ctypes.byref(sq), _ptr(ref_k), _ptr(ra), B, nwin, R, H, hd, float(scale),
+                                                    dtype_code(q), self._stream(q, ref_k, ra)), "gwd_ref_scores_forward")
+
+    def ref_scores_backward(self, q, ref_k, g, dq, d_ref_k, B, nwin, scale):
+        H, hd, R = q.shape[2], q.shape[3], ref_k.shape[1]
+        sq, sdq = _strided(q), _strided(dq)
+        self._check(self.lib.gwd_ref_scores_backward(ctypes.byref(sq), _ptr(ref_k), _ptr(g), ctypes.byref(sdq), _ptr(d_ref_k), B, nwin,
+                                                     R, H, hd, float(scale), dtype_code(q), self._stream(q, ref_k, g, dq, d_ref_k)),
+                    "gwd_ref_scores_backward")
+
+    def ref_mix_forward(self, ra, ref_v, q_new, att, H):
+        """ra (B, T, R, H), ref_v (B, R, C) -> q_new (B, T, C), att (B, T, R, H) or None."""
+        B, T, R = ra.shape[0], ra.shape[1], ra.shape[2]
+        self._check(self.lib.gwd_ref_mix_forward(_ptr(ra), _ptr(ref_v), _ptr(q_new), _ptr(att), B, T, R, H, ref_v.shape[2] // H,
+                                                 dtype_code(ra), self._stream(ra, ref_v, q_new, att)), "gwd_ref_mix_forward")
+
+    def ref_mix_backward(self, att, ref_v, g, d_ra, d_ref_v, H):
+        B, T, R = att.shape[0], att.shape[1], att.shape[2]
+        self._check(self.lib.gwd_ref_mix_backward(_ptr(att), _ptr(ref_v), _ptr(g), _ptr(d_ra), _ptr(d_ref_v), B, T, R, H,
+                                                  ref_v.shape[2] // H, dtype_code(att), self._stream(att, ref_v, g, d_ra, d_ref_v)),
+                    "gwd_ref_mix_backward")
 
     def tokattn_forward(self, q, k, v, o, scale):
         """q,o: (W,49,heads,4); k,v: (W,49,heads,e) tensors or views."""

@@ -354,10 +354,13 @@ class WindowAttnBase(nn.Module):
         self.qkv = Linear(dim, dim * 3)
         self.proj = Linear(dim, dim)
 
-    def bias_dense(self):
-        """(heads, 49, 49) fp32 relative-position bias (multiscale_transformerr.py:313-315)."""
-        n = WS * WS
-        return ops.table_gather(self.relative_position_bias_table, self.relative_position_index.view(-1)).view(n, n, -1).permute(2, 0, 1)
+    def rel_index(self):
+        """relative_position_index (49, 49) int64 buffer as the flat int32 vector the kernels gather the bias table through
+        (multiscale_transformerr.py:313-315: bias(h, i, j) = table[index[i, j], h]); built once per device."""
+        r = getattr(self, "_rel32", None)
+        if r is None or r.device != self.relative_position_index.device:
+            r = self._rel32 = self.relative_position_index.reshape(-1).to(torch.int32).contiguous()
+        return r
 
 
 class WindowAttention(WindowAttnBase):
@@ -372,23 +375,16 @@ class WindowAttention(WindowAttnBase):
         B_, N, C = xw.shape
         hd = C // HEADS
         qkv = self.qkv(xw).view(B_, N, 3, HEADS, hd)
-        q = qkv[:, :, 0].permute(0, 2, 1, 3)                                        # (B_, nH, N, hd) view
         rqk = self.ref_qk(x_ref)
-        rB, nrf = rqk.shape[0], rqk.shape[1]
-        nwin = B_ // rB
-        ref_q = self.diff_mu.to(rqk.dtype) + self.diff_logsigma.exp().to(rqk.dtype) * rqk[..., :C]
-        ref_k = ref_q.reshape(rB, nrf, HEADS, hd).permute(0, 2, 1, 3)            # (rB, nH, nrf, hd)
-        ref_v = rqk[..., C:].reshape(rB, nrf, HEADS, hd).permute(0, 2, 1, 3)
-        qs = (q * self.scale).reshape(rB, nwin, HEADS, N, hd)
-        ra = torch.einsum("bwhnd,bhrd->bwnrh", qs, ref_k).reshape(rB, nwin * N, nrf, HEADS)  # pixel-major (B, nWin*N, nrf, heads)
+        rB = rqk.shape[0]
+        ref_k = self.diff_mu.to(rqk.dtype) + self.diff_logsigma.exp().to(rqk.dtype) * rqk[..., :C]      # (rB, nrf, C), :289-292
+        ra = ops.ref_scores(qkv, ref_k, rB, self.scale)                          # (rB, nWin*N, nrf, heads): pixel-major map, :295-298
         for _ in range(3):                                                        # :299-302
-            upd = ops.conv2d(ra.contiguous(), self.ref_attn_diffusion.weight, self.ref_attn_diffusion.bias, pad=1)
+            upd = ops.conv2d(ra, self.ref_attn_diffusion.weight, self.ref_attn_diffusion.bias, pad=1)
             ra = ops.inorm_gelu_residual(ra, upd, 1e-5)
-        ra = ra.reshape(rB, nwin, N, nrf, HEADS).permute(0, 1, 4, 2, 3)          # (rB, nwin, nH, N, nrf)
-        att = ops.softmax_lastdim(ra)
-        q_new = torch.einsum("bwhnr,bhrd->bwnhd", att, ref_v).reshape(B_, N, HEADS, hd)      # second *scale: in-kernel
+        q_new = ops.ref_mix(ra, rqk[..., C:], HEADS).view(B_, N, HEADS, hd)      # softmax over the ref tokens, . ref_v; second *scale: in-kernel
         wpi = regions.shape[0] if regions is not None else 1
-        x = ops.window_attention(q_new, qkv[:, :, 1], qkv[:, :, 2], self.bias_dense(), regions, wpi, self.scale)
+        x = ops.window_attention_qkv(q_new, qkv, self.relative_position_bias_table, self.rel_index(), regions, wpi, self.scale)
         return self.proj(x)
 
 
@@ -406,7 +402,7 @@ class WindowClassAttention(WindowAttnBase):
         B_, N, C = xw.shape
         qkv = self.qkv(xw).view(B_, N, 3, HEADS, C // HEADS)
         wpi = regions.shape[0] if regions is not None else 1
-        x = self.proj(ops.window_attention_packed(qkv, self.bias_dense(), regions, wpi, self.scale))
+        x = self.proj(ops.window_attention_packed(qkv, self.relative_position_bias_table, self.rel_index(), regions, wpi, self.scale))
         tdim = dtok.shape[-1]
         tx = torch.cat([x, dtok, stok], dim=-1)
         tC = tx.shape[-1]
@@ -467,7 +463,7 @@ class SwinBlock(nn.Module):
             else:
                 rc, rpos = ref_coors, ref_pos
             x_ref = (ops.point_sample(sx, rc, nearest=True) + ops.point_sample(rpos, rc, nearest=True)).to(x.dtype)   # (B, S, C)
-            aw = self.attn(window_partition(sx), x_ref, mask)
+            aw = self.attn(ops.window_gather(xn, shift), x_ref, mask)          # == window_partition(sx), one index-remapping copy
         else:
             tC = dtok.shape[-1]
             dn = ops.window_gather(self.norm_depth1(dtok).view(B, H, W, tC), shift)
@@ -480,7 +476,7 @@ class SwinBlock(nn.Module):
             s = ops.window_scatter(sw, B, H, W, shift, residual=stok).view(B, H * W, tC)
             s = self.mlp_seg(self.norm_seg2(s), residual=s)
             return x, d, s
-        x = x + unroll_crop(aw, H, W, Hp, Wp, shift).reshape(B, H * W, C)
+        x = ops.window_scatter(aw, B, H, W, shift, residual=x).view(B, H * W, C)     # window reverse + un-shift + crop + skip
         x = self.mlp(self.norm2(x), residual=x)
         return x, None, None
 

@@ -321,34 +321,6 @@ def _nearest_upsample_backward(gv, Hi, Wi):
     return gx
 
 
-_ONEHOT = {}
-
-
-class _TableGatherFn(torch.autograd.Function):
-    """rows = table[index] for a FIXED index vector; the gradient is onehot(index)^T @ g - one small GEMM instead of
-    aten::index_put_(accumulate=True), which sorts its 2 401 indices on every call (39 us x 9 blocks per step)."""
-
-    @staticmethod
-    def forward(ctx, table, index):
-        ctx.index, ctx.rows = index, table.shape[0]
-        return table.index_select(0, index)
-
-    @staticmethod
-    def backward(ctx, g):
-        index = ctx.index
-        key = (index.data_ptr(), index.numel(), ctx.rows, g.dtype, str(g.device))
-        oh = _ONEHOT.get(key)
-        if oh is None:
-            oh = _ONEHOT[key] = torch.zeros(ctx.rows, index.numel(), dtype=g.dtype, device=g.device)
-            oh[index, torch.arange(index.numel(), device=g.device)] = 1
-        return oh @ g.reshape(index.numel(), -1), None
-
-
-def table_gather(table, index):
-    """table[index] (index: fixed int64 vector, e.g. the relative-position index buffer), GEMM backward."""
-    return _TableGatherFn.apply(table, index)
-
-
 def _sink(p, shape=None):
     """(flat-gradient view, hook) of a parameter managed by engine.TrainStep, else None."""
     g = getattr(p, "_gwd_grad", None)
@@ -685,68 +657,174 @@ def avg_pool(x, k):
 
 
 class _WinAttnPackedFn(torch.autograd.Function):
-    """qkv (W, 49, 3, heads, hd) packed as the qkv Linear writes it -> (W, 49, heads*hd)."""
+    """qkv (W, 49, 3, heads, hd) packed as the qkv Linear writes it -> (W, 49, heads*hd).  `table` is the relative-position
+    bias PARAMETER (n_rel, heads), gathered through rel (49*49 int32) inside the kernels; its gradient is accumulated by the
+    backward kernel straight into the flat gradient buffer when the parameter is managed by engine.TrainStep (sink)."""
 
     @staticmethod
-    def forward(ctx, qkv, bias, region, wpi, scale):
+    def forward(ctx, qkv, table, rel, region, wpi, scale, sink):
         qkv = qkv.contiguous()
         W, N, _, H, D = qkv.shape
         out = torch.empty((W, N, H, D), dtype=qkv.dtype, device=qkv.device)
-        bias = bias.contiguous().float()
-        _lib().winattn_forward(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], out, bias, region, wpi, scale)
-        ctx.save_for_backward(qkv, bias, region)
+        tb = table.detach()
+        _lib().winattn_forward(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], out, tb, region, wpi, scale, rel_index=rel)
+        ctx.save_for_backward(qkv, tb, rel, region)
         ctx.cfg = (wpi, scale)
+        ctx.sink = sink
         return out.view(W, N, H * D)
 
     @staticmethod
     def backward(ctx, go):
-        qkv, bias, region = ctx.saved_tensors
+        qkv, tb, rel, region = ctx.saved_tensors
         wpi, scale = ctx.cfg
         W, N, _, H, D = qkv.shape
         go = go.contiguous().view(W, N, H, D)
         g = torch.empty_like(qkv)
-        dbias = torch.zeros_like(bias)
-        _lib().winattn_backward(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], go, g[:, :, 0], g[:, :, 1], g[:, :, 2], bias,
-                                dbias, region, wpi, scale)
-        return g, dbias, None, None, None
+        direct = ctx.sink is not None
+        dtab = ctx.sink[0] if direct else torch.zeros_like(tb)
+        _lib().winattn_backward(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], go, g[:, :, 0], g[:, :, 1], g[:, :, 2], tb, dtab, region,
+                                wpi, scale, rel_index=rel)
+        if direct and ctx.sink[1] is not None:
+            ctx.sink[1]()
+        return g, (None if direct else dtab), None, None, None, None, None
 
 
 class _WinAttnFn(torch.autograd.Function):
-    """Separate q (W,49,H,D), k, v operands (any window/token/head strides, unit channel stride)."""
+    """Separate q (W,49,H,D), k, v operands (any window/token/head strides, unit channel stride); bias table as above."""
 
     @staticmethod
-    def forward(ctx, q, k, v, bias, region, wpi, scale):
+    def forward(ctx, q, k, v, table, rel, region, wpi, scale, sink):
         W, N, H, D = q.shape
         out = torch.empty((W, N, H, D), dtype=q.dtype, device=q.device)
-        bias = bias.contiguous().float()
+        tb = table.detach()
         fix = lambda t: t if t.stride(3) == 1 else t.contiguous()
         q, k, v = fix(q), fix(k), fix(v)
-        _lib().winattn_forward(q, k, v, out, bias, region, wpi, scale)
-        ctx.save_for_backward(q, k, v, bias, region)
+        _lib().winattn_forward(q, k, v, out, tb, region, wpi, scale, rel_index=rel)
+        ctx.save_for_backward(q, k, v, tb, rel, region)
         ctx.cfg = (wpi, scale)
+        ctx.sink = sink
         return out.view(W, N, H * D)
 
     @staticmethod
     def backward(ctx, go):
-        q, k, v, bias, region = ctx.saved_tensors
+        q, k, v, tb, rel, region = ctx.saved_tensors
         wpi, scale = ctx.cfg
         W, N, H, D = q.shape
         go = go.contiguous().view(W, N, H, D)
         gq, gk, gv = (torch.empty((W, N, H, D), dtype=q.dtype, device=q.device) for _ in range(3))
-        dbias = torch.zeros_like(bias)
-        _lib().winattn_backward(q, k, v, go, gq, gk, gv, bias, dbias, region, wpi, scale)
-        return gq, gk, gv, dbias, None, None, None
+        direct = ctx.sink is not None
+        dtab = ctx.sink[0] if direct else torch.zeros_like(tb)
+        _lib().winattn_backward(q, k, v, go, gq, gk, gv, tb, dtab, region, wpi, scale, rel_index=rel)
+        if direct and ctx.sink[1] is not None:
+            ctx.sink[1]()
+        return gq, gk, gv, (None if direct else dtab), None, None, None, None, None
 
 
-def window_attention_packed(qkv, bias, region, windows_per_image, scale):
-    """softmax(scale*q k^T + bias (+shift mask)) v over 49-token windows; qkv (W,49,3,H,D); bias (H,49,49)."""
-    return _WinAttnPackedFn.apply(qkv, bias, region, int(windows_per_image), float(scale))
+class _WinAttnQFn(torch.autograd.Function):
+    """Rewritten query q_new (W,49,H,D) against the k / v slots of the packed projection qkv (W,49,3,H,D): the gradient of qkv
+    comes back as ONE packed tensor (q slot zero) instead of two zero-filled select-backward temporaries and their sum."""
+
+    @staticmethod
+    def forward(ctx, q_new, qkv, table, rel, region, wpi, scale, sink):
+        q_new, qkv = q_new.contiguous(), qkv.contiguous()
+        W, N, H, D = q_new.shape
+        out = torch.empty((W, N, H, D), dtype=q_new.dtype, device=q_new.device)
+        tb = table.detach()
+        _lib().winattn_forward(q_new, qkv[:, :, 1], qkv[:, :, 2], out, tb, region, wpi, scale, rel_index=rel)
+        ctx.save_for_backward(q_new, qkv, tb, rel, region)
+        ctx.cfg = (wpi, scale)
+        ctx.sink = sink
+        return out.view(W, N, H * D)
+
+    @staticmethod
+    def backward(ctx, go):
+        q_new, qkv, tb, rel, region = ctx.saved_tensors
+        wpi, scale = ctx.cfg
+        W, N, H, D = q_new.shape
+        go = go.contiguous().view(W, N, H, D)
+        gq = torch.empty_like(q_new)
+        g = torch.empty_like(qkv)
+        g[:, :, 0].zero_()
+        direct = ctx.sink is not None
+        dtab = ctx.sink[0] if direct else torch.zeros_like(tb)
+        _lib().winattn_backward(q_new, qkv[:, :, 1], qkv[:, :, 2], go, gq, g[:, :, 1], g[:, :, 2], tb, dtab, region, wpi, scale, rel_index=rel)
+        if direct and ctx.sink[1] is not None:
+            ctx.sink[1]()
+        return gq, g, (None if direct else dtab), None, None, None, None, None
 
 
-def window_attention(q, k, v, bias, region, windows_per_image, scale):
+def window_attention_qkv(q_new, qkv, table, rel, region, windows_per_image, scale):
+    """softmax(scale*q_new k^T + bias (+shift mask)) v with k, v = qkv[:, :, 1], qkv[:, :, 2] (the 1/32 stage)."""
+    return _WinAttnQFn.apply(q_new, qkv, table, rel, region, int(windows_per_image), float(scale), _sink(table))
+
+
+def window_attention_packed(qkv, table, rel, region, windows_per_image, scale):
+    """softmax(scale*q k^T + bias (+shift mask)) v over 49-token windows; qkv (W,49,3,H,D); bias(h,i,j) = table[rel[i*49+j], h]."""
+    return _WinAttnPackedFn.apply(qkv, table, rel, region, int(windows_per_image), float(scale), _sink(table))
+
+
+def window_attention(q, k, v, table, rel, region, windows_per_image, scale):
     """Separate q / k / v operands (W, 49, H, D): bf16 on the matrix cores (csrc/mfattn.hip, head_dim 4..32), fp32 on the
     lane-per-row kernels (csrc/winattn.hip)."""
-    return _WinAttnFn.apply(q, k, v, bias, region, int(windows_per_image), float(scale))
+    return _WinAttnFn.apply(q, k, v, table, rel, region, int(windows_per_image), float(scale), _sink(table))
+
+
+class _RefScoresFn(torch.autograd.Function):
+    """ra (B, nwin*49, R, H) = scale * q . ref_k per head (multiscale_transformerr.py:296-298); q is read in place from the packed
+    qkv projection (W, 49, 3, H, hd) and its gradient comes back as ONE packed tensor (k and v slots zero)."""
+
+    @staticmethod
+    def forward(ctx, qkv, ref_k, B, scale):
+        qkv, ref_k = qkv.contiguous(), ref_k.contiguous()
+        W, N, _, H, hd = qkv.shape
+        R = ref_k.shape[1]
+        ra = torch.empty((B, (W // B) * N, R, H), dtype=qkv.dtype, device=qkv.device)
+        _lib().ref_scores_forward(qkv[:, :, 0], ref_k, ra, B, W // B, scale)
+        ctx.save_for_backward(qkv, ref_k)
+        ctx.cfg = (B, scale)
+        return ra
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv, ref_k = ctx.saved_tensors
+        B, scale = ctx.cfg
+        gqkv = torch.zeros_like(qkv)
+        dk = torch.empty(ref_k.shape, dtype=torch.float32, device=g.device)
+        _lib().ref_scores_backward(qkv[:, :, 0], ref_k, g.contiguous(), gqkv[:, :, 0], dk, B, qkv.shape[0] // B, scale)
+        return gqkv, dk.to(ref_k.dtype), None, None
+
+
+class _RefMixFn(torch.autograd.Function):
+    """q_new (B, T, C) = softmax_r(ra) . ref_v per head (multiscale_transformerr.py:304-309)."""
+
+    @staticmethod
+    def forward(ctx, ra, ref_v, H):
+        ra, ref_v = ra.contiguous(), ref_v.contiguous()
+        B, T = ra.shape[0], ra.shape[1]
+        q_new = torch.empty((B, T, ref_v.shape[2]), dtype=ra.dtype, device=ra.device)
+        att = torch.empty_like(ra) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None
+        _lib().ref_mix_forward(ra, ref_v, q_new, att, H)
+        ctx.save_for_backward(att, ref_v)
+        ctx.H = H
+        return q_new
+
+    @staticmethod
+    def backward(ctx, g):
+        att, ref_v = ctx.saved_tensors
+        d_ra = torch.empty_like(att)
+        dv = torch.empty(ref_v.shape, dtype=torch.float32, device=g.device)
+        _lib().ref_mix_backward(att, ref_v, g.contiguous(), d_ra, dv, ctx.H)
+        return d_ra, dv.to(ref_v.dtype), None
+
+
+def ref_scores(qkv, ref_k, images, scale):
+    """qkv (images*nwin, 49, 3, H, hd) packed projection, ref_k (images, R, H*hd) -> (images, nwin*49, R, H)."""
+    return _RefScoresFn.apply(qkv, ref_k, int(images), float(scale))
+
+
+def ref_mix(ra, ref_v, heads):
+    """ra (images, T, R, H), ref_v (images, R, H*hd) -> (images, T, H*hd)."""
+    return _RefMixFn.apply(ra, ref_v, int(heads))
 
 
 class _TokAttnFn(torch.autograd.Function):

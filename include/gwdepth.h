@@ -180,17 +180,38 @@ typedef struct {
 
 /* Fused 7x7 window attention, 49 tokens per window, head_dim in {4, 8, 16, 32}:
  *   O = softmax(scale * Q K^T + bias[head] (+ -100 where region[token_i] != region[token_j])) V
- * bias is the dense [heads][49][49] fp32 relative-position bias; region (optional, int32
+ * bias is the dense [heads][49][49] fp32 relative-position bias when rel_index is NULL; with rel_index (int32 [49*49], the
+ * reference's relative_position_index buffer) bias is the PARAMETER ITSELF, the [n_rel][heads] table (n_rel = 169), and
+ * bias(h, i, j) = table[rel_index[i*49+j]][h] is gathered in the kernel - no dense copy, and the backward accumulates
+ * straight into a table-shaped gradient (multiscale_transformerr.py:313-316).  region (optional, int32
  * [windows_per_image][49]) encodes the SW-MSA shift mask.  Replaces the attention core of
  * WindowAttention / WindowClassAttention (src/models/multiscale_transformerr.py:311-328, 538-556, mask
  * :937-955).  The backward recomputes P, writes dQ/dK/dV and ACCUMULATES dbias (fp32 atomics; caller zeroes). */
 int gwd_winattn_forward(const gwd_strided *q, const gwd_strided *k, const gwd_strided *v, const gwd_strided *o,
-                        const float *bias, const int32_t *region, int64_t n_windows, int32_t windows_per_image,
-                        int32_t heads, int32_t head_dim, float scale, int32_t dtype, void *stream);
+                        const float *bias, const int32_t *rel_index, int32_t n_rel, const int32_t *region, int64_t n_windows,
+                        int32_t windows_per_image, int32_t heads, int32_t head_dim, float scale, int32_t dtype, void *stream);
 int gwd_winattn_backward(const gwd_strided *q, const gwd_strided *k, const gwd_strided *v, const gwd_strided *go,
                          const gwd_strided *gq, const gwd_strided *gk, const gwd_strided *gv, const float *bias,
-                         float *dbias, const int32_t *region, int64_t n_windows, int32_t windows_per_image,
-                         int32_t heads, int32_t head_dim, float scale, int32_t dtype, void *stream);
+                         float *dbias, const int32_t *rel_index, int32_t n_rel, const int32_t *region, int64_t n_windows,
+                         int32_t windows_per_image, int32_t heads, int32_t head_dim, float scale, int32_t dtype, void *stream);
+
+/* Line-point-guided query rewrite of the 1/32-stage WindowAttention (src/models/multiscale_transformerr.py:295-310), the two
+ * batched einsums of the reference as kernels that write the layout their consumer reads:
+ *   ref_scores:  ra[b][t][r][h] = scale * sum_d q[b,t,h,d] * ref_k[b,r,h,d]   (t = window*49 + token; q is the (B*nwin, 49, H, hd)
+ *                operand inside the packed qkv projection; ref_k (B, R, H*hd); ra (B, nwin*49, R, H) = the pixel-major map the
+ *                3x3 "diffusion" conv runs over).  backward: g -> dq (same operand addressing, every element written) and
+ *                d_ref_k fp32 (B, R, H*hd), overwritten.
+ *   ref_mix:     att = softmax over r of ra[b,t,:,h];  q_new[b][t][h*hd+d] = sum_r att[b,t,r,h] * ref_v[b,r,h,d]; att (B,T,R,H)
+ *                is saved for the backward pass (NULL: not written).  backward: att, g -> d_ra (B,T,R,H), d_ref_v fp32.
+ * R <= 128, H <= 64, hd <= 64.  No atomics: sums over the tokens are gathered per output element (bit-reproducible).     */
+int gwd_ref_scores_forward(const gwd_strided *q, const void *ref_k, void *ra, int32_t B, int32_t nwin, int32_t R, int32_t H,
+                           int32_t hd, float scale, int32_t dtype, void *stream);
+int gwd_ref_scores_backward(const gwd_strided *q, const void *ref_k, const void *g, const gwd_strided *dq, float *d_ref_k, int32_t B,
+                            int32_t nwin, int32_t R, int32_t H, int32_t hd, float scale, int32_t dtype, void *stream);
+int gwd_ref_mix_forward(const void *ra, const void *ref_v, void *q_new, void *att, int32_t B, int32_t T, int32_t R, int32_t H,
+                        int32_t hd, int32_t dtype, void *stream);
+int gwd_ref_mix_backward(const void *att, const void *ref_v, const void *g, void *d_ra, float *d_ref_v, int32_t B, int32_t T,
+                         int32_t R, int32_t H, int32_t hd, int32_t dtype, void *stream);
 
 /* Class-token attention of WindowClassAttention (src/models/multiscale_transformerr.py:560-578), per
  * (window, head): A = softmax_c(scale * sum_n q[n][r] k[n][c]), o[n][r] = sum_c A[r][c] v[n][c]; 49 tokens n,

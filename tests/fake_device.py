@@ -396,15 +396,22 @@ class FakeDevice:
             s = s + m.repeat(W // wpi, 1, 1)[:, None]
         return s
 
-    def winattn_forward(self, q, k, v, o, bias, region, wpi, scale):
-        p = F.softmax(self._winattn_scores(q, k, bias, region, wpi, scale), dim=-1)
+    @staticmethod
+    def _dense_bias(bias, rel_index):
+        """(n_rel, heads) table + rel_index (49*49) -> (heads, 49, 49) (multiscale_transformerr.py:313-315)."""
+        if rel_index is None:
+            return bias
+        return bias[rel_index.long()].view(49, 49, -1).permute(2, 0, 1)
+
+    def winattn_forward(self, q, k, v, o, bias, region, wpi, scale, rel_index=None):
+        p = F.softmax(self._winattn_scores(q, k, self._dense_bias(bias, rel_index), region, wpi, scale), dim=-1)
         o.copy_(torch.einsum("whij,wjhd->wihd", p, v.float()))
 
-    def winattn_backward(self, q, k, v, go, gq, gk, gv, bias, dbias, region, wpi, scale):
+    def winattn_backward(self, q, k, v, go, gq, gk, gv, bias, dbias, region, wpi, scale, rel_index=None):
         qf, kf, vf = (t.detach().float().clone().requires_grad_(True) for t in (q, k, v))
         bf = bias.detach().clone().requires_grad_(True)
         with torch.enable_grad():
-            p = F.softmax(self._winattn_scores(qf, kf, bf, region, wpi, scale), dim=-1)
+            p = F.softmax(self._winattn_scores(qf, kf, self._dense_bias(bf, rel_index), region, wpi, scale), dim=-1)
             out = torch.einsum("whij,wjhd->wihd", p, vf)
             g = torch.autograd.grad(out, [qf, kf, vf, bf], go.float())
         gq.copy_(g[0])
@@ -412,6 +419,32 @@ class FakeDevice:
         gv.copy_(g[2])
         if dbias is not None:
             dbias.add_(g[3])
+
+    def ref_scores_forward(self, q, ref_k, ra, B, nwin, scale):
+        """multiscale_transformerr.py:296-298: (q * scale) @ ref_k^T per head, written pixel-major (B, nwin*49, R, H)."""
+        H, hd, R = q.shape[2], q.shape[3], ref_k.shape[1]
+        qs = q.float().reshape(B, nwin * 49, H, hd) * scale
+        ra.copy_(torch.einsum("bthd,brhd->btrh", qs, ref_k.float().reshape(B, R, H, hd)))
+
+    def ref_scores_backward(self, q, ref_k, g, dq, d_ref_k, B, nwin, scale):
+        H, hd, R = q.shape[2], q.shape[3], ref_k.shape[1]
+        gf, kf = g.float(), ref_k.float().reshape(B, R, H, hd)
+        dq.copy_((torch.einsum("btrh,brhd->bthd", gf, kf) * scale).reshape(dq.shape))
+        d_ref_k.copy_((torch.einsum("btrh,bthd->brhd", gf, q.float().reshape(B, nwin * 49, H, hd)) * scale).reshape(d_ref_k.shape))
+
+    def ref_mix_forward(self, ra, ref_v, q_new, att, H):
+        B, T, R = ra.shape[0], ra.shape[1], ra.shape[2]
+        a = F.softmax(ra.float(), dim=2)
+        if att is not None:
+            att.copy_(a)
+        q_new.copy_(torch.einsum("btrh,brhd->bthd", a, ref_v.float().reshape(B, R, H, -1)).reshape(q_new.shape))
+
+    def ref_mix_backward(self, att, ref_v, g, d_ra, d_ref_v, H):
+        B, T, R = att.shape[0], att.shape[1], att.shape[2]
+        a, gf = att.float(), g.float().reshape(B, T, H, -1)
+        da = torch.einsum("bthd,brhd->btrh", gf, ref_v.float().reshape(B, R, H, -1))
+        d_ra.copy_(a * (da - (a * da).sum(2, keepdim=True)))
+        d_ref_v.copy_(torch.einsum("btrh,bthd->brhd", a, gf).reshape(d_ref_v.shape))
 
     def tokattn_forward(self, q, k, v, o, scale):
         a = F.softmax(torch.einsum("wnhr,wnhc->whrc", q.float(), k.float()) * scale, dim=-1)

@@ -280,27 +280,33 @@ def test_avgpool(dev, shape, dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("hd,nwin,wpi,shifted", [(4, 37, 1, False), (4, 24, 12, True), (8, 20, 4, True), (16, 9, 9, True),
                                                   (32, 6, 3, True), (32, 5, 1, False), (8, 2100, 4, True)])
-def test_window_attention(dev, hd, nwin, wpi, shifted, dtype):
+@pytest.mark.parametrize("table", [False, True], ids=["dense_bias", "bias_table"])
+def test_window_attention(dev, hd, nwin, wpi, shifted, dtype, table):
+    """table: the (169, heads) relative-position PARAMETER gathered through relative_position_index inside the kernels, the
+    gradient accumulated into a table-shaped buffer (the product path); dense: a (heads, 49, 49) bias."""
+    from gw_depth_amd.model import relative_position_index
     fake = FakeDevice()
     H = 16
     qkv = rnd(nwin, 49, 3, H, hd, dtype=dtype, seed=1)
-    bias = rnd(H, 49, 49, seed=2, scale=0.5)
+    bias = rnd(169, H, seed=2, scale=0.5) if table else rnd(H, 49, 49, seed=2, scale=0.5)
+    rel = relative_position_index().reshape(-1).to(torch.int32) if table else None
     g = torch.Generator().manual_seed(7)
     region = torch.randint(0, 3, (wpi, 49), generator=g, dtype=torch.int32) if shifted else None
     go = rnd(nwin, 49, H, hd, dtype=dtype, seed=3)
     scale = hd ** -0.5
     o_r = torch.empty(nwin, 49, H, hd, dtype=dtype)
-    fake.winattn_forward(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], o_r, bias, region, wpi, scale)
+    fake.winattn_forward(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], o_r, bias, region, wpi, scale, rel_index=rel)
     g_r, db_r = torch.empty_like(qkv), torch.zeros_like(bias)
     fake.winattn_backward(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], go, g_r[:, :, 0], g_r[:, :, 1], g_r[:, :, 2], bias, db_r,
-                          region, wpi, scale)
+                          region, wpi, scale, rel_index=rel)
     Q = qkv.cuda()
     rg = None if region is None else region.cuda()
+    rl = None if rel is None else rel.cuda()
     o = torch.full_like(o_r, float("nan")).cuda()
-    dev.winattn_forward(Q[:, :, 0], Q[:, :, 1], Q[:, :, 2], o, bias.cuda(), rg, wpi, scale)
+    dev.winattn_forward(Q[:, :, 0], Q[:, :, 1], Q[:, :, 2], o, bias.cuda(), rg, wpi, scale, rel_index=rl)
     G, db = torch.full_like(g_r, float("nan")).cuda(), torch.zeros_like(bias).cuda()
     dev.winattn_backward(Q[:, :, 0], Q[:, :, 1], Q[:, :, 2], go.cuda(), G[:, :, 0], G[:, :, 1], G[:, :, 2], bias.cuda(), db,
-                         rg, wpi, scale)
+                         rg, wpi, scale, rel_index=rl)
     torch.cuda.synchronize()
     assert rel(o, o_r) < TOL[dtype], "forward"
     for idx, name in enumerate(("dq", "dk", "dv")):
@@ -600,6 +606,43 @@ def test_conv_wgrad_row_scale(dev, dtype, spec):
     dev.conv_wgrad(x.cuda(), gy.cuda(), dw1, dims, stride=stride, pad=pad, scale=sc.cuda())
     dev.conv_wgrad_batch([(x.cuda(), gy.cuda(), dw2, dims, dict(stride=stride, pad=pad, scale=sc.cuda()))])
     assert rel(dw1, ref) < TOL[dtype] and rel(dw2, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(8, 9, 40, 16, 32), (2, 4, 40, 16, 32), (1, 1, 7, 16, 8), (3, 2, 128, 4, 64)])
+def test_ref_point_attention_kernels(dev, shape, dtype):
+    """gwd_ref_scores_* / gwd_ref_mix_* (the line-point-guided query rewrite of the 1/32 stage) vs the reference's einsums in
+    fp32 torch (tests/fake_device.py): q read in place from the packed qkv projection, gradients incl. the token sums."""
+    B, nwin, R, H, hd = shape
+    fake = FakeDevice()
+    C, T = H * hd, nwin * 49
+    qkv = rnd(B * nwin, 49, 3, H, hd, dtype=dtype, seed=1)
+    ref_k, ref_v = rnd(B, R, C, dtype=dtype, seed=2), rnd(B, R, C, dtype=dtype, seed=3)
+    g_ra, g_q = rnd(B, T, R, H, dtype=dtype, seed=4), rnd(B, T, C, dtype=dtype, seed=5)
+    scale = hd ** -0.5
+    ra_r = torch.empty(B, T, R, H, dtype=dtype)
+    fake.ref_scores_forward(qkv[:, :, 0], ref_k, ra_r, B, nwin, scale)
+    dq_r, dk_r = torch.zeros_like(qkv), torch.empty(B, R, C)
+    fake.ref_scores_backward(qkv[:, :, 0], ref_k, g_ra, dq_r[:, :, 0], dk_r, B, nwin, scale)
+    qn_r, att_r = torch.empty(B, T, C, dtype=dtype), torch.empty(B, T, R, H, dtype=dtype)
+    fake.ref_mix_forward(ra_r, ref_v, qn_r, att_r, H)
+    dra_r, dv_r = torch.empty(B, T, R, H, dtype=dtype), torch.empty(B, R, C)
+    fake.ref_mix_backward(att_r, ref_v, g_q, dra_r, dv_r, H)
+
+    Q, K, V = qkv.cuda(), ref_k.cuda(), ref_v.cuda()
+    ra = torch.full((B, T, R, H), float("nan"), dtype=dtype, device="cuda")
+    dev.ref_scores_forward(Q[:, :, 0], K, ra, B, nwin, scale)
+    dq, dk = torch.zeros_like(Q), torch.full((B, R, C), float("nan"), device="cuda")
+    dev.ref_scores_backward(Q[:, :, 0], K, g_ra.cuda(), dq[:, :, 0], dk, B, nwin, scale)
+    qn, att = torch.full((B, T, C), float("nan"), dtype=dtype, device="cuda"), torch.full((B, T, R, H), float("nan"), dtype=dtype, device="cuda")
+    dev.ref_mix_forward(ra_r.cuda(), V, qn, att, H)
+    dra, dv = torch.full((B, T, R, H), float("nan"), dtype=dtype, device="cuda"), torch.full((B, R, C), float("nan"), device="cuda")
+    dev.ref_mix_backward(att_r.cuda(), V, g_q.cuda(), dra, dv, H)
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    assert rel(ra, ra_r) < tol and rel(dq[:, :, 0], dq_r[:, :, 0]) < tol and rel(dk, dk_r) < tol
+    assert float(dq[:, :, 1:].abs().max()) == 0.0                      # only the q slot is written
+    assert rel(qn, qn_r) < tol and rel(att, att_r) < tol and rel(dra, dra_r) < 2 * tol and rel(dv, dv_r) < tol
 
 
 MHA_SHAPES = [
