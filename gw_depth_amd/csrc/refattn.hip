@@ -23,58 +23,101 @@ struct QOpW {
     long ws, ts, hs;
 };
 
-// ra[b][t][r][h] = scale * q[b,t,h,:] . refk[b,r,h,:]; one thread per output, h fastest
-template <typename T>
-__global__ void ref_scores_fwd_kernel(QOp q, const T *__restrict__ refk, T *__restrict__ ra, int B, int nwin, int R, int H, int hd,
-                                      float scale) {
-    const long total = (long)B * nwin * 49 * R * H;
-    const int C = H * hd;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int h = (int)(i % H);
-        const int r = (int)((i / H) % R);
-        const long bt = i / ((long)H * R);
-        const int t = (int)(bt % (nwin * 49)), b = (int)(bt / (nwin * 49));
-        const T *qp = (const T *)q.p + ((long)b * nwin + t / 49) * q.ws + (long)(t % 49) * q.ts + (long)h * q.hs;
-        const T *kp = refk + ((long)b * R + r) * C + h * hd;
-        float acc = 0.f;
-        for (int d = 0; d < hd; ++d) acc += to_f32(qp[d]) * to_f32(kp[d]);
-        ra[i] = from_f32<T>(acc * scale);
+template <typename T, int HD>
+__device__ __forceinline__ void load_row(float (&v)[HD], const T *p) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int c = 0; c < HD; c += 8) {
+            const bf16x8 x = *(const bf16x8 *)(p + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[c + j] = (float)x[j];
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < HD; c += 4) {
+            const float4 x = *(const float4 *)(p + c);
+            v[c] = x.x, v[c + 1] = x.y, v[c + 2] = x.z, v[c + 3] = x.w;
+        }
     }
 }
 
-// role 0: dq[b,t,h,d] = scale * sum_r g[b,t,r,h] * refk[b,r,h,d]      (one thread per (b,t,h,d))
-// role 1: drefk[b,r,h,d] = scale * sum_t g[b,t,r,h] * q[b,t,h,d]      (one thread per (b,r,h,d), walks t)
-template <typename T>
-__global__ void ref_scores_bwd_kernel(QOp q, const T *__restrict__ refk, const T *__restrict__ g, QOpW dq, float *__restrict__ drefk,
-                                      int B, int nwin, int R, int H, int hd, float scale, int dq_blocks) {
-    const int C = H * hd, Tn = nwin * 49;
-    if ((int)blockIdx.x < dq_blocks) {
-        const long total = (long)B * Tn * C;
-        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)dq_blocks * blockDim.x) {
-            const int d = (int)(i % hd), h = (int)((i / hd) % H);
-            const long bt = i / C;
-            const int t = (int)(bt % Tn), b = (int)(bt / Tn);
-            const T *gp = g + (bt * R) * H + h;
-            const T *kp = refk + (long)b * R * C + h * hd + d;
+// ra[b][t][r][h] = scale * q[b,t,h,:] . refk[b,r,h,:]: one thread per (b, t, h) keeps its query row in registers and walks the
+// R reference rows (the same for every token of the image: L1-resident)
+template <typename T, int HD>
+__global__ void ref_scores_fwd_kernel(QOp q, const T *__restrict__ refk, T *__restrict__ ra, int B, int nwin, int R, int H, float scale) {
+    const long total = (long)B * nwin * 49 * H;
+    const int C = H * HD, Tn = nwin * 49;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int h = (int)(i % H);
+        const long bt = i / H;
+        const int t = (int)(bt % Tn), b = (int)(bt / Tn);
+        float qv[HD];
+        load_row<T, HD>(qv, (const T *)q.p + ((long)b * nwin + t / 49) * q.ws + (long)(t % 49) * q.ts + (long)h * q.hs);
+        const T *kp = refk + (long)b * R * C + h * HD;
+        T *dst = ra + bt * R * H + h;
+        for (int r = 0; r < R; ++r) {
+            float kv[HD];
+            load_row<T, HD>(kv, kp + (long)r * C);
             float acc = 0.f;
-            for (int r = 0; r < R; ++r) acc += to_f32(gp[(long)r * H]) * to_f32(kp[(long)r * C]);
-            T *dst = (T *)dq.p + ((long)b * nwin + t / 49) * dq.ws + (long)(t % 49) * dq.ts + (long)h * dq.hs + d;
-            *dst = from_f32<T>(acc * scale);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc += qv[d] * kv[d];
+            dst[(long)r * H] = from_f32<T>(acc * scale);
         }
-    } else {
-        const long total = (long)B * R * C;
-        const long nb = gridDim.x - dq_blocks;
-        for (long i = (long)(blockIdx.x - dq_blocks) * blockDim.x + threadIdx.x; i < total; i += nb * blockDim.x) {
-            const int d = (int)(i % hd), h = (int)((i / hd) % H);
-            const int r = (int)((i / C) % R), b = (int)(i / ((long)C * R));
-            const T *gp = g + ((long)b * Tn * R + r) * H + h;
-            float acc = 0.f;
-            for (int t = 0; t < Tn; ++t) {
-                const T *qp = (const T *)q.p + ((long)b * nwin + t / 49) * q.ws + (long)(t % 49) * q.ts + (long)h * q.hs + d;
-                acc += to_f32(gp[(long)t * R * H]) * to_f32(*qp);
-            }
-            drefk[i] = acc * scale;
+    }
+}
+
+// dq[b,t,h,:] = scale * sum_r g[b,t,r,h] * refk[b,r,h,:]: one thread per (b, t, h), HD accumulators
+template <typename T, int HD>
+__global__ void ref_scores_dq_kernel(const T *__restrict__ refk, const T *__restrict__ g, QOpW dq, int B, int nwin, int R, int H, float scale) {
+    const long total = (long)B * nwin * 49 * H;
+    const int C = H * HD, Tn = nwin * 49;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int h = (int)(i % H);
+        const long bt = i / H;
+        const int t = (int)(bt % Tn), b = (int)(bt / Tn);
+        const T *gp = g + bt * R * H + h;
+        const T *kp = refk + (long)b * R * C + h * HD;
+        float acc[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+        for (int r = 0; r < R; ++r) {
+            float kv[HD];
+            load_row<T, HD>(kv, kp + (long)r * C);
+            const float gv = to_f32(gp[(long)r * H]);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] += gv * kv[d];
         }
+        T *dst = (T *)dq.p + ((long)b * nwin + t / 49) * dq.ws + (long)(t % 49) * dq.ts + (long)h * dq.hs;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) dst[d] = from_f32<T>(acc[d] * scale);
+    }
+}
+
+// out[b][r][h][:] = scale * sum_t a[b,t,r,h] * x[b,t,h,:]   (d ref_k: a = g, x = q;  d ref_v: a = att, x = g of q_new)
+// One WAVE per (b, r, h): the lanes split the tokens, HD accumulators each, then a cross-lane sum - no atomics.
+template <typename T, int HD>
+__global__ void token_reduce_kernel(const T *__restrict__ a, QOp x, float *__restrict__ out, int B, int nwin, int R, int H, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, total = (long)B * R * H;
+    if (wave >= total) return;                       // whole waves leave together
+    const int h = (int)(wave % H), r = (int)((wave / H) % R), b = (int)(wave / ((long)H * R));
+    const int Tn = nwin * 49;
+    const T *ap = a + ((long)b * Tn * R + r) * H + h;
+    float acc[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+    for (int t = lane; t < Tn; t += 64) {
+        float xv[HD];
+        load_row<T, HD>(xv, (const T *)x.p + ((long)b * nwin + t / 49) * x.ws + (long)(t % 49) * x.ts + (long)h * x.hs);
+        const float av = to_f32(ap[(long)t * R * H]);
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[d] += av * xv[d];
+    }
+    float *dst = out + ((long)b * R + r) * H * HD + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+        const float s = wave_sum(acc[d]);
+        if (lane == (d & 63)) dst[d] = s * scale;
     }
 }
 
@@ -142,23 +185,6 @@ __global__ void ref_mix_bwd_kernel(const T *__restrict__ att, const T *__restric
         dra[bt * RH + e] = from_f32<T>(to_f32(att[bt * RH + e]) * (da[e] - dot[e % H]));
 }
 
-// drefv[b,r,h,d] = sum_t att[b,t,r,h] * g[b,t,h,d]: one thread per output walks t
-template <typename T>
-__global__ void ref_mix_bwd_v_kernel(const T *__restrict__ att, const T *__restrict__ g, float *__restrict__ drefv, int B, int Tn, int R,
-                                     int H, int hd) {
-    const int C = H * hd;
-    const long total = (long)B * R * C;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int e = (int)(i % C), h = e / hd;
-        const int r = (int)((i / C) % R), b = (int)(i / ((long)C * R));
-        const T *ap = att + ((long)b * Tn * R + r) * H + h;
-        const T *gp = g + (long)b * Tn * C + e;
-        float acc = 0.f;
-        for (int t = 0; t < Tn; ++t) acc += to_f32(ap[(long)t * R * H]) * to_f32(gp[(long)t * C]);
-        drefv[i] = acc;
-    }
-}
-
 bool shape_ok(int B, int nwin, int R, int H, int hd) { return B > 0 && nwin > 0 && R > 0 && R <= 128 && H > 0 && H <= 64 && hd > 0 && hd <= 64; }
 int blocks_for(long n, int per, int cap) {
     long b = (n + per - 1) / per;
@@ -167,17 +193,37 @@ int blocks_for(long n, int per, int cap) {
 
 }  // namespace
 
-// q: (B*nwin, 49, H, hd) strided operand; ref_k (B, R, H*hd); ra OUT (B, nwin*49, R, H), all `dtype`.
+#define HD_SWITCH(hd, CALL)            \
+    switch (hd) {                      \
+        case 8: { CALL(8) } break;     \
+        case 16: { CALL(16) } break;   \
+        case 32: { CALL(32) } break;   \
+        case 64: { CALL(64) } break;   \
+        default: return -4;            \
+    }
+
+bool q_aligned(const gwd_strided *q, int32_t dtype) {
+    const int a = dtype == GWD_BF16 ? 8 : 4;          // 16-byte row pieces
+    return (uintptr_t)q->p % 16 == 0 && q->ws % a == 0 && q->ts % a == 0 && q->hs % a == 0;
+}
+
+// q: (B*nwin, 49, H, hd) strided operand; ref_k (B, R, H*hd); ra OUT (B, nwin*49, R, H), all `dtype`.  hd in {8, 16, 32, 64}.
 extern "C" int gwd_ref_scores_forward(const gwd_strided *q, const void *ref_k, void *ra, int32_t B, int32_t nwin, int32_t R, int32_t H,
                                       int32_t hd, float scale, int32_t dtype, void *stream) {
     if (!q || !q->p || !ref_k || !ra || !shape_ok(B, nwin, R, H, hd)) return -1;
+    if (!q_aligned(q, dtype) || (uintptr_t)ref_k % 16) return -5;
     const QOp qo{q->p, q->ws, q->ts, q->hs};
-    const long total = (long)B * nwin * 49 * R * H;
-    const int grid = blocks_for(total, 256, 16384);
+    const int grid = blocks_for((long)B * nwin * 49 * H, 64, 16384);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GWD_BF16) ref_scores_fwd_kernel<__bf16><<<grid, 256, 0, s>>>(qo, (const __bf16 *)ref_k, (__bf16 *)ra, B, nwin, R, H, hd, scale);
-    else if (dtype == GWD_F32) ref_scores_fwd_kernel<float><<<grid, 256, 0, s>>>(qo, (const float *)ref_k, (float *)ra, B, nwin, R, H, hd, scale);
-    else return -2;
+    if (dtype == GWD_BF16) {
+#define CALL(HD_) ref_scores_fwd_kernel<__bf16, HD_><<<grid, 64, 0, s>>>(qo, (const __bf16 *)ref_k, (__bf16 *)ra, B, nwin, R, H, scale);
+        HD_SWITCH(hd, CALL)
+#undef CALL
+    } else if (dtype == GWD_F32) {
+#define CALL(HD_) ref_scores_fwd_kernel<float, HD_><<<grid, 64, 0, s>>>(qo, (const float *)ref_k, (float *)ra, B, nwin, R, H, scale);
+        HD_SWITCH(hd, CALL)
+#undef CALL
+    } else return -2;
     GWD_CHECK_LAUNCH();
     return 0;
 }
@@ -187,16 +233,25 @@ extern "C" int gwd_ref_scores_backward(const gwd_strided *q, const void *ref_k, 
                                        int32_t B, int32_t nwin, int32_t R, int32_t H, int32_t hd, float scale, int32_t dtype,
                                        void *stream) {
     if (!q || !q->p || !dq || !dq->p || !ref_k || !g || !d_ref_k || !shape_ok(B, nwin, R, H, hd)) return -1;
+    if (!q_aligned(q, dtype) || (uintptr_t)ref_k % 16) return -5;
     const QOp qo{q->p, q->ws, q->ts, q->hs};
     const QOpW dqo{dq->p, dq->ws, dq->ts, dq->hs};
-    const int dq_blocks = blocks_for((long)B * nwin * 49 * H * hd, 256, 8192);
-    const int dk_blocks = blocks_for((long)B * R * H * hd, 64, 8192);
+    const int grid = blocks_for((long)B * nwin * 49 * H, 64, 16384);
+    const unsigned rgrid = (unsigned)(((long)B * R * H + 3) / 4);          // 4 waves per workgroup, one (b, r, h) each
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GWD_BF16)
-        ref_scores_bwd_kernel<__bf16><<<dq_blocks + dk_blocks, 256, 0, s>>>(qo, (const __bf16 *)ref_k, (const __bf16 *)g, dqo, d_ref_k, B, nwin, R, H, hd, scale, dq_blocks);
-    else if (dtype == GWD_F32)
-        ref_scores_bwd_kernel<float><<<dq_blocks + dk_blocks, 256, 0, s>>>(qo, (const float *)ref_k, (const float *)g, dqo, d_ref_k, B, nwin, R, H, hd, scale, dq_blocks);
-    else return -2;
+    if (dtype == GWD_BF16) {
+#define CALL(HD_)                                                                                                             \
+    ref_scores_dq_kernel<__bf16, HD_><<<grid, 64, 0, s>>>((const __bf16 *)ref_k, (const __bf16 *)g, dqo, B, nwin, R, H, scale);    \
+    token_reduce_kernel<__bf16, HD_><<<rgrid, 256, 0, s>>>((const __bf16 *)g, qo, d_ref_k, B, nwin, R, H, scale);
+        HD_SWITCH(hd, CALL)
+#undef CALL
+    } else if (dtype == GWD_F32) {
+#define CALL(HD_)                                                                                                             \
+    ref_scores_dq_kernel<float, HD_><<<grid, 64, 0, s>>>((const float *)ref_k, (const float *)g, dqo, B, nwin, R, H, scale);       \
+    token_reduce_kernel<float, HD_><<<rgrid, 256, 0, s>>>((const float *)g, qo, d_ref_k, B, nwin, R, H, scale);
+        HD_SWITCH(hd, CALL)
+#undef CALL
+    } else return -2;
     GWD_CHECK_LAUNCH();
     return 0;
 }
@@ -216,18 +271,26 @@ extern "C" int gwd_ref_mix_forward(const void *ra, const void *ref_v, void *q_ne
 }
 
 // att (B, T, R, H) from the forward, g (B, T, H*hd) -> d_ra (B, T, R, H) and d_ref_v fp32 (B, R, H*hd), both overwritten.
+// T must be a multiple of 49 (tokens of whole windows).
 extern "C" int gwd_ref_mix_backward(const void *att, const void *ref_v, const void *g, void *d_ra, float *d_ref_v, int32_t B, int32_t T,
                                     int32_t R, int32_t H, int32_t hd, int32_t dtype, void *stream) {
-    if (!att || !ref_v || !g || !d_ra || !d_ref_v || T <= 0 || !shape_ok(B, 1, R, H, hd)) return -1;
+    if (!att || !ref_v || !g || !d_ra || !d_ref_v || T <= 0 || T % 49 || !shape_ok(B, 1, R, H, hd)) return -1;
+    if ((uintptr_t)g % 16) return -5;
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = ((size_t)H * hd + (size_t)R * H + H) * sizeof(float);
-    const int vb = blocks_for((long)B * R * H * hd, 64, 8192);
+    const unsigned rgrid = (unsigned)(((long)B * R * H + 3) / 4);
+    const long C = (long)H * hd;
+    const QOp go{g, 49 * C, C, hd};                    // g of q_new viewed as the (B*nwin, 49, H, hd) operand
     if (dtype == GWD_BF16) {
         ref_mix_bwd_kernel<__bf16><<<(unsigned)((long)B * T), 256, lds, s>>>((const __bf16 *)att, (const __bf16 *)ref_v, (const __bf16 *)g, (__bf16 *)d_ra, R, H, hd, T);
-        ref_mix_bwd_v_kernel<__bf16><<<vb, 64, 0, s>>>((const __bf16 *)att, (const __bf16 *)g, d_ref_v, B, T, R, H, hd);
+#define CALL(HD_) token_reduce_kernel<__bf16, HD_><<<rgrid, 256, 0, s>>>((const __bf16 *)att, go, d_ref_v, B, T / 49, R, H, 1.0f);
+        HD_SWITCH(hd, CALL)
+#undef CALL
     } else if (dtype == GWD_F32) {
         ref_mix_bwd_kernel<float><<<(unsigned)((long)B * T), 256, lds, s>>>((const float *)att, (const float *)ref_v, (const float *)g, (float *)d_ra, R, H, hd, T);
-        ref_mix_bwd_v_kernel<float><<<vb, 64, 0, s>>>((const float *)att, (const float *)g, d_ref_v, B, T, R, H, hd);
+#define CALL(HD_) token_reduce_kernel<float, HD_><<<rgrid, 256, 0, s>>>((const float *)att, go, d_ref_v, B, T / 49, R, H, 1.0f);
+        HD_SWITCH(hd, CALL)
+#undef CALL
     } else return -2;
     GWD_CHECK_LAUNCH();
     return 0;

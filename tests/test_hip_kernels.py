@@ -289,19 +289,19 @@ def test_window_attention(dev, hd, nwin, wpi, shifted, dtype, table):
     H = 16
     qkv = rnd(nwin, 49, 3, H, hd, dtype=dtype, seed=1)
     bias = rnd(169, H, seed=2, scale=0.5) if table else rnd(H, 49, 49, seed=2, scale=0.5)
-    rel = relative_position_index().reshape(-1).to(torch.int32) if table else None
+    ridx = relative_position_index().reshape(-1).to(torch.int32) if table else None
     g = torch.Generator().manual_seed(7)
     region = torch.randint(0, 3, (wpi, 49), generator=g, dtype=torch.int32) if shifted else None
     go = rnd(nwin, 49, H, hd, dtype=dtype, seed=3)
     scale = hd ** -0.5
     o_r = torch.empty(nwin, 49, H, hd, dtype=dtype)
-    fake.winattn_forward(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], o_r, bias, region, wpi, scale, rel_index=rel)
+    fake.winattn_forward(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], o_r, bias, region, wpi, scale, rel_index=ridx)
     g_r, db_r = torch.empty_like(qkv), torch.zeros_like(bias)
     fake.winattn_backward(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], go, g_r[:, :, 0], g_r[:, :, 1], g_r[:, :, 2], bias, db_r,
-                          region, wpi, scale, rel_index=rel)
+                          region, wpi, scale, rel_index=ridx)
     Q = qkv.cuda()
     rg = None if region is None else region.cuda()
-    rl = None if rel is None else rel.cuda()
+    rl = None if ridx is None else ridx.cuda()
     o = torch.full_like(o_r, float("nan")).cuda()
     dev.winattn_forward(Q[:, :, 0], Q[:, :, 1], Q[:, :, 2], o, bias.cuda(), rg, wpi, scale, rel_index=rl)
     G, db = torch.full_like(g_r, float("nan")).cuda(), torch.zeros_like(bias).cuda()
