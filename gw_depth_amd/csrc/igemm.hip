@@ -264,6 +264,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const gwd_conv_desc d) {
     T *y = (T *)d.y;
     T *z = (T *)d.z;
     const T *res = (const T *)d.residual;
+    const T *mul = (const T *)d.mult;
     if constexpr (sizeof(T) == 2) {
         if ((N & 7) == 0) {
             // each wave transposes one 32x32 accumulator tile at a time through a private LDS patch, then every
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const gwd_conv_desc d) {
                             const f32x4 hi = *(const f32x4 *)(stage + row * 36 + vc + 4);
                             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                             const size_t o = (size_t)m * N + nb;
-                            if (res) {
+                            if (res && !mul) {
                                 const bf16x8 rv = *(const bf16x8 *)(res + o);
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e] + (float)rv[e];
@@ -310,8 +311,18 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const gwd_conv_desc d) {
                                 for (int e = 0; e < 8; ++e) out[e] = (__bf16)v[e];
                                 *(bf16x8 *)(z + o) = out;
                             }
+                            if (mul) {                   // y = act_scale * act(v) * mult + residual (dropout, then the skip)
+                                const bf16x8 mv = *(const bf16x8 *)(mul + o);
+                                bf16x8 rv;
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) out[e] = (__bf16)(apply_act(v[e], d.act) * d.act_scale);
+                                for (int e = 0; e < 8; ++e) rv[e] = (__bf16)0.0f;
+                                if (res) rv = *(const bf16x8 *)(res + o);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) out[e] = (__bf16)(apply_act(v[e], d.act) * d.act_scale * (float)mv[e] + (float)rv[e]);
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) out[e] = (__bf16)(apply_act(v[e], d.act) * d.act_scale);
+                            }
                             *(bf16x8 *)(y + o) = out;
                         }
                     }
@@ -334,9 +345,10 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const gwd_conv_desc d) {
                 if (m >= M) continue;
                 const size_t o = (size_t)m * N + n;
                 float v = acc[i][j][r] * sc + sh;
-                if (res) v += to_f32(res[o]);
+                if (res && !mul) v += to_f32(res[o]);
                 if (z) z[o] = from_f32<T>(v);
                 v = apply_act(v, d.act) * d.act_scale;
+                if (mul) v = v * to_f32(mul[o]) + (res ? to_f32(res[o]) : 0.f);
                 y[o] = from_f32<T>(v);
             }
         }
@@ -551,6 +563,7 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
     T *y = (T *)d.y;
     T *z = (T *)d.z;
     const T *res = (const T *)d.residual;
+    const T *mul = (const T *)d.mult;
     float *stage = (float *)smem + wave * (32 * 36);
     const int vr = lane >> 2, vc = (lane & 3) * 8;
 #pragma unroll
@@ -578,7 +591,7 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
                     const f32x4 hi = *(const f32x4 *)(stage + row * 36 + vc + 4);
                     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     const size_t o = (size_t)m * N + nb;
-                    if (res) {
+                    if (res && !mul) {
                         const bf16x8 rv = *(const bf16x8 *)(res + o);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e] + (float)rv[e];
@@ -592,8 +605,18 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
                         for (int e = 0; e < 8; ++e) out[e] = (__bf16)v[e];
                         *(bf16x8 *)(z + o) = out;
                     }
+                    if (mul) {                           // y = act_scale * act(v) * mult + residual (dropout, then the skip)
+                        const bf16x8 mv = *(const bf16x8 *)(mul + o);
+                        bf16x8 rv;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) out[e] = (__bf16)(apply_act(v[e], d.act) * d.act_scale);
+                        for (int e = 0; e < 8; ++e) rv[e] = (__bf16)0.0f;
+                        if (res) rv = *(const bf16x8 *)(res + o);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) out[e] = (__bf16)(apply_act(v[e], d.act) * d.act_scale * (float)mv[e] + (float)rv[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) out[e] = (__bf16)(apply_act(v[e], d.act) * d.act_scale);
+                    }
                     *(bf16x8 *)(y + o) = out;
                 }
             }

@@ -186,7 +186,7 @@ bool thin_common(const gwd_conv_desc *d) {
 
 // 1 = launched, 0 = not a thin problem (caller continues with the implicit-GEMM kernels)
 int gwd_thin_conv_forward(const gwd_conv_desc *d, hipStream_t s) {
-    if (!thin_common(d)) return 0;
+    if (!thin_common(d) || d->mult) return 0;
     const unsigned tiles = (unsigned)(d->B * ((d->Hi + TILE - 1) / TILE) * ((d->Wi + TILE - 1) / TILE));
     if (d->gather == GWD_GATHER_CONV && d->Cin == C && (d->Cout == 1 || d->Cout == 2) && !d->residual) {
         if (d->Cout == 1) thin_fwd_kernel<1><<<tiles, 256, 0, s>>>(*d);

@@ -42,7 +42,7 @@ class HipUnavailable(RuntimeError):
 class ConvDesc(ctypes.Structure):
     _fields_ = [("x", ctypes.c_void_p), ("w", ctypes.c_void_p), ("y", ctypes.c_void_p), ("z", ctypes.c_void_p),
                 ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("residual", ctypes.c_void_p),
-                ("zero_page", ctypes.c_void_p)] + \
+                ("zero_page", ctypes.c_void_p), ("mult", ctypes.c_void_p)] + \
                [(n, ctypes.c_int32) for n in ("B", "Hi", "Wi", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad",
                                               "gather", "Hv", "Wv", "act")] + \
                [("act_scale", ctypes.c_float), ("dtype", ctypes.c_int32)]
@@ -209,12 +209,13 @@ class HipLibrary:
     # ------------------------------------------------------------------ entry points
     @staticmethod
     def _desc(x, w, y, dims, z=None, scale=None, shift=None, residual=None, stride=1, pad=0,
-              gather=GATHER_CONV, virt=(0, 0), act=ACT_NONE, act_scale=1.0):
+              gather=GATHER_CONV, virt=(0, 0), act=ACT_NONE, act_scale=1.0, mult=None):
         B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW = dims
         d = ConvDesc()
         d.x, d.w, d.y, d.z = _ptr(x), _ptr(w), _ptr(y), _ptr(z)
         d.scale, d.shift, d.residual = _ptr(scale), _ptr(shift), _ptr(residual)
         d.zero_page = _zero_page(x.device)
+        d.mult = _ptr(mult)
         d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW = B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW
         d.stride, d.pad, d.gather, d.Hv, d.Wv = stride, pad, gather, virt[0], virt[1]
         d.act, d.act_scale, d.dtype = act, act_scale, dtype_code(x)

@@ -166,6 +166,41 @@ class Joiner(nn.Module):
 
 
 # ------------------------------------------------------------------------------------ DETR branch
+class DropPool:
+    """Every dropout multiplier (0 or 1/(1-p)) of one DETR forward pass from ONE ATen launch: F.dropout over a persistent
+    tensor of ones (ATen's graph-safe Philox stream decides), handed out as slices.  The consumers are kernel epilogues
+    (ops.linear(mult=...): x + dropout(sublayer) in the producing GEMM) and the attention kernels - no dropout, masked-scale
+    or residual-add launch is left in the DETR branch.  take() returns None when dropout is off."""
+
+    def __init__(self):
+        self.ones, self.buf, self.off = None, None, 0
+
+    def begin(self, total, p, training, dtype, device):
+        self.buf, self.off = None, 0
+        if not training or p <= 0 or total <= 0 or device.type != "cuda":
+            return self
+        total = (total + 7) // 8 * 8
+        if self.ones is None or self.ones.numel() < total or self.ones.dtype != dtype or self.ones.device != device:
+            self.ones = torch.ones(total, dtype=dtype, device=device)
+        self.buf = F.dropout(self.ones[:total], p, True)
+        return self
+
+    def take(self, *shape):
+        if self.buf is None:
+            return None
+        n = 1
+        for d in shape:
+            n *= int(d)
+        out = self.buf[self.off:self.off + n].view(*shape)
+        self.off += (n + 7) // 8 * 8                     # 16-byte aligned slices
+        return out
+
+
+def _drop(t, p, training, pool):
+    """F.dropout for the paths without a multiplier pool (CPU host-logic tests, fp32 parity mode with dropout on)."""
+    return F.dropout(t, p, training)
+
+
 class MultiheadAttention(nn.Module):
     """Packed in-proj attention, /root/reference/src/models/multi_head_attention.py:117-380, batch-major."""
 
@@ -177,33 +212,35 @@ class MultiheadAttention(nn.Module):
         nn.init.xavier_uniform_(self.in_proj_weight)
         self.dim, self.heads, self.dropout = dim, heads, dropout
 
-    def forward(self, query, key, value, key_padding_mask=None):
+    def forward(self, query, key, value, key_padding_mask=None, pool=None, residual=None, out_mult=None):
+        """out_proj(attention) [* out_mult + residual]: the sub-layer's dropout and skip ride in the out-projection's epilogue
+        when the caller passes them (transformer.py:149-162)."""
         B, L, E = query.shape
         S = key.shape[1]
         H, hd = self.heads, E // self.heads
         W, b = self.in_proj_weight, self.in_proj_bias
         scale = float(hd) ** -0.5
+        amult = pool.take(B, H, L, S) if pool is not None else None
         if query is key:
             qk = ops.linear(query, W, b, rows=(0, 2 * E))
             v = ops.linear(value, W, b, rows=(2 * E, 3 * E))
-            fused = ops.mha_core(qk, None, v, H, key_padding_mask, self.dropout, self.training, scale)
+            fused = ops.mha_core(qk, None, v, H, key_padding_mask, self.dropout, self.training, scale, amult)
             q, k = qk[..., :E], qk[..., E:]
         else:
             q = ops.linear(query, W, b, rows=(0, E))
             k = ops.linear(key, W, b, rows=(E, 2 * E))
             v = ops.linear(value, W, b, rows=(2 * E, 3 * E))
-            fused = ops.mha_core(q, k, v, H, key_padding_mask, self.dropout, self.training, scale)
-        if fused is not None:               # bf16: one matrix-core kernel each way, no L x S tensor, no head split / merge copies
-            return self.out_proj(fused)
-        # fp32 parity mode: the unfused arithmetic of the reference
-        q = q.reshape(B, L, H, hd).transpose(1, 2)
-        k = k.reshape(B, S, H, hd).transpose(1, 2)
-        v = v.reshape(B, S, H, hd).transpose(1, 2)
-        # q * scaling and masked_fill(-inf) (multi_head_attention.py:329-352) are folded into the softmax kernel
-        att = ops.attention_softmax(q @ k.transpose(-2, -1), key_padding_mask, float(hd) ** -0.5)
-        att = F.dropout(att, self.dropout, self.training)
-        out = (att @ v).transpose(1, 2).reshape(B, L, E)
-        return self.out_proj(out)
+            fused = ops.mha_core(q, k, v, H, key_padding_mask, self.dropout, self.training, scale, amult)
+        if fused is None:                   # fp32 parity mode: the unfused arithmetic of the reference
+            q = q.reshape(B, L, H, hd).transpose(1, 2)
+            k = k.reshape(B, S, H, hd).transpose(1, 2)
+            v = v.reshape(B, S, H, hd).transpose(1, 2)
+            # q * scaling and masked_fill(-inf) (multi_head_attention.py:329-352) are folded into the softmax kernel
+            att = ops.attention_softmax(q @ k.transpose(-2, -1), key_padding_mask, scale)
+            att = att * amult if amult is not None else F.dropout(att, self.dropout, self.training)
+            fused = (att @ v).transpose(1, 2).reshape(B, L, E)
+        # bf16: one matrix-core kernel each way, no L x S tensor, no head split / merge copies
+        return self.out_proj(fused, residual=residual, mult=out_mult)
 
 
 class EncoderLayer(nn.Module):
@@ -214,9 +251,13 @@ class EncoderLayer(nn.Module):
         self.norm1, self.norm2 = LayerNorm(d), LayerNorm(d)
         self.p = dropout
 
-    def forward(self, x, pos, kpm):
+    def forward(self, x, pos, kpm, pool=None):
         """TransformerEncoderLayer.forward_post, /root/reference/src/models/transformer.py:149-162."""
         qk = x + pos
+        if pool is not None and pool.buf is not None:      # dropout multipliers + skips inside the producing GEMMs' epilogues
+            x = self.norm1(self.self_attn(qk, qk, x, kpm, pool, residual=x, out_mult=pool.take(*x.shape)))
+            h = self.linear1(x, ACT_RELU, mult=pool.take(*x.shape[:-1], self.linear1.weight.shape[0]))
+            return self.norm2(self.linear2(h, residual=x, mult=pool.take(*x.shape)))
         x = self.norm1(x + F.dropout(self.self_attn(qk, qk, x, kpm), self.p, self.training))
         ff = self.linear2(F.dropout(self.linear1(x, ACT_RELU), self.p, self.training))
         return self.norm2(x + F.dropout(ff, self.p, self.training))
@@ -231,9 +272,14 @@ class DecoderLayer(nn.Module):
         self.norm1, self.norm2, self.norm3 = LayerNorm(d), LayerNorm(d), LayerNorm(d)
         self.p = dropout
 
-    def forward(self, tgt, memory, mem_pos, pos, qpos, kpm):
+    def forward(self, tgt, memory, mem_pos, pos, qpos, kpm, pool=None):
         """TransformerDecoderLayer.forward_post, /root/reference/src/models/transformer.py:212-233."""
         qk = tgt + qpos
+        if pool is not None and pool.buf is not None:
+            tgt = self.norm1(self.self_attn(qk, qk, tgt, None, pool, residual=tgt, out_mult=pool.take(*tgt.shape)))
+            tgt = self.norm2(self.multihead_attn(tgt + qpos, mem_pos, memory, kpm, pool, residual=tgt, out_mult=pool.take(*tgt.shape)))
+            h = self.linear1(tgt, ACT_RELU, mult=pool.take(*tgt.shape[:-1], self.linear1.weight.shape[0]))
+            return self.norm3(self.linear2(h, residual=tgt, mult=pool.take(*tgt.shape)))
         tgt = self.norm1(tgt + F.dropout(self.self_attn(qk, qk, tgt), self.p, self.training))
         t2 = self.multihead_attn(tgt + qpos, mem_pos, memory, kpm)
         tgt = self.norm2(tgt + F.dropout(t2, self.p, self.training))
@@ -267,14 +313,24 @@ class Transformer(nn.Module):
         x = src.flatten(1, 2)
         pos = pos.flatten(1, 2).to(x.dtype)
         kpm = mask.flatten(1)
+        L, d, Q, H = x.shape[1], x.shape[2], query_embed.shape[0], self.nhead
+        p = self.encoder.layers[0].p if len(self.encoder.layers) else 0.0
+        ff = self.encoder.layers[0].linear1.weight.shape[0] if len(self.encoder.layers) else 0
+        pool = None
+        if x.is_cuda and x.dtype == torch.bfloat16 and self.training and p > 0:
+            n_enc = len(self.encoder.layers) * (B * H * L * L + 2 * B * L * d + B * L * ff + 32)
+            n_dec = len(self.decoder.layers) * (B * H * Q * Q + B * H * Q * L + 3 * B * Q * d + B * Q * ff + 48)
+            if not hasattr(self, "_pool"):
+                self._pool = DropPool()
+            pool = self._pool.begin(n_enc + n_dec, p, True, x.dtype, x.device)
         for layer in self.encoder.layers:
-            x = layer(x, pos, kpm)
+            x = layer(x, pos, kpm, pool)
         memory, mem_pos = x, x + pos
         qpos = query_embed.to(x.dtype).unsqueeze(0).expand(B, -1, -1)
         tgt = torch.zeros_like(qpos)
         inter = []
         for layer in self.decoder.layers:
-            tgt = layer(tgt, memory, mem_pos, pos, qpos, kpm)
+            tgt = layer(tgt, memory, mem_pos, pos, qpos, kpm, pool)
             inter.append(self.decoder.norm(tgt))
         return torch.stack(inter)
 

@@ -229,10 +229,11 @@ def _weight_transposed(w, row_scale, dtype):
 
 
 class _ConvFn(torch.autograd.Function):
-    """y = act_scale * act(conv(x, w * row_scale) + shift + residual), all in one kernel launch."""
+    """y = act_scale * act(conv(x, w * row_scale) + shift + residual), all in one kernel launch; with `mult` (an element-wise
+    dropout multiplier) y = act_scale * act(conv + shift) * mult + residual: the skip is added after the dropout."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual, row_scale, shift_const, stride, pad, act, act_scale, virt, shadow, sinks):
+    def forward(ctx, x, w, bias, residual, row_scale, shift_const, stride, pad, act, act_scale, virt, shadow, sinks, mult=None):
         lib = _lib()
         B, Hi, Wi, Cin = x.shape
         Cout, KH, KW, Cw = w.shape
@@ -254,20 +255,29 @@ class _ConvFn(torch.autograd.Function):
         if residual is not None:
             residual = residual.contiguous()
         dims = (B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW)
+        if mult is not None:
+            mult = mult.contiguous()
         lib.conv_forward(x, wk, y, dims, z=z, shift=shift, residual=residual, stride=stride, pad=pad, gather=gather,
-                         virt=vv, act=act, act_scale=act_scale)
+                         virt=vv, act=act, act_scale=act_scale, mult=mult)
         ctx.cfg = (dims, stride, pad, act, act_scale, gather, vv, bias is not None, residual is not None)
         ctx.sinks = sinks
-        ctx.save_for_backward(x, w, row_scale, z if act == ACT_GELU else (y if act != ACT_NONE else None))
+        if mult is not None and act not in (ACT_NONE, ACT_RELU):
+            raise ValueError("conv2d: a dropout multiplier is supported behind no activation or ReLU only")
+        # ReLU's backward needs only the sign of the output: y * mult has the sign of relu(v) wherever mult > 0, and where
+        # mult == 0 the incoming gradient is multiplied by zero anyway
+        ctx.save_for_backward(x, w, row_scale, z if act == ACT_GELU else (y if act != ACT_NONE else None), mult)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         lib = _lib()
-        x, w, row_scale, ref = ctx.saved_tensors
+        x, w, row_scale, ref, mult = ctx.saved_tensors
         dims, stride, pad, act, act_scale, gather, vv, has_bias, has_res = ctx.cfg
         B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW = dims
         gy = gy.contiguous()
+        g_skip = gy                                    # the post-dropout skip connection gets the incoming gradient as is
+        if mult is not None:
+            gy = gy * mult
         rows = B * Ho * Wo
         w_sink, b_sink = ctx.sinks if ctx.sinks is not None else (None, None)
         bias_done = False
@@ -308,8 +318,8 @@ class _ConvFn(torch.autograd.Function):
             else:
                 gb = torch.zeros(Cout, dtype=torch.float32, device=gy.device)
                 lib.colsum(dv, gb, rows, Cout)
-        gres = dv if (has_res and ctx.needs_input_grad[3]) else None
-        return gx, gw, gb, gres, None, None, None, None, None, None, None, None, None
+        gres = (g_skip if mult is not None else dv) if (has_res and ctx.needs_input_grad[3]) else None
+        return gx, gw, gb, gres, None, None, None, None, None, None, None, None, None, None
 
 
 def _nearest_upsample_backward(gv, Hi, Wi):
@@ -330,16 +340,16 @@ def _sink(p, shape=None):
 
 
 def conv2d(x, w, bias=None, *, stride=1, pad=0, act=ACT_NONE, act_scale=1.0, residual=None, row_scale=None,
-           shift=None, upsample_to=None):
+           shift=None, upsample_to=None, mult=None):
     """x (B,H,W,Cin); w (Cout,KH,KW,Cin) fp32 master; bias fp32 parameter or None.
     row_scale / shift: constant per-Cout tensors of a folded FrozenBatchNorm.
     upsample_to=(Hv,Wv): convolve a nearest-upsampled view of x without materialising it."""
     sinks = (_sink(w), _sink(bias) if bias is not None else None)
     return _ConvFn.apply(x, w, bias, residual, row_scale, shift, stride, pad, act, float(act_scale), upsample_to,
-                         getattr(w, "_gwd_bf16", None), sinks if (sinks[0] or sinks[1]) else None)
+                         getattr(w, "_gwd_bf16", None), sinks if (sinks[0] or sinks[1]) else None, mult)
 
 
-def linear(x, w, bias=None, act=ACT_NONE, rows=None, residual=None):
+def linear(x, w, bias=None, act=ACT_NONE, rows=None, residual=None, mult=None):
     """x (..., K) @ w(N, K)^T + bias, optional fused activation; same kernel as conv2d (1x1, one pixel per row).
     rows=(r0, r1): use only that row range of a packed parameter (the q/k/v blocks of an attention in-projection);
     the gradient then goes straight into that slice of the parameter's flat gradient instead of through a
@@ -361,9 +371,10 @@ def linear(x, w, bias=None, act=ACT_NONE, rows=None, residual=None):
     n = w.shape[0]
     sinks = (None if ws is None else (ws[0].view(n, 1, 1, K), ws[1]), bs)
     res = None if residual is None else residual.reshape(-1, 1, 1, n)
+    mul = None if mult is None else mult.reshape(-1, 1, 1, n)
     y = _ConvFn.apply(x2, w.view(n, 1, 1, K), bias, res, None, None, 1, 0, act, 1.0, None,
                       None if shadow is None else shadow.view(n, 1, 1, K),
-                      sinks if (sinks[0] or sinks[1]) else None)
+                      sinks if (sinks[0] or sinks[1]) else None, mul)
     return y.view(*lead, n)
 
 
@@ -519,7 +530,7 @@ def _dense_rows(t):
     return t if ok else t.contiguous()
 
 
-def mha_core(qk, k, v, heads, key_padding_mask, dropout_p, training, scale):
+def mha_core(qk, k, v, heads, key_padding_mask, dropout_p, training, scale, mult=None):
     """Attention core of one MultiheadAttention call (multi_head_attention.py:329-375) as ONE kernel each way.  qk: the packed
     (B, L, 2E) q|k projection with k=None, or q with a separate k (B, S, E); v (B, S, E).  Returns the merged (B, L, E) output,
     or None when the kernels do not cover the call (not bf16 on a HIP device, head_dim != 32): the caller keeps the unfused
@@ -529,8 +540,7 @@ def mha_core(qk, k, v, heads, key_padding_mask, dropout_p, training, scale):
         return None
     B, L = qk.shape[0], qk.shape[1]
     S = v.shape[1]
-    mult = None
-    if training and dropout_p > 0:       # ATen's graph-safe Philox stream decides which probabilities are dropped
+    if mult is None and training and dropout_p > 0:      # no pool: ATen's graph-safe Philox stream decides which probabilities are dropped
         mult = F.dropout(torch.ones((B, heads, L, S), dtype=v.dtype, device=v.device), dropout_p, True)
     return _MhaFlashFn.apply(_dense_rows(qk), None if k is None else _dense_rows(k), _dense_rows(v), int(heads), key_padding_mask,
                              mult, float(scale))

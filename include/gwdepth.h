@@ -43,6 +43,11 @@ typedef struct {
     const void *residual; /* optional [B][Ho][Wo][Cout] added before the activation             */
     const void *zero_page;/* optional: >= 64 zero bytes of device memory.  Enables the LDS-DMA     */
                           /* pipeline (out-of-image taps are fetched from it instead of branching) */
+    const void *mult;     /* optional [B][Ho][Wo][Cout] element-wise multiplier applied AFTER the    */
+                          /* activation (dropout keep-mask / (1-p)); with it, `residual` is added    */
+                          /* after the multiply instead of before the activation:                    */
+                          /*   y = act_scale * act(conv + shift) * mult + residual                   */
+                          /* (x + dropout(sublayer(x)) of src/models/transformer.py:149-162,212-233)  */
     int32_t B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
     int32_t gather;       /* GWD_GATHER_*                                                       */
     int32_t Hv, Wv;       /* virtual input size for GWD_GATHER_UPSAMPLED                        */

@@ -90,17 +90,22 @@ class FakeDevice:
         return out.permute(0, 2, 3, 1)
 
     def conv_forward(self, x, w, y, dims, z=None, scale=None, shift=None, residual=None, stride=1, pad=0,
-                     gather=hip.GATHER_CONV, virt=(0, 0), act=hip.ACT_NONE, act_scale=1.0):
+                     gather=hip.GATHER_CONV, virt=(0, 0), act=hip.ACT_NONE, act_scale=1.0, mult=None):
         v = self._conv_core(x, w, dims, stride, pad, gather, virt)
         if scale is not None:
             v = v * scale
         if shift is not None:
             v = v + shift
-        if residual is not None:
+        if residual is not None and mult is None:
             v = v + residual.reshape(v.shape).float()
         if z is not None:
             z.copy_(v.reshape(z.shape))
-        y.copy_((_act(v, act) * act_scale).reshape(y.shape))
+        out = _act(v, act) * act_scale
+        if mult is not None:                          # y = act_scale * act(v) * mult + residual (dropout, then the skip)
+            out = out * mult.reshape(v.shape).float()
+            if residual is not None:
+                out = out + residual.reshape(v.shape).float()
+        y.copy_(out.reshape(y.shape))
 
     def conv_wgrad(self, x, gy, dw, dims, stride=1, pad=0, gather=hip.GATHER_CONV, virt=(0, 0), scale=None, **_):
         B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW = dims

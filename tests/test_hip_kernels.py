@@ -117,6 +117,49 @@ def test_conv_forward_dgrad_wgrad(dev, case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2400, 256, 256, hip.ACT_NONE, True), (2400, 256, 2048, hip.ACT_RELU, False), (800, 2048, 256, hip.ACT_NONE, True),
+                                   (37, 40, 24, hip.ACT_RELU, True), (153600, 64, 128, hip.ACT_NONE, True)])
+def test_linear_epilogue_dropout_multiplier_and_skip(dev, shape, dtype):
+    """y = act(x W^T + b) * mult + residual in the GEMM epilogue (x + dropout(sublayer(x)), transformer.py:149-162) on every
+    forward kernel (LDS-DMA 64x64 / 256x128 tiles, the register-staged fp32 / odd-width kernels, vector and scalar epilogues)."""
+    M, K, N, act, with_res = shape
+    fake = FakeDevice()
+    x, w = rnd(M, 1, 1, K, dtype=dtype, seed=1), rnd(N, 1, 1, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    b = rnd(N, seed=3)
+    g = torch.Generator().manual_seed(4)
+    mult = ((torch.rand(M, 1, 1, N, generator=g) > 0.1).float() / 0.9).to(dtype)
+    res = rnd(M, 1, 1, N, dtype=dtype, seed=5) if with_res else None
+    dims = (M, 1, 1, K, 1, 1, N, 1, 1)
+    y_r = torch.empty(M, 1, 1, N, dtype=dtype)
+    fake.conv_forward(x, w, y_r, dims, shift=b, residual=res, act=act, mult=mult)
+    y = torch.full((M, 1, 1, N), float("nan"), dtype=dtype, device="cuda")
+    dev.conv_forward(x.cuda(), w.cuda(), y, dims, shift=b.cuda(), residual=None if res is None else res.cuda(), act=act, mult=mult.cuda())
+    torch.cuda.synchronize()
+    assert rel(y, y_r) < TOL[dtype]
+
+
+@pytest.mark.parametrize("act", [hip.ACT_NONE, hip.ACT_RELU])
+def test_linear_with_dropout_multiplier_autograd(dev, act):
+    """ops.linear(..., residual=r, mult=m) forward AND backward (x, weight, bias, skip) against torch autograd of
+    act(x W^T + b) * m + r, fp32 (exact-fp32 MFMA)."""
+    from gw_depth_amd import ops
+    M, K, N = 600, 256, 512
+    x, w, b, r = (rnd(*sh, seed=i).cuda().requires_grad_(True) for i, sh in enumerate([(2, M // 2, K), (N, K), (N,), (2, M // 2, N)], start=1))
+    g = torch.Generator().manual_seed(9)
+    m = ((torch.rand(2, M // 2, N, generator=g) > 0.1).float() / 0.9).cuda()
+    go = rnd(2, M // 2, N, seed=7).cuda()
+    y = ops.linear(x, w, b, act, residual=r, mult=m)
+    gx, gw, gb, gr = torch.autograd.grad(y, [x, w, b, r], go)
+    x2, w2, b2, r2 = (t.detach().clone().requires_grad_(True) for t in (x, w, b, r))
+    pre = x2 @ w2.t() + b2
+    y2 = (torch.relu(pre) if act == hip.ACT_RELU else pre) * m + r2
+    ex, ew, eb, er = torch.autograd.grad(y2, [x2, w2, b2, r2], go)
+    torch.cuda.synchronize()
+    for got, want in ((y, y2), (gx, ex), (gw, ew), (gb, eb), (gr, er)):
+        assert rel(got, want) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("rows,C,gelu,affine", [(300, 256, False, True), (1000, 64, False, True), (77, 160, True, True),
                                                 (513, 30, True, True), (64, 512, False, True), (40, 320, False, False),
                                                 (777, 60, True, True), (130, 300, True, True), (65, 120, False, True), (33, 6, False, True)])
