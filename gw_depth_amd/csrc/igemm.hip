@@ -122,7 +122,7 @@ __device__ __forceinline__ f32x16 mma(float a, float b, const f32x16 &c) {
 // ----------------------------------------------------------------------------------------------
 // forward / data gradient
 // ----------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN, int BK>
+template <typename T, int BM, int BN, int WM, int WN, int BK, bool MULT = false>
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(const gwd_conv_desc d) {
     constexpr int VEC = Cfg<T>::VEC;
     constexpr int KV = BK / VEC;        // 16-byte vectors per tile row (4)
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const gwd_conv_desc d) {
     T *y = (T *)d.y;
     T *z = (T *)d.z;
     const T *res = (const T *)d.residual;
-    const T *mul = (const T *)d.mult;
+    const T *mul = MULT ? (const T *)d.mult : nullptr;
     if constexpr (sizeof(T) == 2) {
         if ((N & 7) == 0) {
             // each wave transposes one 32x32 accumulator tile at a time through a private LDS patch, then every
@@ -375,7 +375,7 @@ __device__ __forceinline__ int xcd_band(int id, int total) {
     return xcd * per + (xcd < rem ? xcd : rem) + idx;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int GM>
+template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false>
 __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_desc d, const int tile_base, const int tile_count) {
     typedef __bf16 T;
     constexpr int BK = 32, NW = WM * WN;                 // 4 or 8 waves
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
     T *y = (T *)d.y;
     T *z = (T *)d.z;
     const T *res = (const T *)d.residual;
-    const T *mul = (const T *)d.mult;
+    const T *mul = MULT ? (const T *)d.mult : nullptr;       // compile-time: the multiplier path costs the plain kernels registers
     float *stage = (float *)smem + wave * (32 * 36);
     const int vr = lane >> 2, vc = (lane & 3) * 8;
 #pragma unroll
@@ -1158,6 +1158,21 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
     const int M = d->B * d->Ho * d->Wo, N = d->Cout;
     constexpr int BK = Cfg<T>::BK;
     const unsigned gm = (M + 127) / 128;
+    if (d->mult) {
+        // element-wise multiplier in the epilogue (dropout + skip of the DETR sub-layers: GEMMs with M <= a few thousand rows):
+        // dedicated instantiations of the 64x64 tiles, so that the multiplier path costs the other kernels nothing
+        if constexpr (sizeof(T) == 2) {
+            if (dma_enabled() && d->zero_page && (d->Cin % 32) == 0 && (N % 8) == 0 && d->gather == GWD_GATHER_CONV) {
+                const dim3 g(((M + 63) / 64) * ((N + 63) / 64));
+                igemm_dma_kernel<64, 64, 2, 2, 4, 0, true><<<g, 256, 0, s>>>(*d, 0, (int)g.x);
+                GWD_CHECK_LAUNCH();
+                return 0;
+            }
+        }
+        igemm_fwd_kernel<T, 64, 64, 2, 2, BK, true><<<dim3((M + 63) / 64, (N + 63) / 64), 256, 0, s>>>(*d);
+        GWD_CHECK_LAUNCH();
+        return 0;
+    }
     if constexpr (sizeof(T) == 2) {
         if (dma_enabled() && d->zero_page && (d->Cin % 32) == 0 && (N % 8) == 0) {
             const int gmk = d->gather == GWD_GATHER_CONV ? 0 : ((d->gather == GWD_GATHER_TRANSPOSED && d->stride == 1) ? 1 : 2);

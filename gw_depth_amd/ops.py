@@ -261,8 +261,8 @@ class _ConvFn(torch.autograd.Function):
                          virt=vv, act=act, act_scale=act_scale, mult=mult)
         ctx.cfg = (dims, stride, pad, act, act_scale, gather, vv, bias is not None, residual is not None)
         ctx.sinks = sinks
-        if mult is not None and act not in (ACT_NONE, ACT_RELU):
-            raise ValueError("conv2d: a dropout multiplier is supported behind no activation or ReLU only")
+        if mult is not None and (act not in (ACT_NONE, ACT_RELU) or (act == ACT_RELU and residual is not None)):
+            raise ValueError("conv2d: a dropout multiplier is supported behind no activation (+ skip) or behind ReLU (no skip) only")
         # ReLU's backward needs only the sign of the output: y * mult has the sign of relu(v) wherever mult > 0, and where
         # mult == 0 the incoming gradient is multiplied by zero anyway
         ctx.save_for_backward(x, w, row_scale, z if act == ACT_GELU else (y if act != ACT_NONE else None), mult)

@@ -118,7 +118,7 @@ def test_conv_forward_dgrad_wgrad(dev, case, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(2400, 256, 256, hip.ACT_NONE, True), (2400, 256, 2048, hip.ACT_RELU, False), (800, 2048, 256, hip.ACT_NONE, True),
-                                   (37, 40, 24, hip.ACT_RELU, True), (153600, 64, 128, hip.ACT_NONE, True)])
+                                   (37, 40, 24, hip.ACT_RELU, True), (15360, 64, 128, hip.ACT_NONE, True)])
 def test_linear_epilogue_dropout_multiplier_and_skip(dev, shape, dtype):
     """y = act(x W^T + b) * mult + residual in the GEMM epilogue (x + dropout(sublayer(x)), transformer.py:149-162) on every
     forward kernel (LDS-DMA 64x64 / 256x128 tiles, the register-staged fp32 / odd-width kernels, vector and scalar epilogues)."""
@@ -148,7 +148,8 @@ def test_linear_with_dropout_multiplier_autograd(dev, act):
     g = torch.Generator().manual_seed(9)
     m = ((torch.rand(2, M // 2, N, generator=g) > 0.1).float() / 0.9).cuda()
     go = rnd(2, M // 2, N, seed=7).cuda()
-    y = ops.linear(x, w, b, act, residual=r, mult=m)
+    skip = act == hip.ACT_NONE                     # the product's two uses: out-projection / linear2 (+ skip), linear1 + ReLU (no skip)
+    y = ops.linear(x, w, b, act, residual=r if skip else None, mult=m) + (0 if skip else r)
     gx, gw, gb, gr = torch.autograd.grad(y, [x, w, b, r], go)
     x2, w2, b2, r2 = (t.detach().clone().requires_grad_(True) for t in (x, w, b, r))
     pre = x2 @ w2.t() + b2
