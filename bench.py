@@ -239,6 +239,10 @@ def main():
     roofline = None
     if rank == 0:
         roofline = dominant_kernel_roofline(lib, dtype)
+        try:                        # the same kernel INSIDE the step (cold operands, neighbours on the chip): one eager step under the tracer
+            roofline.update(in_step_kernel_time(step, batch, roofline["algorithmic_gflop_per_launch"], roofline["peak"]))
+        except Exception as exc:
+            roofline["in_step_error"] = repr(exc)
     out = {
         "metric": "images/sec (train fwd+bwd) %dx%d bs=%d/GPU" % (a.height, a.width, a.batch),     # BASELINE.json's metric at the defaults
         "value": round(ips, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -257,6 +261,15 @@ def main():
     }
     if comm is not None:
         out["comm"] = comm
+    try:                            # step-level HBM-side traffic: PMC bytes of one step (committed profile) over the measured step time
+        with open(os.path.join(ROOT, "profiles", "r02_hbm_step.json")) as f:
+            hb = json.load(f)["hbm_bytes_per_step"]
+        if a.batch == 8 and a.height == 480 and a.width == 640 and a.dtype == "bf16":
+            gbps = hb / (el / a.steps) / 1e9
+            out["hbm"] = {"bytes_per_step_pmc": hb, "achieved_GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / PEAK_HBM_GBPS, 4),
+                          "source": "profiles/r02_hbm_step.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction)"}
+    except (OSError, KeyError, ValueError):
+        pass
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         print("[bench] GPU leg done: %.2f images/s; timing the CPU baseline (oracle) ..." % ips, file=sys.stderr, flush=True)
         out["cpu_baseline"] = cpu_baseline(sd_cpu, cfg, a.cpu_baseline_budget_s)
@@ -265,6 +278,24 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def in_step_kernel_time(step, batch, gflop, peak):
+    """Average duration of the dominant kernel's launches inside ONE eager train step (torch profiler device trace)."""
+    from torch.profiler import ProfilerActivity, profile
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        step._on_graph_stream(batch, None) if step.use_graph else step.forward_backward(batch)
+        torch.cuda.synchronize()
+    # the 160 -> 160 launches of the template (the 800 -> 320 layer runs the same template 5x longer)
+    d = [e.device_time_total if hasattr(e, "device_time_total") else e.cuda_time_total for e in prof.events()
+         if "igemm_dma_kernel<256, 160, 8, 1, 3, 0>" in e.name]
+    d = [v for v in d if 0 < v < 400.0]
+    if not d:
+        return {"in_step_error": "kernel not found in the trace"}
+    ms = sum(d) / len(d) / 1e3
+    ach = gflop / ms / 1e3
+    return {"in_step_launch_ms": round(ms, 4), "in_step_launches": len(d), "in_step_achieved": round(ach, 2), "in_step_frac": round(ach / peak, 4)}
 
 
 def dominant_kernel_roofline(lib, dtype):
