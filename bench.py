@@ -289,7 +289,7 @@ def in_step_kernel_time(step, batch, gflop, peak):
         torch.cuda.synchronize()
     # the 160 -> 160 launches of the template (the 800 -> 320 layer runs the same template 5x longer)
     d = [e.device_time_total if hasattr(e, "device_time_total") else e.cuda_time_total for e in prof.events()
-         if "igemm_dma_kernel<256, 160, 8, 1, 3, 0>" in e.name]
+         if "igemm_dma_kernel<256, 160, 8, 1, 3, 0" in e.name.replace("(anonymous namespace)::", "")]
     d = [v for v in d if 0 < v < 400.0]
     if not d:
         return {"in_step_error": "kernel not found in the trace"}
