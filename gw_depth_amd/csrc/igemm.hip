@@ -1345,13 +1345,16 @@ int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s, WgradCollecto
 // thinconv.hip: streaming kernels for the 1-2 channel heads; return 1 when they took the problem
 int gwd_thin_conv_forward(const gwd_conv_desc *d, hipStream_t s);
 int gwd_thin_conv_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s);
+// tileconv.hip: halo-tiled 3x3 kernels for 32 / 64-channel layers on large maps; return 1 when they took the problem
+int gwd_tile_conv_forward(const gwd_conv_desc *d, hipStream_t s);
+int gwd_tile_conv_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s);
 
 extern "C" int gwd_conv_forward(const gwd_conv_desc *d, void *stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!d->w) return -1;
     if ((int64_t)d->B * d->Ho * d->Wo * d->Cout >= (1LL << 40)) return -7;
-    if (gwd_thin_conv_forward(d, (hipStream_t)stream)) {
+    if (gwd_thin_conv_forward(d, (hipStream_t)stream) || gwd_tile_conv_forward(d, (hipStream_t)stream)) {
         GWD_CHECK_LAUNCH();
         return 0;
     }
@@ -1362,7 +1365,7 @@ extern "C" int gwd_conv_wgrad(const gwd_conv_desc *d, float *dw, void *stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!dw) return -1;
-    if (gwd_thin_conv_wgrad(d, dw, (hipStream_t)stream)) {
+    if (gwd_thin_conv_wgrad(d, dw, (hipStream_t)stream) || gwd_tile_conv_wgrad(d, dw, (hipStream_t)stream)) {
         GWD_CHECK_LAUNCH();
         return 0;
     }
@@ -1382,7 +1385,7 @@ extern "C" int gwd_conv_wgrad_batch(const gwd_conv_desc *descs, float *const *dw
     for (int i = 0; i < n; ++i) {
         const gwd_conv_desc *d = descs + i;
         if (coll.g128.n == WG_GROUP || coll.g64.n == WG_GROUP) coll.flush(s);
-        if (gwd_thin_conv_wgrad(d, dws[i], s)) continue;
+        if (gwd_thin_conv_wgrad(d, dws[i], s) || gwd_tile_conv_wgrad(d, dws[i], s)) continue;
         const int rc = d->dtype == GWD_BF16 ? launch_wgrad<__bf16>(d, dws[i], s, &coll) : launch_wgrad<float>(d, dws[i], s);
         if (rc) return rc;
     }

@@ -1,0 +1,354 @@
+// 3x3 stride-1 convolutions with 32 / 64 channels on large maps (the full- and half-resolution decoder of
+// /root/reference/src/models/dense_upsample.py:160-182 and ResNet layer1's 3x3: 0.15 - 2.5 M output pixels, 288 - 576 MACs each).
+// These layers are HBM-bound by arithmetic intensity, but the tap-by-tap implicit GEMM re-reads every input pixel nine times
+// from L2 (1.4 GB of L2 -> LDS traffic for a 157 MB map): 165 - 340 us per launch against a 60 - 70 us HBM floor.
+//
+// Here an 8 x 32 output tile's (8+2) x (32+2) input HALO is staged in LDS once and all nine taps read it there; the weights
+// (<= 83 KB) sit in LDS for the whole launch (persistent workgroups walk the tiles, the next tile's halo is prefetched into
+// registers during the MFMAs).  Products run as Y^T = W . X^T on v_mfma_f32_32x32x16_bf16: A = one tap's weights (rows =
+// output channels), B = 32 consecutive pixels of a halo row (lane = pixel, 8 channels per k-slot) - the accumulator has the
+// PIXEL on the lane and 4 consecutive channels per register quad, so the epilogue (shift, activation) stores 8 bytes per lane.
+// Gather modes: plain, data gradient (taps mirrored, transposed weights prepared by gwd_weight_prep), and the exact 2x nearest
+// up-sample of the up-convolutions (source pixel = virtual pixel >> 1), fused into the halo load.
+// The weight gradient uses the same halo: dW[co][tap][ci] += gy^T . x_shifted per tap, both operands gathered by column with
+// ds_read_b64_tr_b16, accumulated in registers over all tiles a workgroup visits, one set of fp32 atomics at the end.
+#include "common.h"
+#include <stdlib.h>
+
+namespace tconv {
+
+constexpr int TH = 8, TW = 32, HH = TH + 2, HW = TW + 2, HPIX = HH * HW;     // output tile, halo
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ f32x16 mma(const bf16x8 &a, const bf16x8 &b, const f32x16 &c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+template <int CIN> struct Halo {
+    static constexpr int PS = CIN + 8;                      // pixel stride in elements (80 / 144 bytes: spreads the banks)
+    static constexpr int CHUNKS = HPIX * (CIN / 8);         // 16-byte pieces of one halo
+    static constexpr int NCH = (CHUNKS + 255) / 256;        // per thread
+    static constexpr int BYTES = HPIX * PS * 2;
+};
+
+// one 16-byte piece of the halo of tile (b, oy0, ox0): chunk -> (halo pixel, channel group); zero outside the (virtual) image
+template <int CIN, bool UP>
+__device__ __forceinline__ u32x4 halo_fetch(const __bf16 *__restrict__ x, int chunk, int b, int oy0, int ox0, int Hs, int Ws, int Hv, int Wv) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    if (chunk >= Halo<CIN>::CHUNKS) return z;
+    const int hp = chunk / (CIN / 8), part = chunk - hp * (CIN / 8);
+    const int hy = hp / HW, hx = hp - hy * HW;
+    const int vy = oy0 - 1 + hy, vx = ox0 - 1 + hx;
+    if ((unsigned)vy >= (unsigned)Hv || (unsigned)vx >= (unsigned)Wv) return z;
+    const int sy = UP ? (vy >> 1) : vy, sx = UP ? (vx >> 1) : vx;
+    return *(const u32x4 *)(x + (((size_t)b * Hs + sy) * Ws + sx) * CIN + part * 8);
+}
+
+template <int CIN>
+__device__ __forceinline__ void halo_put(__bf16 *halo, int chunk, const u32x4 &v) {
+    if (chunk < Halo<CIN>::CHUNKS) {
+        const int hp = chunk / (CIN / 8), part = chunk - hp * (CIN / 8);
+        *(u32x4 *)(halo + hp * Halo<CIN>::PS + part * 8) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward / data gradient
+// x: [B][Hs][Ws][CIN] (Hs = Hv / 2 when UP), w: [COUT][3][3][CIN] bf16 (already scaled / transposed by gwd_weight_prep),
+// y: [B][Hv][Wv][COUT].  FLIP: the data-gradient gather (source = pixel + 1 - tap).
+template <int CIN, int COUT, bool UP, bool FLIP>
+__global__ __launch_bounds__(256) void tconv_fwd_kernel(const gwd_conv_desc d, int tiles_y, int tiles_x, int ntiles) {
+    using H = Halo<CIN>;
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
+    __bf16 *halo = lds, *wl = lds + HPIX * H::PS;           // weights [tap][COUT][PS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const __bf16 *x = (const __bf16 *)d.x, *w = (const __bf16 *)d.w;
+    __bf16 *y = (__bf16 *)d.y;
+    const int Hv = d.Ho, Wv = d.Wo, Hs = d.Hi, Ws = d.Wi;   // same-size convolution on the (virtual) grid Hv x Wv
+    for (int c = tid; c < 9 * COUT * (CIN / 8); c += 256) {
+        const int part = c % (CIN / 8), row = c / (CIN / 8), co = row / 9, tap = row - co * 9;      // source row = (co, tap)
+        *(u32x4 *)(wl + (tap * COUT + co) * H::PS + part * 8) = *(const u32x4 *)(w + (size_t)row * CIN + part * 8);
+    }
+    float sh[COUT / 32][16];
+#pragma unroll
+    for (int nt = 0; nt < COUT / 32; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sh[nt][i] = d.shift ? d.shift[32 * nt + acc_row(i, h)] : 0.f;
+
+    u32x4 pre[H::NCH];
+    int tile = blockIdx.x;
+    auto where = [&](int t, int &b, int &oy0, int &ox0) {
+        const int per = tiles_y * tiles_x;
+        b = t / per;
+        const int rem = t - b * per;
+        oy0 = (rem / tiles_x) * TH;
+        ox0 = (rem % tiles_x) * TW;
+    };
+    if (tile < ntiles) {
+        int b, oy0, ox0;
+        where(tile, b, oy0, ox0);
+#pragma unroll
+        for (int i = 0; i < H::NCH; ++i) pre[i] = halo_fetch<CIN, UP>(x, tid + 256 * i, b, oy0, ox0, Hs, Ws, Hv, Wv);
+    }
+    for (; tile < ntiles; tile += gridDim.x) {
+        int b, oy0, ox0;
+        where(tile, b, oy0, ox0);
+        __syncthreads();                                     // every wave is done with the previous halo (and, first time, the weights are in)
+#pragma unroll
+        for (int i = 0; i < H::NCH; ++i) halo_put<CIN>(halo, tid + 256 * i, pre[i]);
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) {               // the next tile's halo travels during the MFMAs
+            int nb, ny, nx;
+            where(tile + gridDim.x, nb, ny, nx);
+#pragma unroll
+            for (int i = 0; i < H::NCH; ++i) pre[i] = halo_fetch<CIN, UP>(x, tid + 256 * i, nb, ny, nx, Hs, Ws, Hv, Wv);
+        }
+        f32x16 acc[2][COUT / 32];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < COUT / 32; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            const int dy = FLIP ? 2 - kh : kh, dx = FLIP ? 2 - kw : kw;      // halo offset of the tap (0..2)
+#pragma unroll
+            for (int s = 0; s < CIN / 16; ++s) {
+                bf16x8 bf[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    bf[mt] = *(const bf16x8 *)(halo + ((2 * wave + mt + dy) * HW + r + dx) * H::PS + 16 * s + 8 * h);
+#pragma unroll
+                for (int nt = 0; nt < COUT / 32; ++nt) {
+                    const bf16x8 af = *(const bf16x8 *)(wl + (tap * COUT + 32 * nt + r) * H::PS + 16 * s + 8 * h);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = mma(af, bf[mt], acc[mt][nt]);
+                }
+            }
+        }
+        // epilogue: lane = pixel, registers 4g..4g+3 = channels 32 nt + 8 g + 4 h + 0..3
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int oy = oy0 + 2 * wave + mt, ox = ox0 + r;
+            if (oy < Hv && ox < Wv) {
+                __bf16 *dst = y + (((size_t)b * Hv + oy) * Wv + ox) * COUT;
+#pragma unroll
+                for (int nt = 0; nt < COUT / 32; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        union { uint2 u; __bf16 e[4]; } v;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v.e[j] = (__bf16)(apply_act(acc[mt][nt][4 * g + j] + sh[nt][4 * g + j], d.act) * d.act_scale);
+                        *(uint2 *)(dst + 32 * nt + 8 * g + 4 * h) = v.u;
+                    }
+            }
+        }
+    }
+}
+
+template <int CIN, int COUT>
+size_t fwd_lds() { return (size_t)(HPIX * Halo<CIN>::PS + 9 * COUT * Halo<CIN>::PS) * 2; }
+
+static bool enabled() {                      // A/B switch (GWD_TILE_CONV=0: the tap-by-tap implicit GEMM for these layers as well)
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GWD_TILE_CONV");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+template <int CIN, int COUT, bool UP, bool FLIP>
+int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
+    const int ty = (d->Ho + TH - 1) / TH, tx = (d->Wo + TW - 1) / TW;
+    const long ntiles = (long)d->B * ty * tx;
+    const size_t lds = fwd_lds<CIN, COUT>();
+    static bool attr = false;
+    if (!attr) {                                            // dynamic LDS beyond 64 KiB has to be requested once per kernel
+        (void)hipFuncSetAttribute((const void *)tconv_fwd_kernel<CIN, COUT, UP, FLIP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
+    long grid = 256L * per_cu;
+    if (grid > ntiles) grid = ntiles;
+    tconv_fwd_kernel<CIN, COUT, UP, FLIP><<<(unsigned)grid, 256, lds, s>>>(*d, ty, tx, (int)ntiles);
+    return 1;
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[cg][tap][cx] += sum over pixels of gy[p][cg] * x[p + tap - 1][cx]  (x through the same halo, optionally 2x up-sampled).
+// 3 waves, 3 taps each; per tile 16 k-steps of 16 consecutive pixels; D^T-free orientation: A = gy^T (rows = gy channels),
+// B = shifted x (columns = x channels), both column gathers (ds_read_b64_tr_b16, natural k order) from [pixel][channel] images.
+__device__ __forceinline__ bf16x8 gather16(const __bf16 *img, int rs, int pix0, int col0, int lane) {
+    // lane (r, h) gets img[pix0 + 8 h + j][col0 + r], j = 0..7 (32 columns from col0)
+    const int g = lane >> 4, t = lane & 15, q = t >> 2, p = t & 3;
+    const __bf16 *a = img + (pix0 + 8 * (g >> 1) + q) * rs + col0 + 16 * (g & 1) + 4 * p;
+    union { s16x4 h[2]; bf16x8 v; } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)a);
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(a + 4 * rs));
+    return u.v;
+}
+
+template <int CX, int CG, bool UP>
+__global__ __launch_bounds__(192) void tconv_wgrad_kernel(const gwd_conv_desc d, float *__restrict__ dw, int tiles_y, int tiles_x, int ntiles) {
+    using H = Halo<CX>;
+    constexpr int GS = CG + 8;                              // gy image pixel stride
+    constexpr int GCH = TH * TW * (CG / 8), NG = (GCH + 191) / 192, NX = (H::CHUNKS + 191) / 192;
+    constexpr int TX = CX / 32, TG = CG / 32;
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
+    __bf16 *halo = lds, *gimg = lds + HPIX * H::PS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const __bf16 *x = (const __bf16 *)d.x, *gy = (const __bf16 *)d.y;      // gwd_conv_wgrad: the desc's y slot carries the output gradient
+    const int Hv = d.Ho, Wv = d.Wo, Hs = d.Hi, Ws = d.Wi;
+    f32x16 acc[3][TG][TX];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < TG; ++b)
+#pragma unroll
+            for (int c = 0; c < TX; ++c)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[a][b][c][i] = 0.f;
+    auto where = [&](int t, int &b, int &oy0, int &ox0) {
+        const int per = tiles_y * tiles_x;
+        b = t / per;
+        const int rem = t - b * per;
+        oy0 = (rem / tiles_x) * TH;
+        ox0 = (rem % tiles_x) * TW;
+    };
+    auto gy_fetch = [&](int chunk, int b, int oy0, int ox0) -> u32x4 {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        if (chunk >= GCH) return z;
+        const int pix = chunk / (CG / 8), part = chunk - pix * (CG / 8);
+        const int oy = oy0 + pix / TW, ox = ox0 + pix % TW;
+        if (oy >= Hv || ox >= Wv) return z;
+        return *(const u32x4 *)(gy + (((size_t)b * Hv + oy) * Wv + ox) * CG + part * 8);
+    };
+    u32x4 px[NX], pg[NG];
+    int tile = blockIdx.x;
+    if (tile < ntiles) {
+        int b, oy0, ox0;
+        where(tile, b, oy0, ox0);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) px[i] = halo_fetch<CX, UP>(x, tid + 192 * i, b, oy0, ox0, Hs, Ws, Hv, Wv);
+#pragma unroll
+        for (int i = 0; i < NG; ++i) pg[i] = gy_fetch(tid + 192 * i, b, oy0, ox0);
+    }
+    for (; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NX; ++i) halo_put<CX>(halo, tid + 192 * i, px[i]);
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int chunk = tid + 192 * i;
+            if (chunk < GCH) *(u32x4 *)(gimg + (chunk / (CG / 8)) * GS + (chunk % (CG / 8)) * 8) = pg[i];
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) {
+            int nb, ny, nx;
+            where(tile + gridDim.x, nb, ny, nx);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) px[i] = halo_fetch<CX, UP>(x, tid + 192 * i, nb, ny, nx, Hs, Ws, Hv, Wv);
+#pragma unroll
+            for (int i = 0; i < NG; ++i) pg[i] = gy_fetch(tid + 192 * i, nb, ny, nx);
+        }
+#pragma unroll 2
+        for (int ks = 0; ks < 16; ++ks) {                   // 16 consecutive pixels of tile row ks / 2
+            const int row = ks >> 1, x0 = (ks & 1) * 16;
+            bf16x8 af[TG];
+#pragma unroll
+            for (int b = 0; b < TG; ++b) af[b] = gather16(gimg, GS, row * TW + x0, 32 * b, lane);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int tap = 3 * wave + a, kh = tap / 3, kw = tap - 3 * kh;
+#pragma unroll
+                for (int c = 0; c < TX; ++c) {
+                    const bf16x8 bf = gather16(halo, H::PS, (row + kh) * HW + x0 + kw, 32 * c, lane);
+#pragma unroll
+                    for (int b = 0; b < TG; ++b) acc[a][b][c] = mma(af[b], bf, acc[a][b][c]);
+                }
+            }
+        }
+    }
+    // flush: D[cg][cx] of tap -> dw[cg][tap][cx] (fp32 atomics, lanes = consecutive cx)
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int tap = 3 * wave + a;
+#pragma unroll
+        for (int b = 0; b < TG; ++b)
+#pragma unroll
+            for (int c = 0; c < TX; ++c)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int cg = 32 * b + acc_row(i, h), cx = 32 * c + r;
+                    const float sc = d.scale ? d.scale[cg] : 1.0f;
+                    unsafeAtomicAdd(dw + ((size_t)cg * 9 + tap) * CX + cx, acc[a][b][c][i] * sc);
+                }
+    }
+}
+
+template <int CX, int CG, bool UP>
+int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s) {
+    const int ty = (d->Ho + TH - 1) / TH, tx = (d->Wo + TW - 1) / TW;
+    const long ntiles = (long)d->B * ty * tx;
+    const size_t lds = (size_t)(HPIX * Halo<CX>::PS + TH * TW * (CG + 8)) * 2;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)tconv_wgrad_kernel<CX, CG, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int per_cu = lds > 53 * 1024 ? 2 : 3;
+    long grid = 256L * per_cu;
+    if (grid > ntiles) grid = ntiles;
+    tconv_wgrad_kernel<CX, CG, UP><<<(unsigned)grid, 192, lds, s>>>(*d, dw, ty, tx, (int)ntiles);
+    return 1;
+}
+
+}  // namespace tconv
+
+// 1 = launched, 0 = not one of these layers (the caller continues with the generic kernels)
+int gwd_tile_conv_forward(const gwd_conv_desc *d, hipStream_t s) {
+    using namespace tconv;
+    if (!enabled() || d->dtype != GWD_BF16 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1) return 0;
+    if (d->scale || d->residual || d->z || d->mult || !d->w) return 0;
+    if ((long)d->B * d->Ho * d->Wo < 131072 || (long)d->B * d->Ho * d->Wo >= (1L << 31)) return 0;
+    if (((uintptr_t)d->x | (uintptr_t)d->w | (uintptr_t)d->y) % 16) return 0;
+    const bool up = d->gather == GWD_GATHER_UPSAMPLED, flip = d->gather == GWD_GATHER_TRANSPOSED;
+    if (up) {
+        if (d->Hv != 2 * d->Hi || d->Wv != 2 * d->Wi || d->Ho != d->Hv || d->Wo != d->Wv) return 0;
+    } else if (d->Ho != d->Hi || d->Wo != d->Wi) return 0;
+    const int ci = d->Cin, co = d->Cout;
+#define TC(CI, CO)                                                                                  \
+    if (ci == CI && co == CO) {                                                                     \
+        if (up) return launch_fwd<CI, CO, true, false>(d, s);                                       \
+        if (flip) return launch_fwd<CI, CO, false, true>(d, s);                                     \
+        return launch_fwd<CI, CO, false, false>(d, s);                                              \
+    }
+    TC(32, 32) TC(32, 64)
+    if (up) { TC(64, 32) TC(64, 64) }         // 64 input channels: one workgroup per CU (90 - 132 KB of LDS) only pays with the 4x smaller source map
+#undef TC
+    return 0;
+}
+
+// gwd_conv_wgrad's thin-channel case (desc.x = layer input, desc.y = output gradient, Cin = x channels, Cout = gy channels)
+int gwd_tile_conv_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s) {
+    using namespace tconv;
+    if (!enabled() || d->dtype != GWD_BF16 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1) return 0;
+    if ((long)d->B * d->Ho * d->Wo < 131072 || (long)d->B * d->Ho * d->Wo >= (1L << 31)) return 0;
+    if (((uintptr_t)d->x | (uintptr_t)d->y) % 16) return 0;
+    const bool up = d->gather == GWD_GATHER_UPSAMPLED;
+    if (up) {
+        if (d->Hv != 2 * d->Hi || d->Wv != 2 * d->Wi || d->Ho != d->Hv || d->Wo != d->Wv) return 0;
+    } else if (d->gather != GWD_GATHER_CONV || d->Ho != d->Hi || d->Wo != d->Wi) return 0;
+    const int cx = d->Cin, cg = d->Cout;
+#define TW_(CX_, CG_)                                                                               \
+    if (cx == CX_ && cg == CG_) return up ? launch_wgrad<CX_, CG_, true>(d, dw, s) : launch_wgrad<CX_, CG_, false>(d, dw, s);
+    TW_(32, 32) TW_(64, 32)
+#undef TW_
+    return 0;
+}
