@@ -17,7 +17,7 @@
 
 namespace tconv {
 
-constexpr int TH = 8, TW = 32, HH = TH + 2, HW = TW + 2, HPIX = HH * HW;     // output tile, halo
+constexpr int TW = 32, HW = TW + 2;            // output tile width, halo width; tile height TH = 8 or 16 rows (2 rows per wave)
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -27,18 +27,19 @@ __device__ __forceinline__ f32x16 mma(const bf16x8 &a, const bf16x8 &b, const f3
 }
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
-template <int CIN> struct Halo {
+template <int CIN, int TH> struct Halo {
+    static constexpr int HH = TH + 2, HPIX = HH * HW;       // halo rows / pixels
+    static constexpr int NT = 32 * TH;                      // threads: one wave per two output rows
     static constexpr int PS = CIN + 8;                      // pixel stride in elements (80 / 144 bytes: spreads the banks)
     static constexpr int CHUNKS = HPIX * (CIN / 8);         // 16-byte pieces of one halo
-    static constexpr int NCH = (CHUNKS + 255) / 256;        // per thread
-    static constexpr int BYTES = HPIX * PS * 2;
+    static constexpr int NCH = (CHUNKS + NT - 1) / NT;      // per thread
 };
 
 // one 16-byte piece of the halo of tile (b, oy0, ox0): chunk -> (halo pixel, channel group); zero outside the (virtual) image
-template <int CIN, bool UP>
+template <int CIN, int TH, bool UP>
 __device__ __forceinline__ u32x4 halo_fetch(const __bf16 *__restrict__ x, int chunk, int b, int oy0, int ox0, int Hs, int Ws, int Hv, int Wv) {
     const u32x4 z = {0u, 0u, 0u, 0u};
-    if (chunk >= Halo<CIN>::CHUNKS) return z;
+    if (chunk >= Halo<CIN, TH>::CHUNKS) return z;
     const int hp = chunk / (CIN / 8), part = chunk - hp * (CIN / 8);
     const int hy = hp / HW, hx = hp - hy * HW;
     const int vy = oy0 - 1 + hy, vx = ox0 - 1 + hx;
@@ -47,27 +48,28 @@ __device__ __forceinline__ u32x4 halo_fetch(const __bf16 *__restrict__ x, int ch
     return *(const u32x4 *)(x + (((size_t)b * Hs + sy) * Ws + sx) * CIN + part * 8);
 }
 
-template <int CIN>
+template <int CIN, int TH>
 __device__ __forceinline__ void halo_put(__bf16 *halo, int chunk, const u32x4 &v) {
-    if (chunk < Halo<CIN>::CHUNKS) {
+    if (chunk < Halo<CIN, TH>::CHUNKS) {
         const int hp = chunk / (CIN / 8), part = chunk - hp * (CIN / 8);
-        *(u32x4 *)(halo + hp * Halo<CIN>::PS + part * 8) = v;
+        *(u32x4 *)(halo + hp * Halo<CIN, TH>::PS + part * 8) = v;
     }
 }
 
 // ------------------------------------------------------------------------------------------------ forward / data gradient
 // x: [B][Hs][Ws][CIN] (Hs = Hv / 2 when UP), w: [COUT][3][3][CIN] bf16 (already scaled / transposed by gwd_weight_prep),
 // y: [B][Hv][Wv][COUT].  FLIP: the data-gradient gather (source = pixel + 1 - tap).
-template <int CIN, int COUT, bool UP, bool FLIP>
-__global__ __launch_bounds__(256) void tconv_fwd_kernel(const gwd_conv_desc d, int tiles_y, int tiles_x, int ntiles) {
-    using H = Halo<CIN>;
+template <int CIN, int COUT, int TH, bool UP, bool FLIP>
+__global__ __launch_bounds__(32 * TH) void tconv_fwd_kernel(const gwd_conv_desc d, int tiles_y, int tiles_x, int ntiles) {
+    using H = Halo<CIN, TH>;
+    constexpr int NT = H::NT;
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
-    __bf16 *halo = lds, *wl = lds + HPIX * H::PS;           // weights [tap][COUT][PS]
+    __bf16 *halo = lds, *wl = lds + H::HPIX * H::PS;        // weights [tap][COUT][PS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const __bf16 *x = (const __bf16 *)d.x, *w = (const __bf16 *)d.w;
     __bf16 *y = (__bf16 *)d.y;
     const int Hv = d.Ho, Wv = d.Wo, Hs = d.Hi, Ws = d.Wi;   // same-size convolution on the (virtual) grid Hv x Wv
-    for (int c = tid; c < 9 * COUT * (CIN / 8); c += 256) {
+    for (int c = tid; c < 9 * COUT * (CIN / 8); c += NT) {
         const int part = c % (CIN / 8), row = c / (CIN / 8), co = row / 9, tap = row - co * 9;      // source row = (co, tap)
         *(u32x4 *)(wl + (tap * COUT + co) * H::PS + part * 8) = *(const u32x4 *)(w + (size_t)row * CIN + part * 8);
     }
@@ -90,20 +92,20 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(const gwd_conv_desc d, i
         int b, oy0, ox0;
         where(tile, b, oy0, ox0);
 #pragma unroll
-        for (int i = 0; i < H::NCH; ++i) pre[i] = halo_fetch<CIN, UP>(x, tid + 256 * i, b, oy0, ox0, Hs, Ws, Hv, Wv);
+        for (int i = 0; i < H::NCH; ++i) pre[i] = halo_fetch<CIN, TH, UP>(x, tid + NT * i, b, oy0, ox0, Hs, Ws, Hv, Wv);
     }
     for (; tile < ntiles; tile += gridDim.x) {
         int b, oy0, ox0;
         where(tile, b, oy0, ox0);
         __syncthreads();                                     // every wave is done with the previous halo (and, first time, the weights are in)
 #pragma unroll
-        for (int i = 0; i < H::NCH; ++i) halo_put<CIN>(halo, tid + 256 * i, pre[i]);
+        for (int i = 0; i < H::NCH; ++i) halo_put<CIN, TH>(halo, tid + NT * i, pre[i]);
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) {               // the next tile's halo travels during the MFMAs
             int nb, ny, nx;
             where(tile + gridDim.x, nb, ny, nx);
 #pragma unroll
-            for (int i = 0; i < H::NCH; ++i) pre[i] = halo_fetch<CIN, UP>(x, tid + 256 * i, nb, ny, nx, Hs, Ws, Hv, Wv);
+            for (int i = 0; i < H::NCH; ++i) pre[i] = halo_fetch<CIN, TH, UP>(x, tid + NT * i, nb, ny, nx, Hs, Ws, Hv, Wv);
         }
         f32x16 acc[2][COUT / 32];
 #pragma unroll
@@ -150,8 +152,8 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(const gwd_conv_desc d, i
     }
 }
 
-template <int CIN, int COUT>
-size_t fwd_lds() { return (size_t)(HPIX * Halo<CIN>::PS + 9 * COUT * Halo<CIN>::PS) * 2; }
+template <int CIN, int COUT, int TH>
+size_t fwd_lds() { return (size_t)(Halo<CIN, TH>::HPIX * Halo<CIN, TH>::PS + 9 * COUT * Halo<CIN, TH>::PS) * 2; }
 
 static bool enabled() {                      // A/B switch (GWD_TILE_CONV=0: the tap-by-tap implicit GEMM for these layers as well)
     static int v = -1;
@@ -164,18 +166,22 @@ static bool enabled() {                      // A/B switch (GWD_TILE_CONV=0: the
 
 template <int CIN, int COUT, bool UP, bool FLIP>
 int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
+    // 64 -> 32 (90 KB of LDS at 8 rows = one 4-wave workgroup per CU): 16-row tiles with 8 waves double the waves per CU for the same
+    // weights in LDS (277 -> 162 us on the up-convolution); the 32-channel-input variants fit 2-3 workgroups per CU at 8 rows and are
+    // faster there (104 vs 124 us), 64 -> 64 has no room for a 16-row halo beside its 83 KB of weights
+    constexpr int TH = (CIN == 64 && COUT == 32) ? 16 : 8;
     const int ty = (d->Ho + TH - 1) / TH, tx = (d->Wo + TW - 1) / TW;
     const long ntiles = (long)d->B * ty * tx;
-    const size_t lds = fwd_lds<CIN, COUT>();
+    const size_t lds = fwd_lds<CIN, COUT, TH>();
     static bool attr = false;
     if (!attr) {                                            // dynamic LDS beyond 64 KiB has to be requested once per kernel
-        (void)hipFuncSetAttribute((const void *)tconv_fwd_kernel<CIN, COUT, UP, FLIP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)tconv_fwd_kernel<CIN, COUT, TH, UP, FLIP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
     long grid = 256L * per_cu;
     if (grid > ntiles) grid = ntiles;
-    tconv_fwd_kernel<CIN, COUT, UP, FLIP><<<(unsigned)grid, 256, lds, s>>>(*d, ty, tx, (int)ntiles);
+    tconv_fwd_kernel<CIN, COUT, TH, UP, FLIP><<<(unsigned)grid, 32 * TH, lds, s>>>(*d, ty, tx, (int)ntiles);
     return 1;
 }
 
@@ -195,7 +201,8 @@ __device__ __forceinline__ bf16x8 gather16(const __bf16 *img, int rs, int pix0, 
 
 template <int CX, int CG, bool UP>
 __global__ __launch_bounds__(192) void tconv_wgrad_kernel(const gwd_conv_desc d, float *__restrict__ dw, int tiles_y, int tiles_x, int ntiles) {
-    using H = Halo<CX>;
+    constexpr int TH = 8, HPIX = (TH + 2) * HW;
+    using H = Halo<CX, TH>;
     constexpr int GS = CG + 8;                              // gy image pixel stride
     constexpr int GCH = TH * TW * (CG / 8), NG = (GCH + 191) / 192, NX = (H::CHUNKS + 191) / 192;
     constexpr int TX = CX / 32, TG = CG / 32;
@@ -234,14 +241,14 @@ __global__ __launch_bounds__(192) void tconv_wgrad_kernel(const gwd_conv_desc d,
         int b, oy0, ox0;
         where(tile, b, oy0, ox0);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) px[i] = halo_fetch<CX, UP>(x, tid + 192 * i, b, oy0, ox0, Hs, Ws, Hv, Wv);
+        for (int i = 0; i < NX; ++i) px[i] = halo_fetch<CX, 8, UP>(x, tid + 192 * i, b, oy0, ox0, Hs, Ws, Hv, Wv);
 #pragma unroll
         for (int i = 0; i < NG; ++i) pg[i] = gy_fetch(tid + 192 * i, b, oy0, ox0);
     }
     for (; tile < ntiles; tile += gridDim.x) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < NX; ++i) halo_put<CX>(halo, tid + 192 * i, px[i]);
+        for (int i = 0; i < NX; ++i) halo_put<CX, 8>(halo, tid + 192 * i, px[i]);
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             const int chunk = tid + 192 * i;
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(192) void tconv_wgrad_kernel(const gwd_conv_desc d,
             int nb, ny, nx;
             where(tile + gridDim.x, nb, ny, nx);
 #pragma unroll
-            for (int i = 0; i < NX; ++i) px[i] = halo_fetch<CX, UP>(x, tid + 192 * i, nb, ny, nx, Hs, Ws, Hv, Wv);
+            for (int i = 0; i < NX; ++i) px[i] = halo_fetch<CX, 8, UP>(x, tid + 192 * i, nb, ny, nx, Hs, Ws, Hv, Wv);
 #pragma unroll
             for (int i = 0; i < NG; ++i) pg[i] = gy_fetch(tid + 192 * i, nb, ny, nx);
         }
@@ -294,9 +301,10 @@ __global__ __launch_bounds__(192) void tconv_wgrad_kernel(const gwd_conv_desc d,
 
 template <int CX, int CG, bool UP>
 int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s) {
+    constexpr int TH = 8;
     const int ty = (d->Ho + TH - 1) / TH, tx = (d->Wo + TW - 1) / TW;
     const long ntiles = (long)d->B * ty * tx;
-    const size_t lds = (size_t)(HPIX * Halo<CX>::PS + TH * TW * (CG + 8)) * 2;
+    const size_t lds = (size_t)(Halo<CX, TH>::HPIX * Halo<CX, TH>::PS + TH * TW * (CG + 8)) * 2;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void *)tconv_wgrad_kernel<CX, CG, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -329,8 +337,7 @@ int gwd_tile_conv_forward(const gwd_conv_desc *d, hipStream_t s) {
         if (flip) return launch_fwd<CI, CO, false, true>(d, s);                                     \
         return launch_fwd<CI, CO, false, false>(d, s);                                              \
     }
-    TC(32, 32) TC(32, 64)
-    if (up) { TC(64, 32) TC(64, 64) }         // 64 input channels: one workgroup per CU (90 - 132 KB of LDS) only pays with the 4x smaller source map
+    TC(32, 32) TC(32, 64) TC(64, 32) TC(64, 64)
 #undef TC
     return 0;
 }
