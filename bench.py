@@ -284,12 +284,22 @@ def in_step_kernel_time(step, batch, gflop, peak):
     """Average duration of the dominant kernel's launches inside ONE eager train step (torch profiler device trace)."""
     from torch.profiler import ProfilerActivity, profile
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
         step._on_graph_stream(batch, None) if step.use_graph else step.forward_backward(batch)
         torch.cuda.synchronize()
     # the 160 -> 160 launches of the template (the 800 -> 320 layer runs the same template 5x longer)
-    d = [e.device_time_total if hasattr(e, "device_time_total") else e.cuda_time_total for e in prof.events()
-         if "igemm_dma_kernel<256, 160, 8, 1, 3, 0" in e.name.replace("(anonymous namespace)::", "")]
+    key = "igemm_dma_kernel<256, 160, 8, 1, 3, 0"
+    d = []
+    try:                                            # kineto's own records: kernel name + duration in ns
+        for ev in prof.profiler.kineto_results.events():
+            if key in ev.name().replace("(anonymous namespace)::", ""):
+                d.append(ev.duration_ns() / 1e3)
+    except Exception:
+        d = []
+    if not d:
+        for e in prof.events():
+            if key in e.name.replace("(anonymous namespace)::", ""):
+                d.append(getattr(e, "device_time_total", 0) or getattr(e, "cuda_time_total", 0) or getattr(e, "self_device_time_total", 0))
     d = [v for v in d if 0 < v < 400.0]
     if not d:
         return {"in_step_error": "kernel not found in the trace"}
