@@ -281,11 +281,13 @@ def main():
 
 
 def in_step_kernel_time(step, batch, gflop, peak):
-    """Average duration of the dominant kernel's launches inside ONE eager train step (torch profiler device trace)."""
+    """Average duration of the dominant kernel's launches inside ONE train step as the bench runs it (a replay of the captured
+    graph chain in graph mode: kernels back to back, operands cold), from the profiler's device trace."""
     from torch.profiler import ProfilerActivity, profile
     torch.cuda.synchronize()
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-        step._on_graph_stream(batch, None) if step.use_graph else step.forward_backward(batch)
+        step(batch)
+        step.flush()
         torch.cuda.synchronize()
     # the 160 -> 160 launches of the template (the 800 -> 320 layer runs the same template 5x longer)
     key = "igemm_dma_kernel<256, 160, 8, 1, 3, 0"
@@ -304,7 +306,7 @@ def in_step_kernel_time(step, batch, gflop, peak):
     if not d:
         return {"in_step_error": "kernel not found in the trace"}
     ms = sum(d) / len(d) / 1e3
-    ach = gflop / ms / 1e3
+    ach = gflop / ms                                   # GFLOP per ms = TFLOP/s
     return {"in_step_launch_ms": round(ms, 4), "in_step_launches": len(d), "in_step_achieved": round(ach, 2), "in_step_frac": round(ach / peak, 4)}
 
 

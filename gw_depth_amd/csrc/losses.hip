@@ -22,32 +22,34 @@ __device__ __forceinline__ int nearest_src(int dst, int in, int out) {
     return min((int)floorf((float)dst * ((float)in / (float)out)), in - 1);
 }
 
+// One (image, row) of the prediction at a time: the GT row and the row's base offsets are computed once (no per-element 64-bit
+// div / mod - they were most of the kernel's instructions), threads walk the columns.
 template <typename T>
-__device__ __forceinline__ bool silog_term(const T *pred, const float *gt, int64_t i, int h, int w, int H, int W,
-                                            int log_err, float &d, float &p) {
-    const int x = (int)(i % w);
-    const int64_t r = i / w;
-    const int y = (int)(r % h);
-    const int64_t b = r / h;
-    const float g = gt[(b * H + nearest_src(y, H, h)) * W + nearest_src(x, W, w)];
+__device__ __forceinline__ bool silog_term(const T *prow, const float *grow, int x, int w, int W, int log_err, float &d, float &p) {
+    const float g = grow[nearest_src(x, W, w)];
     if (!(g >= 0.2f && g < 10.0f)) return false;
-    p = to_f32(pred[i]);
+    p = to_f32(prow[x]);
     d = log_err ? (logf(p) - logf(g)) : ((p + logf(p)) - (g + logf(g)));
     return true;
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void silog_sums_kernel(const T *__restrict__ pred, const float *__restrict__ gt,
-                                                         double *__restrict__ sums, int64_t total, int h, int w, int H,
+                                                         double *__restrict__ sums, int rows, int h, int w, int H,
                                                          int W, int log_err) {
     __shared__ double sh[4];
     double s1 = 0.0, s2 = 0.0, cnt = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        float d, p;
-        if (silog_term(pred, gt, i, h, w, H, W, log_err, d, p)) {
-            s1 += d;
-            s2 += (double)d * d;
-            cnt += 1.0;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int b = row / h, y = row - b * h;
+        const T *prow = pred + (int64_t)row * w;
+        const float *grow = gt + ((int64_t)b * H + nearest_src(y, H, h)) * W;
+        for (int x = threadIdx.x; x < w; x += blockDim.x) {
+            float d, p;
+            if (silog_term(prow, grow, x, w, W, log_err, d, p)) {
+                s1 += d;
+                s2 += (double)d * d;
+                cnt += 1.0;
+            }
         }
     }
     s1 = block_sum_d(s1, sh);
@@ -63,16 +65,22 @@ __global__ __launch_bounds__(256) void silog_sums_kernel(const T *__restrict__ p
 template <typename T>
 __global__ void silog_bwd_kernel(const T *__restrict__ pred, const float *__restrict__ gt, const double *__restrict__ sums,
                                  const float *__restrict__ gloss, float loss_weight, float lambda, T *__restrict__ gpred,
-                                 int64_t total, int h, int w, int H, int W, int log_err) {
+                                 int rows, int h, int w, int H, int W, int log_err) {
     const double n = sums[2];
     const double mean = sums[0] / n, var = sums[1] / n - (double)lambda * mean * mean;
     // L = 10 sqrt(var);  dL/dd_i = 10/(2 sqrt(var)) * (2 d_i / n - 2 lambda mean / n)
     const float c = (float)(10.0 / sqrt(var) / n) * loss_weight * gloss[0];
     const float lm = (float)((double)lambda * mean);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        float d, p, g = 0.f;
-        if (silog_term(pred, gt, i, h, w, H, W, log_err, d, p)) g = c * (d - lm) * (log_err ? 1.0f / p : 1.0f + 1.0f / p);
-        gpred[i] = from_f32<T>(g);
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int b = row / h, y = row - b * h;
+        const T *prow = pred + (int64_t)row * w;
+        const float *grow = gt + ((int64_t)b * H + nearest_src(y, H, h)) * W;
+        T *orow = gpred + (int64_t)row * w;
+        for (int x = threadIdx.x; x < w; x += blockDim.x) {
+            float d, p, g = 0.f;
+            if (silog_term(prow, grow, x, w, W, log_err, d, p)) g = c * (d - lm) * (log_err ? 1.0f / p : 1.0f + 1.0f / p);
+            orow[x] = from_f32<T>(g);
+        }
     }
 }
 
@@ -115,12 +123,13 @@ inline int flat_grid(int64_t total) {
 extern "C" int gwd_silog_sums(const void *pred, const float *gt, double *sums, int32_t B, int32_t h, int32_t w, int32_t H,
                               int32_t W, int32_t log_depth_error, int32_t dtype, void *stream) {
     if (!pred || !gt || !sums || B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return -1;
-    const int64_t total = (int64_t)B * h * w;
+    if ((int64_t)B * h >= (1LL << 31)) return -7;
+    const int rows = B * h, grid = rows < 512 ? rows : 512, block = w > 128 ? 256 : (w > 64 ? 128 : 64);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == GWD_BF16)
-        silog_sums_kernel<__bf16><<<flat_grid(total), 256, 0, s>>>((const __bf16 *)pred, gt, sums, total, h, w, H, W, log_depth_error);
+        silog_sums_kernel<__bf16><<<grid, block, 0, s>>>((const __bf16 *)pred, gt, sums, rows, h, w, H, W, log_depth_error);
     else if (dtype == GWD_F32)
-        silog_sums_kernel<float><<<flat_grid(total), 256, 0, s>>>((const float *)pred, gt, sums, total, h, w, H, W, log_depth_error);
+        silog_sums_kernel<float><<<grid, block, 0, s>>>((const float *)pred, gt, sums, rows, h, w, H, W, log_depth_error);
     else
         return -2;
     GWD_CHECK_LAUNCH();
@@ -131,12 +140,13 @@ extern "C" int gwd_silog_backward(const void *pred, const float *gt, const doubl
                                   float loss_weight, float lambda, void *gpred, int32_t B, int32_t h, int32_t w,
                                   int32_t H, int32_t W, int32_t log_depth_error, int32_t dtype, void *stream) {
     if (!pred || !gt || !sums || !gloss || !gpred || B <= 0 || h <= 0 || w <= 0) return -1;
-    const int64_t total = (int64_t)B * h * w;
+    if ((int64_t)B * h >= (1LL << 31)) return -7;
+    const int rows = B * h, grid = rows < 2048 ? rows : 2048, block = w > 128 ? 256 : (w > 64 ? 128 : 64);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == GWD_BF16)
-        silog_bwd_kernel<__bf16><<<flat_grid(total), 256, 0, s>>>((const __bf16 *)pred, gt, sums, gloss, loss_weight, lambda, (__bf16 *)gpred, total, h, w, H, W, log_depth_error);
+        silog_bwd_kernel<__bf16><<<grid, block, 0, s>>>((const __bf16 *)pred, gt, sums, gloss, loss_weight, lambda, (__bf16 *)gpred, rows, h, w, H, W, log_depth_error);
     else if (dtype == GWD_F32)
-        silog_bwd_kernel<float><<<flat_grid(total), 256, 0, s>>>((const float *)pred, gt, sums, gloss, loss_weight, lambda, (float *)gpred, total, h, w, H, W, log_depth_error);
+        silog_bwd_kernel<float><<<grid, block, 0, s>>>((const float *)pred, gt, sums, gloss, loss_weight, lambda, (float *)gpred, rows, h, w, H, W, log_depth_error);
     else
         return -2;
     GWD_CHECK_LAUNCH();

@@ -319,6 +319,11 @@ int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s) {
 
 }  // namespace tconv
 
+// (Round 2 also tried the same register-resident-weights idea for the 1x1 / Linear layers with K <= 256 on 153 600 rows - each wave
+//  streaming 32-row tiles of x straight from global memory as B fragments, lane = row: correct, but 23 -> 28 us (64 -> 128) and
+//  33 -> 72 us (64 -> 256) against the LDS-DMA kernel: a lane-per-row 16-byte load touches 32 different 128-byte lines per wave
+//  instruction, a quarter of the coalesced rate.  Removed; those layers stay on igemm_dma_kernel.)
+
 // 1 = launched, 0 = not one of these layers (the caller continues with the generic kernels)
 int gwd_tile_conv_forward(const gwd_conv_desc *d, hipStream_t s) {
     using namespace tconv;
