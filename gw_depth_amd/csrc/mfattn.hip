@@ -559,6 +559,242 @@ int gwd_mfattn_window(bool backward, const gwd_strided *q, const gwd_strided *k,
 }
 
 // =====================================================================================================================
+// Class-token ("transposed") attention of WindowClassAttention on the matrix cores (multiscale_transformerr.py:560-578):
+//   S[r][c] = scale * sum_n q[n][r] k[n][c]  (r < 4 token channels, c < E feature channels, n = the 49 tokens),
+//   A = softmax over c,  O[n][r] = sum_c A[r][c] v[n][c].
+// S^T[c][r] = K^T . Q (4 k-steps over the tokens; both operands column gathers from [token][channel] LDS images) leaves the
+// softmax axis c in the REGISTERS of lane r; O^T[r][n] = A . V^T takes that accumulator as its A operand (k = c, permuted) and V
+// rows as B: lane = token holds its 4 outputs -> one 8-byte store.  Backward: dA^T = V^T . dO the same way, dQ like O with K,
+// dK^T[c][n] = dS^T . Q^T and dV^T = A^T . dO^T sum over r (4 values, on the lane): dS and A cross LDS as tiny [c][16] bf16 images
+// and come back as row fragments; lane = token stores its E gradients in 8-byte pieces.  ~8 MFMAs forward, ~14 backward per
+// (window, head) instead of 48-96 six-step DPP wave reductions each way.
+namespace tok {
+using namespace mfattn;
+
+constexpr int QS = 24, KSTR = 40, AS = 24;          // row strides (elements): q / dO images [64][16+8], k / v images [64][32+8], A / dS [32][16+8]
+
+struct TOp {
+    void *p;
+    long ws, ts, hs;
+};
+
+// k / v rows of E channels (8-byte pieces: E = 12 is 24 bytes) -> image row, zero-filled to 32 columns
+template <int E>
+__device__ __forceinline__ void put_row_e(__bf16 *img, const __bf16 *src, int lane) {
+    if (lane < NT) {
+        __bf16 *dst = img + lane * KSTR;
+#pragma unroll
+        for (int c = 0; c < 32; c += 4) {
+            uint2 v = make_uint2(0, 0);
+            if (c < E) v = *(const uint2 *)(src + c);
+            *(uint2 *)(dst + c) = v;
+        }
+    }
+}
+__device__ __forceinline__ void put_row_4(__bf16 *img, const __bf16 *src, int lane) {      // q / dO rows: 4 channels, zero-filled to 16
+    if (lane < NT) {
+        __bf16 *dst = img + lane * QS;
+        *(uint2 *)dst = *(const uint2 *)src;
+        *(uint2 *)(dst + 4) = make_uint2(0, 0);
+        *(uint4 *)(dst + 8) = make_uint4(0, 0, 0, 0);
+    }
+}
+
+// X^T[c][r] = sum_n a[n][c] * b[n][r] over the 64 (padded) tokens: A = column gather of the [token][32] image, B = of the [token][16] image
+__device__ __forceinline__ f32x16 tokens_product(const __bf16 *img_c, const __bf16 *img_r, int lane) {
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = mma(gather_nat(img_c, KSTR, 0, 0, s, true, lane), gather_nat(img_r, QS, 0, 0, s, false, lane), acc);
+    return acc;
+}
+
+// Z[r][n] = sum_c x[c][r] * img[token n][c] for the 32 tokens of tile nt: A = the accumulator (k = c, permuted), B = image rows
+template <int E>
+__device__ __forceinline__ f32x16 channels_product(const f32x16 &x, const __bf16 *img, int nt, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int s = 0; s < (E > 16 ? 2 : 1); ++s) {
+        const __bf16 *row = img + (32 * nt + r) * KSTR + 16 * s + 4 * h;
+        union { uint2 u[2]; bf16x8 v; } b;
+        b.u[0] = *(const uint2 *)row;
+        b.u[1] = *(const uint2 *)(row + 8);
+        acc = mma(accfrag(x, s), b.v, acc);
+    }
+    return acc;
+}
+
+// softmax over the rows c < E of an S^T accumulator (lane = column r): in-register + one exchange with lane ^ 32
+template <int E>
+__device__ __forceinline__ void softmax_rows(f32x16 &x, float scale, int h) {
+    float m = -1e30f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        x[i] = acc_row(i, h) < E ? x[i] * scale : -1e30f;
+        m = fmaxf(m, x[i]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        x[i] = acc_row(i, h) < E ? __expf(x[i] - m) : 0.f;
+        l += x[i];
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] *= inv;
+}
+
+__device__ __forceinline__ void store4(const TOp &o, long w, int head, int nt, const f32x16 &z, float mul, int lane) {
+    const int tokn = 32 * nt + (lane & 31);
+    if ((lane >> 5) == 0 && tokn < NT) {                  // rows r = 0..3 are registers 0..3 of the lower half
+        union { uint2 u; __bf16 e[4]; } v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v.e[j] = (__bf16)(z[j] * mul);
+        *(uint2 *)((__bf16 *)o.p + w * o.ws + (long)tokn * o.ts + (long)head * o.hs) = v.u;
+    }
+}
+
+template <int E, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void tok_fwd_kernel(TOp q, TOp k, TOp v, TOp o, long n_problems, int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem_t[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    constexpr int PER = 64 * QS + 2 * 64 * KSTR;
+    __bf16 *qi = smem_t + wave * PER, *ki = qi + 64 * QS, *vi = ki + 64 * KSTR;
+    for (int e = lane * 8; e < PER; e += 512) *(uint4 *)(qi + e) = make_uint4(0, 0, 0, 0);
+    lds_settle();
+    const int tokc = lane < NT ? lane : NT - 1;
+    for (long pb = (long)blockIdx.x * WAVES + wave; pb < n_problems; pb += (long)gridDim.x * WAVES) {
+        const long w = pb / heads;
+        const int head = (int)(pb - w * heads);
+        put_row_4(qi, (const __bf16 *)q.p + w * q.ws + (long)tokc * q.ts + (long)head * q.hs, lane);
+        put_row_e<E>(ki, (const __bf16 *)k.p + w * k.ws + (long)tokc * k.ts + (long)head * k.hs, lane);
+        put_row_e<E>(vi, (const __bf16 *)v.p + w * v.ws + (long)tokc * v.ts + (long)head * v.hs, lane);
+        lds_settle();
+        f32x16 a = tokens_product(ki, qi, lane);           // S^T[c][r]
+        softmax_rows<E>(a, scale, h);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) store4(o, w, head, nt, channels_product<E>(a, vi, nt, lane), 1.0f, lane);
+        lds_settle();
+    }
+}
+
+// accumulator X[c][r] (lane = r < 4 real) -> bf16 image [c][16] (columns 4..15 stay zero)
+__device__ __forceinline__ void put_cr(__bf16 *img, const f32x16 &x, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    if (r < 4) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) img[acc_row(i, h) * AS + r] = (__bf16)x[i];
+    }
+}
+
+// D^T[c][n] = sum_r img_cr[c][r] * img_tok[token n][r] for token tile nt (one k-step: r = 0..15, 4 real)
+__device__ __forceinline__ f32x16 r_product(const __bf16 *img_cr, const __bf16 *img_tok, int nt, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    const bf16x8 a = *(const bf16x8 *)(img_cr + r * AS + 8 * h);
+    const bf16x8 b = *(const bf16x8 *)(img_tok + (32 * nt + r) * QS + 8 * h);
+    return mma(a, b, zero16());
+}
+
+// D^T accumulator (rows = channels c, lane = token) -> E channels of the token's row, 8-byte pieces
+template <int E>
+__device__ __forceinline__ void store_e(const TOp &o, long w, int head, int nt, const f32x16 &z, float mul, int lane) {
+    const int tokn = 32 * nt + (lane & 31), h = lane >> 5;
+    if (tokn >= NT) return;
+    __bf16 *dst = (__bf16 *)o.p + w * o.ws + (long)tokn * o.ts + (long)head * o.hs;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int c0 = 8 * g + 4 * h;
+        if (c0 < E) {
+            union { uint2 u; __bf16 e[4]; } v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v.e[j] = (__bf16)(z[4 * g + j] * mul);
+            *(uint2 *)(dst + c0) = v.u;
+        }
+    }
+}
+
+template <int E, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void tok_bwd_kernel(TOp q, TOp k, TOp v, TOp go, TOp gq, TOp gk, TOp gv, long n_problems, int heads,
+                                                            float scale) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem_u[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    constexpr int PER = 2 * 64 * QS + 2 * 64 * KSTR + 2 * 32 * AS;
+    __bf16 *qi = smem_u + wave * PER, *oi = qi + 64 * QS, *ki = oi + 64 * QS, *vi = ki + 64 * KSTR, *ai = vi + 64 * KSTR, *si = ai + 32 * AS;
+    for (int e = lane * 8; e < PER; e += 512) *(uint4 *)(qi + e) = make_uint4(0, 0, 0, 0);
+    lds_settle();
+    const int tokc = lane < NT ? lane : NT - 1;
+    for (long pb = (long)blockIdx.x * WAVES + wave; pb < n_problems; pb += (long)gridDim.x * WAVES) {
+        const long w = pb / heads;
+        const int head = (int)(pb - w * heads);
+        put_row_4(qi, (const __bf16 *)q.p + w * q.ws + (long)tokc * q.ts + (long)head * q.hs, lane);
+        put_row_4(oi, (const __bf16 *)go.p + w * go.ws + (long)tokc * go.ts + (long)head * go.hs, lane);
+        put_row_e<E>(ki, (const __bf16 *)k.p + w * k.ws + (long)tokc * k.ts + (long)head * k.hs, lane);
+        put_row_e<E>(vi, (const __bf16 *)v.p + w * v.ws + (long)tokc * v.ts + (long)head * v.hs, lane);
+        lds_settle();
+        f32x16 a = tokens_product(ki, qi, lane);           // S^T[c][r]
+        softmax_rows<E>(a, scale, h);
+        f32x16 da = tokens_product(vi, oi, lane);          // dA^T[c][r] = sum_n v[n][c] dO[n][r]
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dot += a[i] * da[i];
+        dot += __shfl_xor(dot, 32, 64);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) da[i] = a[i] * (da[i] - dot);      // dS^T (unscaled; the scale rides on the stores)
+        put_cr(ai, a, lane);
+        put_cr(si, da, lane);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) store4(gq, w, head, nt, channels_product<E>(da, ki, nt, lane), scale, lane);     // dq[n][r] = scale sum_c dS[r][c] k[n][c]
+        lds_settle();
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            store_e<E>(gk, w, head, nt, r_product(si, qi, nt, lane), scale, lane);       // dk[n][c] = scale sum_r dS[r][c] q[n][r]
+            store_e<E>(gv, w, head, nt, r_product(ai, oi, nt, lane), 1.0f, lane);        // dv[n][c] = sum_r A[r][c] dO[n][r]
+        }
+        lds_settle();
+    }
+}
+
+template <int E>
+int run(bool bwd, const gwd_strided *const *s, long n_problems, int heads, float scale, hipStream_t st) {
+    for (int i = 0; i < (bwd ? 7 : 4); ++i)                 // 8-byte rows everywhere
+        if ((uintptr_t)s[i]->p % 8 || s[i]->ws % 4 || s[i]->ts % 4 || s[i]->hs % 4) return 1;
+    auto mk = [](const gwd_strided *x) { return TOp{x->p, x->ws, x->ts, x->hs}; };
+    if (!bwd) {
+        constexpr int WAVES = 4;
+        long bx = (n_problems + WAVES - 1) / WAVES;
+        if (bx > 1024) bx = 1024;
+        const size_t lds = (size_t)WAVES * (64 * QS + 2 * 64 * KSTR) * 2;
+        tok_fwd_kernel<E, WAVES><<<(unsigned)bx, 64 * WAVES, lds, st>>>(mk(s[0]), mk(s[1]), mk(s[2]), mk(s[3]), n_problems, heads, scale);
+    } else {
+        constexpr int WAVES = 2;
+        long bx = (n_problems + WAVES - 1) / WAVES;
+        if (bx > 2048) bx = 2048;
+        const size_t lds = (size_t)WAVES * (2 * 64 * QS + 2 * 64 * KSTR + 2 * 32 * AS) * 2;
+        tok_bwd_kernel<E, WAVES><<<(unsigned)bx, 64 * WAVES, lds, st>>>(mk(s[0]), mk(s[1]), mk(s[2]), mk(s[3]), mk(s[4]), mk(s[5]), mk(s[6]), n_problems,
+                                                                         heads, scale);
+    }
+    return 0;
+}
+
+}  // namespace tok
+
+// 0 = launched, 1 = not covered (the caller keeps the lane-per-token kernels); bf16 only
+int gwd_mfattn_token(bool backward, const gwd_strided *const *ops, long n_problems, int heads, int e, float scale, hipStream_t s) {
+    // measured per launch (53 k problems at E = 12, 13.8 k at 16, 3.8 k at 24): forward 107 / 39 / 23 us on the lane-per-token kernels ->
+    // 90 / 20 / ~12 here; backward 224 / 77 / 43 -> 269 / 52 / 20: at E = 12 the 48 wave reductions of the VALU form are cheaper than this
+    // kernel's 8-24-byte-per-lane row traffic, so that one case stays there
+    if (backward && e == 12) return 1;
+    switch (e) {
+        case 12: return tok::run<12>(backward, ops, n_problems, heads, scale, s);
+        case 16: return tok::run<16>(backward, ops, n_problems, heads, scale, s);
+        case 24: return tok::run<24>(backward, ops, n_problems, heads, scale, s);
+        default: return 1;
+    }
+}
+
+// =====================================================================================================================
 // DETR multi-head attention core (head_dim 32), forward and backward, flash style: no L x S matrix ever reaches memory.
 //   O = dropout(softmax(scale Q K^T + key-padding mask)) V, heads merged   (/root/reference/src/models/multi_head_attention.py:329-375)
 // One wave per (batch, head, 32-query tile) walks the key tiles with an online softmax (query on the lane, so the running

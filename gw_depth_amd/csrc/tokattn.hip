@@ -5,6 +5,7 @@
 // One 64-lane wave per problem, lane = token n: S and dA are 4*E wave reductions (DPP/shuffle butterflies, every
 // lane ends up with the full 4 x E matrix), everything else is lane-local.  E = (dim + 128) / 16 in {12, 16, 24}.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -194,10 +195,26 @@ int by_e(int e, bool bwd, const gwd_strided *const *s, long np, int heads, float
 
 }  // namespace
 
+// mfattn.hip: the same problem on the matrix cores (bf16); 0 = launched, 1 = not covered
+int gwd_mfattn_token(bool backward, const gwd_strided *const *ops, long n_problems, int heads, int e, float scale, hipStream_t s);
+
+static bool mfma_token_enabled() {            // A/B switch (GWD_MFMA_TOKATTN=0: the lane-per-token kernels for bf16 as well)
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GWD_MFMA_TOKATTN");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 extern "C" int gwd_tokattn_forward(const gwd_strided *q, const gwd_strided *k, const gwd_strided *v, const gwd_strided *o,
                                    int64_t n_windows, int32_t heads, int32_t e, float scale, int32_t dtype, void *stream) {
     if (!q || !k || !v || !o || !q->p || !k->p || !v->p || !o->p || n_windows <= 0 || heads <= 0) return -1;
     const gwd_strided *s[4] = {q, k, v, o};
+    if (dtype == GWD_BF16 && mfma_token_enabled() && gwd_mfattn_token(false, s, n_windows * heads, heads, e, scale, (hipStream_t)stream) == 0) {
+        GWD_CHECK_LAUNCH();
+        return 0;
+    }
     if (dtype == GWD_BF16) return by_e<__bf16>(e, false, s, n_windows * heads, heads, scale, (hipStream_t)stream);
     if (dtype == GWD_F32) return by_e<float>(e, false, s, n_windows * heads, heads, scale, (hipStream_t)stream);
     return -2;
@@ -209,6 +226,10 @@ extern "C" int gwd_tokattn_backward(const gwd_strided *q, const gwd_strided *k, 
     if (!q || !k || !v || !go || !gq || !gk || !gv || n_windows <= 0 || heads <= 0) return -1;
     if (!q->p || !k->p || !v->p || !go->p || !gq->p || !gk->p || !gv->p) return -1;
     const gwd_strided *s[7] = {q, k, v, go, gq, gk, gv};
+    if (dtype == GWD_BF16 && mfma_token_enabled() && gwd_mfattn_token(true, s, n_windows * heads, heads, e, scale, (hipStream_t)stream) == 0) {
+        GWD_CHECK_LAUNCH();
+        return 0;
+    }
     if (dtype == GWD_BF16) return by_e<__bf16>(e, true, s, n_windows * heads, heads, scale, (hipStream_t)stream);
     if (dtype == GWD_F32) return by_e<float>(e, true, s, n_windows * heads, heads, scale, (hipStream_t)stream);
     return -2;
