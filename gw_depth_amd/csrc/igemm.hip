@@ -375,7 +375,9 @@ __device__ __forceinline__ int xcd_band(int id, int total) {
     return xcd * per + (xcd < rem ? xcd : rem) + idx;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false>
+// TAIL: Cin is a multiple of 8 but not of 32 (the 80-channel pyramid layers): the last 32-channel K tile of every tap is part data,
+// part zero page - compile-time variant, like MULT, so that the common kernels pay nothing for the per-lane channel bound.
+template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false, bool TAIL = false>
 __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_desc d, const int tile_base, const int tile_count) {
     typedef __bf16 T;
     constexpr int BK = 32, NW = WM * WN;                 // 4 or 8 waves
@@ -437,11 +439,13 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
     const float up_sh = (float)d.Hi / (float)(d.Hv > 0 ? d.Hv : 1), up_sw = (float)d.Wi / (float)(d.Wv > 0 ? d.Wv : 1);
     const char *b_src[B_IT];
     bool b_ok[B_IT];
+    int b_ck[B_IT];
     const int my_b_loads = (B_FULL == 0 || wave < B_FULL) ? B_IT : B_IT - 1;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
         const int row = 16 * (wave + i * NW) + (lane >> 2);
         const int ck = ((lane & 3) ^ ((row >> 2) & 3)) * 8;
+        b_ck[i] = ck;
         const int n = n0 + row;
         b_ok[i] = row < BN && n < N;
         b_src[i] = (const char *)(wgt + (size_t)(b_ok[i] ? n : 0) * K + ck);
@@ -455,12 +459,12 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int KT = K / BK;
+    const int KT = TAIL ? d.KH * d.KW * ((d.Cin + BK - 1) / BK) : K / BK;
     // reduction order: 64-channel group (one 128-byte line per pixel) outermost, then the filter taps, then the two
     // 32-channel halves of the group - a pixel's line is re-read for the next tap / half one or two tiles later, while
     // it is still in L2 (tap-outermost order has a reuse distance of Cin/32 tiles x every resident workgroup).
     int u_kh = 0, u_kw = 0, u_cb = 0, u_sub = 0, u_c0 = 0;  // workgroup-uniform state of the next tile to issue
-    int u_grp = d.Cin >= 64 ? 2 : 1;                     // 32-channel tiles in the current group
+    int u_grp = d.Cin > 32 ? 2 : 1;                      // 32-channel tiles in the current group (the last one may be a partial tile: TAIL)
     auto issue = [&](int stage) {
         char *sb = smem + stage * STAGE_BYTES;
 #pragma unroll
@@ -490,6 +494,7 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
                 iw = min((int)floorf((float)vw * up_sw), d.Wi - 1);
             }
             ok = ok & a_ok[i];
+            if constexpr (TAIL) ok = ok & (u_c0 + a_ck[i] < d.Cin);
             const size_t off = (a_pix[i] + (size_t)(ok ? ih : 0) * d.Wi + (ok ? iw : 0)) * d.Cin + u_c0 + a_ck[i];
             const char *src = ok ? (const char *)(x + off) : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
@@ -498,7 +503,9 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             if (i < my_b_loads) {                                 // wave-uniform
-                const char *src = b_ok[i] ? b_src[i] + (size_t)((u_kh * d.KW + u_kw) * d.Cin + u_c0) * 2 : zero;
+                bool bok = b_ok[i];
+                if constexpr (TAIL) bok = bok & (u_c0 + b_ck[i] < d.Cin);
+                const char *src = bok ? b_src[i] + (size_t)((u_kh * d.KW + u_kw) * d.Cin + u_c0) * 2 : zero;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(sb + BM * 64 + (wave + i * NW) * 1024), 16, 0, 0);
             }
@@ -510,7 +517,7 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
                 if (++u_kh == d.KH) {
                     u_kh = 0;
                     u_cb += 64;
-                    u_grp = d.Cin - u_cb >= 64 ? 2 : 1;
+                    u_grp = d.Cin - u_cb > 32 ? 2 : 1;
                 }
             }
         }
@@ -1126,6 +1133,15 @@ static bool big_tiles_enabled() {
     return v == 1;
 }
 
+static bool tail_enabled() {                 // A/B switch (GWD_IGEMM_TAILK=0: the register-staged kernel for Cin % 32 != 0, as before)
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GWD_IGEMM_TAILK");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 static int small_tile_threshold() {
     static int v = -1;
     if (v < 0) {
@@ -1174,6 +1190,27 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
         return 0;
     }
     if constexpr (sizeof(T) == 2) {
+        // Cin = 8 (mod 32) multiples such as the 80-channel pyramid: the LDS-DMA kernels with a zero-page channel tail (big maps, the two
+        // hot tile shapes, plain and stride-1 transposed gathers) instead of the register-staged kernel (112-166 us per launch)
+        if (dma_enabled() && tail_enabled() && d->zero_page && (d->Cin % 32) != 0 && (d->Cin % 8) == 0 && d->Cin > 32 && (N % 8) == 0 && M >= 256 * 512 &&
+            (d->gather == GWD_GATHER_CONV || (d->gather == GWD_GATHER_TRANSPOSED && d->stride == 1))) {
+            const bool tr = d->gather != GWD_GATHER_CONV;
+            const unsigned gm2 = (M + 255) / 256;
+            if (N % 160 == 0) {
+                const dim3 g(gm2 * (N / 160));
+                if (tr) igemm_dma_kernel<256, 160, 8, 1, 3, 1, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
+                else igemm_dma_kernel<256, 160, 8, 1, 3, 0, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
+                GWD_CHECK_LAUNCH();
+                return 0;
+            }
+            if (N > 64) {
+                const dim3 g(gm2 * ((N + 127) / 128));
+                if (tr) igemm_dma_kernel<256, 128, 4, 2, 3, 1, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
+                else igemm_dma_kernel<256, 128, 4, 2, 3, 0, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
+                GWD_CHECK_LAUNCH();
+                return 0;
+            }
+        }
         if (dma_enabled() && d->zero_page && (d->Cin % 32) == 0 && (N % 8) == 0) {
             const int gmk = d->gather == GWD_GATHER_CONV ? 0 : ((d->gather == GWD_GATHER_TRANSPOSED && d->stride == 1) ? 1 : 2);
 #define DMA_LAUNCH(BM_, BN_, WM_, WN_, ST_, GRID)                                                              \

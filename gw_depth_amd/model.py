@@ -433,7 +433,7 @@ class WindowAttention(WindowAttnBase):
         qkv = self.qkv(xw).view(B_, N, 3, HEADS, hd)
         rqk = self.ref_qk(x_ref)
         rB = rqk.shape[0]
-        ref_k = self.diff_mu.to(rqk.dtype) + self.diff_logsigma.exp().to(rqk.dtype) * rqk[..., :C]      # (rB, nrf, C), :289-292
+        ref_k = ops.row_affine(rqk[..., :C], self.diff_mu, self.diff_logsigma)      # mu + exp(logsigma) * x, (rB, nrf, C), :289-292
         ra = ops.ref_scores(qkv, ref_k, rB, self.scale)                          # (rB, nWin*N, nrf, heads): pixel-major map, :295-298
         for _ in range(3):                                                        # :299-302
             upd = ops.conv2d(ra, self.ref_attn_diffusion.weight, self.ref_attn_diffusion.bias, pad=1)

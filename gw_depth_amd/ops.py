@@ -779,6 +779,44 @@ def window_attention(q, k, v, table, rel, region, windows_per_image, scale):
     return _WinAttnFn.apply(q, k, v, table, rel, region, int(windows_per_image), float(scale), _sink(table))
 
 
+class _RowAffineFn(torch.autograd.Function):
+    """mu + exp(logsigma) * x with per-channel mu / logsigma (the reference tokens' re-parameterisation,
+    multiscale_transformerr.py:289-292).  The parameter gradients are column sums over the rows: own colsum kernel straight into
+    the flat gradient buffer - ATen's multi-block reduction zeroes its semaphore with hipMemsetAsync once the row count grows
+    (batch 16), which a HIP graph cannot replay (engine.TrainStep refuses the capture)."""
+
+    @staticmethod
+    def forward(ctx, x, mu, logsigma, sinks):
+        e = logsigma.detach().exp().to(x.dtype)
+        ctx.save_for_backward(x, e)
+        ctx.sinks = sinks
+        ctx.shapes = (mu.shape, logsigma.shape)
+        return mu.detach().to(x.dtype) + e * x
+
+    @staticmethod
+    def backward(ctx, g):
+        x, e = ctx.saved_tensors
+        g = g.contiguous()
+        C = g.shape[-1]
+        rows = g.numel() // C
+        gl = (g * x * e).contiguous()
+        outs = []
+        for t, sink, shape in ((g, ctx.sinks[0], ctx.shapes[0]), (gl, ctx.sinks[1], ctx.shapes[1])):
+            if sink is not None:
+                COLSUMS.add(t, sink[0].view(-1), rows, C, sink[1])
+                outs.append(None)
+            else:
+                o = torch.zeros(C, dtype=torch.float32, device=g.device)
+                _lib().colsum(t, o, rows, C)
+                outs.append(o.view(shape))
+        return g * e, outs[0], outs[1], None
+
+
+def row_affine(x, mu, logsigma):
+    """mu + exp(logsigma) * x, x (..., C), mu / logsigma (1, 1, C) parameters."""
+    return _RowAffineFn.apply(x, mu, logsigma, (_sink(mu), _sink(logsigma)))
+
+
 class _RefScoresFn(torch.autograd.Function):
     """ra (B, nwin*49, R, H) = scale * q . ref_k per head (multiscale_transformerr.py:296-298); q is read in place from the packed
     qkv projection (W, 49, 3, H, hd) and its gradient comes back as ONE packed tensor (k and v slots zero)."""

@@ -65,7 +65,9 @@ CASES = [
     ("pyramid2_lastconv_800_320_3x3", (8, 120, 160), 800, 320, 3, 1, 1, None, {},
      "fwd <256,160> two column tiles, K = 7200; dgrad 320->800 <256,160,..,1>; wgrad<160,128> 2 x 57 tiles"),
     ("pyramid2_firstconv_80_160_3x3", (8, 120, 160), 80, 160, 3, 1, 1, None, {},
-     "Cin % 32 != 0: register-staged igemm_fwd_kernel<bf16,128,160>; dgrad 160->80 <256,128,4,2,3,1>; wgrad_dma<160,128>"),
+     "Cin = 80: igemm_dma<256,160,8,1,3,0> with the channel tail (was the register-staged kernel); dgrad 160->80 <256,128,4,2,3,1>; wgrad_dma<160,128>"),
+    ("pyramid2_firstconv_80_80_3x3", (8, 120, 160), 80, 80, 3, 1, 1, None, {},
+     "Cin = 80: igemm_dma<256,128,4,2,3,*> with the zero-page channel tail (27 K tiles: 9 taps x (32 + 32 + 16|zero)), forward and data gradient"),
     ("pyramid2_lastconv_320_80_1x1", (8, 120, 160), 320, 80, 1, 1, 0, None, {},
      "fwd <256,128,4,2,3,0> with 80 of 128 columns; dgrad 80->320 register-staged; wgrad <128,128> plain GEMM"),
     ("class3_mlp_fc1_64_128_gelu", (8, 120, 160), 64, 128, 1, 1, 0, None, dict(shift=True, act=hip.ACT_GELU, z=True),
