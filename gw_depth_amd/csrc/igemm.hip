@@ -1092,6 +1092,10 @@ __global__ __launch_bounds__(256) void weight_prep_batch_kernel(const gwd_prep_j
     const int n0 = (t % nt) * 32, tap = t / nt;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     __bf16 *wf = (__bf16 *)j.w_fwd, *wd = (__bf16 *)j.w_dgrad;
+    // zero-padded destinations (Np > 0): rows N -> Np, every group of Cg input channels -> Cgp; the padding is never written
+    // (the caller zeroes the copies once), only the index map changes
+    const bool pad = j.Np > 0;
+    const int Np = pad ? j.Np : j.N, Cp = pad ? (j.C / j.Cg) * j.Cgp : j.C;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int n = n0 + ty + 8 * k, c = c0 + tx;
@@ -1099,7 +1103,7 @@ __global__ __launch_bounds__(256) void weight_prep_batch_kernel(const gwd_prep_j
         if (n < j.N && c < j.C) {
             const size_t i = ((size_t)n * j.taps + tap) * j.C + c;
             v = j.row_scale ? j.w[i] * j.row_scale[n] : j.w[i];
-            if (wf) wf[i] = (__bf16)v;
+            if (wf) wf[pad ? ((size_t)n * j.taps + tap) * Cp + (c / j.Cg) * j.Cgp + c % j.Cg : i] = (__bf16)v;
         }
         tile[ty + 8 * k][tx] = v;
     }
@@ -1108,8 +1112,31 @@ __global__ __launch_bounds__(256) void weight_prep_batch_kernel(const gwd_prep_j
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = c0 + ty + 8 * k, n = n0 + tx;
-        if (n < j.N && c < j.C) wd[((size_t)c * j.taps + tap) * j.N + n] = (__bf16)tile[tx][ty + 8 * k];
+        if (n < j.N && c < j.C) {
+            const int cp = pad ? (c / j.Cg) * j.Cgp + c % j.Cg : c;
+            wd[((size_t)cp * j.taps + tap) * Np + n] = (__bf16)tile[tx][ty + 8 * k];
+        }
     }
+}
+
+// dst (N, taps, G*Cg) += src (Np, taps, G*Cgp): the weight gradient of a layer that ran on zero-padded channel counts, folded back
+// onto the parameter's own shape.  Jobs by value in the kernel arguments (capturable, nothing to upload), one 256-thread block
+// per 256 destination elements.
+struct UnpadBatch {
+    gwd_unpad_job j[GWD_UNPAD_BATCH];
+    int n;
+};
+__global__ __launch_bounds__(256) void unpad_add_batch_kernel(const UnpadBatch b) {
+    int ji = 0;
+#pragma unroll 1
+    for (int k = 1; k < b.n; ++k)
+        if ((int)blockIdx.x >= b.j[k].block0) ji = k;
+    const gwd_unpad_job j = b.j[ji];
+    const int i = ((int)blockIdx.x - j.block0) * 256 + threadIdx.x;
+    const int C = j.G * j.Cg;
+    if (i >= j.N * j.taps * C) return;
+    const int c = i % C, r = i / C;                      // r = n * taps + tap
+    j.dst[i] += j.src[(size_t)r * (j.G * j.Cgp) + (c / j.Cg) * j.Cgp + c % j.Cg];
 }
 
 int check_desc(const gwd_conv_desc *d) {
@@ -1354,7 +1381,8 @@ int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s, WgradCollecto
                 else if (d->Ho == d->Hi && d->Wo == d->Wi && d->Wo >= 11) fast = 1;
             }
             if (N % 160 == 0 && K >= 256 && (var == 1 || var == 2)) WG_LAUNCH(160, 256, 1, 4, 3)      // var 2: the wide tile for the 160-wide pyramids only
-            else if (N % 160 == 0 && K >= 128 && var != 3) WG_LAUNCH(160, 128, 1, 4, 3)
+            else if (N % 160 == 0 && K >= 128 && var == 4) WG_LAUNCH(160, 128, 1, 4, 3)      // the 3-stage ring (default until round 2)
+            else if (N % 160 == 0 && K >= 128 && var != 3) WG_LAUNCH(160, 128, 1, 4, 4)      // 4 stages = 72 KB, still 2 per CU: +3-4 %
             else if (N > 64 && K >= 256 && var == 1) WG_LAUNCH(128, 256, 2, 2, 3)
             else if (N > 64 && K > 64) WG_LAUNCH(128, 128, 2, 2, 3)
             else if (N <= 32 && K >= 128 && wgrad_variant() != 5) WG_LAUNCH(32, 128, 1, 4, 4)      // narrow layers: no half-empty 64-row tile
@@ -1379,6 +1407,17 @@ int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s, WgradCollecto
 
 }  // namespace
 
+// GWD_TRACE_CONV=1: one stderr line per conv / weight-gradient call (shape census of a step; tools/convcensus.py)
+static bool trace_conv() {
+    static int v = -1;
+    if (v < 0) v = getenv("GWD_TRACE_CONV") ? 1 : 0;
+    return v == 1;
+}
+static void trace_line(const char *what, const gwd_conv_desc *d) {
+    fprintf(stderr, "GWDCONV %s B=%d Hi=%d Wi=%d Cin=%d Ho=%d Wo=%d Cout=%d k=%d s=%d g=%d dt=%d\n", what, d->B, d->Hi, d->Wi, d->Cin, d->Ho,
+            d->Wo, d->Cout, d->KH, d->stride, d->gather, d->dtype);
+}
+
 // thinconv.hip: streaming kernels for the 1-2 channel heads; return 1 when they took the problem
 int gwd_thin_conv_forward(const gwd_conv_desc *d, hipStream_t s);
 int gwd_thin_conv_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s);
@@ -1391,6 +1430,7 @@ extern "C" int gwd_conv_forward(const gwd_conv_desc *d, void *stream) {
     if (rc) return rc;
     if (!d->w) return -1;
     if ((int64_t)d->B * d->Ho * d->Wo * d->Cout >= (1LL << 40)) return -7;
+    if (trace_conv()) trace_line("fwd", d);
     if (gwd_thin_conv_forward(d, (hipStream_t)stream) || gwd_tile_conv_forward(d, (hipStream_t)stream)) {
         GWD_CHECK_LAUNCH();
         return 0;
@@ -1402,6 +1442,7 @@ extern "C" int gwd_conv_wgrad(const gwd_conv_desc *d, float *dw, void *stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!dw) return -1;
+    if (trace_conv()) trace_line("wgrad", d);
     if (gwd_thin_conv_wgrad(d, dw, (hipStream_t)stream) || gwd_tile_conv_wgrad(d, dw, (hipStream_t)stream)) {
         GWD_CHECK_LAUNCH();
         return 0;
@@ -1422,6 +1463,7 @@ extern "C" int gwd_conv_wgrad_batch(const gwd_conv_desc *descs, float *const *dw
     for (int i = 0; i < n; ++i) {
         const gwd_conv_desc *d = descs + i;
         if (coll.g128.n == WG_GROUP || coll.g64.n == WG_GROUP) coll.flush(s);
+        if (trace_conv()) trace_line("wgrad", d);
         if (gwd_thin_conv_wgrad(d, dws[i], s) || gwd_tile_conv_wgrad(d, dws[i], s)) continue;
         const int rc = d->dtype == GWD_BF16 ? launch_wgrad<__bf16>(d, dws[i], s, &coll) : launch_wgrad<float>(d, dws[i], s);
         if (rc) return rc;
@@ -1443,6 +1485,24 @@ extern "C" int gwd_weight_prep(const float *w, const float *row_scale, void *w_f
         weight_prep_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>(w, row_scale, (float *)w_fwd, (float *)w_dgrad, N, taps, C);
     else
         return -2;
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gwd_unpad_add_batch(const gwd_unpad_job *jobs, int32_t n_jobs, void *stream) {
+    if (!jobs || n_jobs <= 0 || n_jobs > GWD_UNPAD_BATCH) return -1;
+    UnpadBatch b;
+    int total = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        gwd_unpad_job j = jobs[i];
+        if (!j.src || !j.dst || j.N <= 0 || j.taps <= 0 || j.G <= 0 || j.Cg <= 0 || j.Cgp < j.Cg) return -1;
+        if ((int64_t)j.N * j.taps * j.G * j.Cg >= (1LL << 31)) return -7;
+        j.block0 = total;
+        total += (j.N * j.taps * j.G * j.Cg + 255) / 256;
+        b.j[i] = j;
+    }
+    b.n = n_jobs;
+    unpad_add_batch_kernel<<<total, 256, 0, (hipStream_t)stream>>>(b);
     GWD_CHECK_LAUNCH();
     return 0;
 }

@@ -295,24 +295,28 @@ template <int VB> struct Raw;
 template <> struct Raw<16> { uint4 v; };
 template <> struct Raw<8> { uint2 v; };
 
-template <typename T, int LPR, int NCH, int VB>
+template <typename T, int LPR, int NCH, int VB, bool PAD = false>
 __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T *__restrict__ x, const float *__restrict__ gamma,
                                                                 const float *__restrict__ beta, T *__restrict__ y,
                                                                 float *__restrict__ mean, float *__restrict__ rstd,
-                                                                int64_t rows, int C, int gelu, const T *__restrict__ res) {
+                                                                int64_t rows, int C, int gelu, const T *__restrict__ res, int ld) {
+    // PAD: rows are ld >= C elements apart and the channels C..ld-1 are padding - their input is ignored (whatever it holds), their
+    // output is written as zeros (the zero-padded activations of a layer that runs on a rounded-up channel count, see
+    // gwd_unpad_add_batch); C need not be a multiple of the vector then, ld is.  !PAD: ld == C.
     constexpr int VEC = VB / (int)sizeof(T), RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, sub = lane % LPR, rsel = lane / LPR;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
     float g[NCH][VEC], b[NCH][VEC];
-    bool okc[NCH];
+    bool okc[NCH];              // the lane's vector lies inside the row
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int ch = (sub + c * LPR) * VEC;
-        okc[c] = ch < C;
+        okc[c] = ch < (PAD ? ld : C);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            g[c][e] = (gamma && okc[c]) ? gamma[ch + e] : 1.f;
-            b[c][e] = (beta && okc[c]) ? beta[ch + e] : 0.f;
+            const bool ok = okc[c] && (!PAD || ch + e < C);
+            g[c][e] = (gamma && ok) ? gamma[ch + e] : 1.f;
+            b[c][e] = (beta && ok) ? beta[ch + e] : 0.f;
         }
     }
     for (int64_t r0 = wave * RPW; r0 < rows; r0 += nw * RPW) {
@@ -323,11 +327,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T *__restr
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             Raw<VB> raw = {};
-            if (okr && okc[c]) raw = *(const Raw<VB> *)(x + r * C + (sub + c * LPR) * VEC);
+            if (okr && okc[c]) raw = *(const Raw<VB> *)(x + r * ld + (sub + c * LPR) * VEC);
             const T *pv = (const T *)&raw;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                v[c][e] = to_f32(pv[e]);
+                v[c][e] = (!PAD || (sub + c * LPR) * VEC + e < C) ? to_f32(pv[e]) : 0.f;
                 s += v[c][e];
             }
         }
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T *__restr
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                const float dlt = okc[c] ? v[c][e] - mu : 0.f;
+                const float dlt = (okc[c] && (!PAD || (sub + c * LPR) * VEC + e < C)) ? v[c][e] - mu : 0.f;
                 q += dlt * dlt;
             }
         q = segment_sum<LPR>(q);
@@ -352,28 +356,29 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T *__restr
             if (!(okr && okc[c])) continue;
             alignas(16) T outv[VEC];
             Raw<VB> rraw = {};
-            if (res) rraw = *(const Raw<VB> *)(res + r * C + (sub + c * LPR) * VEC);
+            if (res) rraw = *(const Raw<VB> *)(res + r * ld + (sub + c * LPR) * VEC);
             const T *pr = (const T *)&rraw;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 float o = (v[c][e] - mu) * rs * g[c][e] + b[c][e];
                 if (gelu) o = gelu_f(o);
                 if (res) o += to_f32(pr[e]);
+                if (PAD && (sub + c * LPR) * VEC + e >= C) o = 0.f;
                 outv[e] = from_f32<T>(o);
             }
-            *(Raw<VB> *)(y + r * C + (sub + c * LPR) * VEC) = *(const Raw<VB> *)outv;
+            *(Raw<VB> *)(y + r * ld + (sub + c * LPR) * VEC) = *(const Raw<VB> *)outv;
         }
     }
 }
 
 // NWV waves per workgroup: 4, or 16 for narrow rows - the affine-gradient reduction ends in one atomic per channel per
 // WORKGROUP, and with hundreds of small workgroups those serialise on the same few cache lines (10-18 us of a 25 us call)
-template <typename T, int LPR, int NCH, int VB, int NWV>
+template <typename T, int LPR, int NCH, int VB, int NWV, bool PAD = false>
 __global__ __launch_bounds__(NWV * 64) void layernorm_bwd_vec_kernel(const T *__restrict__ gy, const T *__restrict__ x,
                                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                 const float *__restrict__ mean, const float *__restrict__ rstd,
                                                                 T *__restrict__ gx, float *__restrict__ dgamma,
-                                                                float *__restrict__ dbeta, int64_t rows, int C, int gelu) {
+                                                                float *__restrict__ dbeta, int64_t rows, int C, int gelu, int ld) {
     constexpr int VEC = VB / (int)sizeof(T), RPW = 64 / LPR;
     __shared__ float red[2][NWV][LPR * NCH * VEC];    // [gamma|beta][wave][channel slot]
     const int lane = threadIdx.x & 63, sub = lane % LPR, rsel = lane / LPR, wv = threadIdx.x >> 6;
@@ -383,11 +388,12 @@ __global__ __launch_bounds__(NWV * 64) void layernorm_bwd_vec_kernel(const T *__
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int ch = (sub + c * LPR) * VEC;
-        okc[c] = ch < C;
+        okc[c] = ch < (PAD ? ld : C);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            g[c][e] = (gamma && okc[c]) ? gamma[ch + e] : 1.f;
-            b[c][e] = (beta && okc[c]) ? beta[ch + e] : 0.f;
+            const bool ok = okc[c] && (!PAD || ch + e < C);
+            g[c][e] = (gamma && ok) ? gamma[ch + e] : 1.f;
+            b[c][e] = (beta && ok) ? beta[ch + e] : 0.f;
             ag[c][e] = ab[c][e] = 0.f;
         }
     }
@@ -400,15 +406,16 @@ __global__ __launch_bounds__(NWV * 64) void layernorm_bwd_vec_kernel(const T *__
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             Raw<VB> rx = {}, rg = {};
-            const bool ok = okr && okc[c];
-            if (ok) {
-                rx = *(const Raw<VB> *)(x + r * C + (sub + c * LPR) * VEC);
-                rg = *(const Raw<VB> *)(gy + r * C + (sub + c * LPR) * VEC);
+            const bool okv = okr && okc[c];
+            if (okv) {
+                rx = *(const Raw<VB> *)(x + r * ld + (sub + c * LPR) * VEC);
+                rg = *(const Raw<VB> *)(gy + r * ld + (sub + c * LPR) * VEC);
             }
             const T *px = (const T *)&rx;
             const T *pg = (const T *)&rg;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
+                const bool ok = okv && (!PAD || (sub + c * LPR) * VEC + e < C);
                 xh[c][e] = ok ? (to_f32(px[e]) - mu) * rs : 0.f;
                 float gg = ok ? to_f32(pg[e]) : 0.f;
                 if (gelu) gg *= gelu_grad_f(xh[c][e] * g[c][e] + b[c][e]);
@@ -428,8 +435,12 @@ __global__ __launch_bounds__(NWV * 64) void layernorm_bwd_vec_kernel(const T *__
             if (!(okr && okc[c])) continue;
             alignas(16) T outv[VEC];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) outv[e] = from_f32<T>(rs * (gw[c][e] - s1 - xh[c][e] * s2));
-            *(Raw<VB> *)(gx + r * C + (sub + c * LPR) * VEC) = *(const Raw<VB> *)outv;
+            for (int e = 0; e < VEC; ++e) {
+                float o = rs * (gw[c][e] - s1 - xh[c][e] * s2);
+                if (PAD && (sub + c * LPR) * VEC + e >= C) o = 0.f;
+                outv[e] = from_f32<T>(o);
+            }
+            *(Raw<VB> *)(gx + r * ld + (sub + c * LPR) * VEC) = *(const Raw<VB> *)outv;
         }
     }
     if (dgamma) {
@@ -631,18 +642,19 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const T *__restrict
     }
 }
 
-template <typename T, int VB>
+template <typename T, int VB, bool PAD = false>
 int launch_ln_fwd_vec(const T *x, const float *ga, const float *be, T *y, float *mean, float *rstd, int64_t rows, int C, int gelu,
-                      const T *res, hipStream_t s) {
+                      const T *res, int ld, hipStream_t s) {
     constexpr int VEC = VB / (int)sizeof(T);
-    const int need = C / VEC;
+    if (ld % VEC) return -5;
+    const int need = ld / VEC;
 #define LN_FWD(LPR, NCH)                                                                                            \
     {                                                                                                               \
         const int64_t wv = (rows + (64 / LPR) - 1) / (64 / LPR);                                                    \
         /* ~20 KiB of rows per workgroup: measured optimum between 10 MB (512 workgroups) and 49 MB (2048) tensors */  \
         int64_t cap = rows * C * (int64_t)sizeof(T) / 20480;                                                        \
         cap = cap < 256 ? 256 : (cap > 2048 ? 2048 : cap);                                                          \
-        layernorm_fwd_vec_kernel<T, LPR, NCH, VB><<<row_grid(wv, 4, (int)cap), 256, 0, s>>>(x, ga, be, y, mean, rstd, rows, C, gelu, res); \
+        layernorm_fwd_vec_kernel<T, LPR, NCH, VB, PAD><<<row_grid(wv, 4, (int)cap), 256, 0, s>>>(x, ga, be, y, mean, rstd, rows, C, gelu, res, ld); \
         return 0;                                                                                                   \
     }
     if (need <= 8) LN_FWD(8, 1)
@@ -654,23 +666,24 @@ int launch_ln_fwd_vec(const T *x, const float *ga, const float *be, T *y, float 
     return -5;
 }
 
-template <typename T, int VB>
+template <typename T, int VB, bool PAD = false>
 int launch_ln_bwd_vec(const T *gy, const T *x, const float *ga, const float *be, const float *mean, const float *rstd, T *gx,
-                      float *dg, float *db, int64_t rows, int C, int gelu, hipStream_t s) {
+                      float *dg, float *db, int64_t rows, int C, int gelu, int ld, hipStream_t s) {
     constexpr int VEC = VB / (int)sizeof(T);
-    const int need = C / VEC;
+    if (ld % VEC) return -5;
+    const int need = ld / VEC;
 #define LN_BWD(LPR, NCH)                                                                                            \
     {                                                                                                               \
         const int64_t wv = (rows + (64 / LPR) - 1) / (64 / LPR);                                                    \
         if (LPR * NCH * VEC <= 512 && dg) {                     /* narrow rows: 16-wave workgroups, one per CU */   \
             int grid = row_grid(wv, 16);                                                                            \
             if (grid > 256) grid = 256;                                                                             \
-            layernorm_bwd_vec_kernel<T, LPR, NCH, VB, 16><<<grid, 1024, 0, s>>>(gy, x, ga, be, mean, rstd, gx, dg, db, rows, C, gelu); \
+            layernorm_bwd_vec_kernel<T, LPR, NCH, VB, 16, PAD><<<grid, 1024, 0, s>>>(gy, x, ga, be, mean, rstd, gx, dg, db, rows, C, gelu, ld); \
             return 0;                                                                                               \
         }                                                                                                           \
         int grid = row_grid(wv, 4);                                                                                 \
         if (grid > 768) grid = 768;                                                                                 \
-        layernorm_bwd_vec_kernel<T, LPR, NCH, VB, 4><<<grid, 256, 0, s>>>(gy, x, ga, be, mean, rstd, gx, dg, db, rows, C, gelu); \
+        layernorm_bwd_vec_kernel<T, LPR, NCH, VB, 4, PAD><<<grid, 256, 0, s>>>(gy, x, ga, be, mean, rstd, gx, dg, db, rows, C, gelu, ld); \
         return 0;                                                                                                   \
     }
     if (need <= 8) LN_BWD(8, 1)
@@ -690,17 +703,26 @@ int launch_ln_bwd_vec(const T *gy, const T *x, const float *ga, const float *be,
     else return -2;
 
 extern "C" int gwd_layernorm_forward(const void *x, const float *gamma, const float *beta, const void *residual, void *y, float *mean,
-                                     float *rstd, int64_t rows, int32_t C, int32_t gelu, int32_t dtype, void *stream) {
+                                     float *rstd, int64_t rows, int32_t C, int32_t ld, int32_t gelu, int32_t dtype, void *stream) {
     if (!x || !y || !mean || !rstd || rows < 0 || C <= 0 || C > 64 * MAX_PER_LANE) return -1;
     if ((gamma == nullptr) != (beta == nullptr)) return -1;
+    if (ld == 0) ld = C;
+    if (ld < C || ld > 64 * MAX_PER_LANE) return -1;
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    if (ld != C) {                           // zero-padded rows: 16-byte vectors over the pitch, per-element channel masks
+        int rc = -5;
+        if (dtype == GWD_BF16 && ld % 8 == 0) rc = launch_ln_fwd_vec<__bf16, 16, true>((const __bf16 *)x, gamma, beta, (__bf16 *)y, mean, rstd, rows, C, gelu, (const __bf16 *)residual, ld, s);
+        else if (dtype == GWD_F32 && ld % 4 == 0) rc = launch_ln_fwd_vec<float, 16, true>((const float *)x, gamma, beta, (float *)y, mean, rstd, rows, C, gelu, (const float *)residual, ld, s);
+        if (rc == 0) { GWD_CHECK_LAUNCH(); return 0; }
+        return -4;
+    }
     {
         int rc = -5;
-        if (dtype == GWD_BF16 && C % 8 == 0) rc = launch_ln_fwd_vec<__bf16, 16>((const __bf16 *)x, gamma, beta, (__bf16 *)y, mean, rstd, rows, C, gelu, (const __bf16 *)residual, s);
-        else if (dtype == GWD_BF16 && C % 4 == 0) rc = launch_ln_fwd_vec<__bf16, 8>((const __bf16 *)x, gamma, beta, (__bf16 *)y, mean, rstd, rows, C, gelu, (const __bf16 *)residual, s);
-        else if (dtype == GWD_F32 && C % 4 == 0) rc = launch_ln_fwd_vec<float, 16>((const float *)x, gamma, beta, (float *)y, mean, rstd, rows, C, gelu, (const float *)residual, s);
-        else if (dtype == GWD_F32 && C % 2 == 0) rc = launch_ln_fwd_vec<float, 8>((const float *)x, gamma, beta, (float *)y, mean, rstd, rows, C, gelu, (const float *)residual, s);
+        if (dtype == GWD_BF16 && C % 8 == 0) rc = launch_ln_fwd_vec<__bf16, 16>((const __bf16 *)x, gamma, beta, (__bf16 *)y, mean, rstd, rows, C, gelu, (const __bf16 *)residual, ld, s);
+        else if (dtype == GWD_BF16 && C % 4 == 0) rc = launch_ln_fwd_vec<__bf16, 8>((const __bf16 *)x, gamma, beta, (__bf16 *)y, mean, rstd, rows, C, gelu, (const __bf16 *)residual, ld, s);
+        else if (dtype == GWD_F32 && C % 4 == 0) rc = launch_ln_fwd_vec<float, 16>((const float *)x, gamma, beta, (float *)y, mean, rstd, rows, C, gelu, (const float *)residual, ld, s);
+        else if (dtype == GWD_F32 && C % 2 == 0) rc = launch_ln_fwd_vec<float, 8>((const float *)x, gamma, beta, (float *)y, mean, rstd, rows, C, gelu, (const float *)residual, ld, s);
         if (rc == 0) { GWD_CHECK_LAUNCH(); return 0; }
     }
     const int grid = row_grid(rows, 4);
@@ -713,17 +735,26 @@ extern "C" int gwd_layernorm_forward(const void *x, const float *gamma, const fl
 
 extern "C" int gwd_layernorm_backward(const void *gy, const void *x, const float *gamma, const float *beta,
                                       const float *mean, const float *rstd, void *gx, float *dgamma, float *dbeta,
-                                      int64_t rows, int32_t C, int32_t gelu, int32_t dtype, void *stream) {
+                                      int64_t rows, int32_t C, int32_t ld, int32_t gelu, int32_t dtype, void *stream) {
     if (!gy || !x || !gx || !mean || !rstd || rows < 0 || C <= 0 || C > 64 * MAX_PER_LANE) return -1;
     if ((dgamma == nullptr) != (dbeta == nullptr)) return -1;
+    if (ld == 0) ld = C;
+    if (ld < C || ld > 64 * MAX_PER_LANE) return -1;
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    if (ld != C) {
+        int rc = -5;
+        if (dtype == GWD_BF16 && ld % 8 == 0) rc = launch_ln_bwd_vec<__bf16, 16, true>((const __bf16 *)gy, (const __bf16 *)x, gamma, beta, mean, rstd, (__bf16 *)gx, dgamma, dbeta, rows, C, gelu, ld, s);
+        else if (dtype == GWD_F32 && ld % 4 == 0) rc = launch_ln_bwd_vec<float, 16, true>((const float *)gy, (const float *)x, gamma, beta, mean, rstd, (float *)gx, dgamma, dbeta, rows, C, gelu, ld, s);
+        if (rc == 0) { GWD_CHECK_LAUNCH(); return 0; }
+        return -4;
+    }
     {
         int rc = -5;
-        if (dtype == GWD_BF16 && C % 8 == 0) rc = launch_ln_bwd_vec<__bf16, 16>((const __bf16 *)gy, (const __bf16 *)x, gamma, beta, mean, rstd, (__bf16 *)gx, dgamma, dbeta, rows, C, gelu, s);
-        else if (dtype == GWD_BF16 && C % 4 == 0) rc = launch_ln_bwd_vec<__bf16, 8>((const __bf16 *)gy, (const __bf16 *)x, gamma, beta, mean, rstd, (__bf16 *)gx, dgamma, dbeta, rows, C, gelu, s);
-        else if (dtype == GWD_F32 && C % 4 == 0) rc = launch_ln_bwd_vec<float, 16>((const float *)gy, (const float *)x, gamma, beta, mean, rstd, (float *)gx, dgamma, dbeta, rows, C, gelu, s);
-        else if (dtype == GWD_F32 && C % 2 == 0) rc = launch_ln_bwd_vec<float, 8>((const float *)gy, (const float *)x, gamma, beta, mean, rstd, (float *)gx, dgamma, dbeta, rows, C, gelu, s);
+        if (dtype == GWD_BF16 && C % 8 == 0) rc = launch_ln_bwd_vec<__bf16, 16>((const __bf16 *)gy, (const __bf16 *)x, gamma, beta, mean, rstd, (__bf16 *)gx, dgamma, dbeta, rows, C, gelu, ld, s);
+        else if (dtype == GWD_BF16 && C % 4 == 0) rc = launch_ln_bwd_vec<__bf16, 8>((const __bf16 *)gy, (const __bf16 *)x, gamma, beta, mean, rstd, (__bf16 *)gx, dgamma, dbeta, rows, C, gelu, ld, s);
+        else if (dtype == GWD_F32 && C % 4 == 0) rc = launch_ln_bwd_vec<float, 16>((const float *)gy, (const float *)x, gamma, beta, mean, rstd, (float *)gx, dgamma, dbeta, rows, C, gelu, ld, s);
+        else if (dtype == GWD_F32 && C % 2 == 0) rc = launch_ln_bwd_vec<float, 8>((const float *)gy, (const float *)x, gamma, beta, mean, rstd, (float *)gx, dgamma, dbeta, rows, C, gelu, ld, s);
         if (rc == 0) { GWD_CHECK_LAUNCH(); return 0; }
     }
     int grid = row_grid(rows, 4);

@@ -31,7 +31,7 @@ ENTRY_POINTS = [
     "gwd_softmax_masked_forward", "gwd_softmax_scaled_backward", "gwd_query_workspace", "gwd_eval_accumulate", "gwd_colsum_batch", "gwd_conv_wgrad_batch",
     "gwd_plane_loss_forward", "gwd_plane_loss_backward", "gwd_collate",
     "gwd_anchor_depth_forward", "gwd_anchor_depth_backward", "gwd_mha_flash_forward", "gwd_mha_flash_backward",
-    "gwd_ref_scores_forward", "gwd_ref_scores_backward", "gwd_ref_mix_forward", "gwd_ref_mix_backward",
+    "gwd_ref_scores_forward", "gwd_ref_scores_backward", "gwd_ref_mix_forward", "gwd_ref_mix_backward", "gwd_unpad_add_batch",
 ]
 
 
@@ -51,7 +51,17 @@ class ConvDesc(ctypes.Structure):
 class PrepJob(ctypes.Structure):
     """gwd_prep_job (include/gwdepth.h)."""
     _fields_ = [("w", ctypes.c_void_p), ("row_scale", ctypes.c_void_p), ("w_fwd", ctypes.c_void_p), ("w_dgrad", ctypes.c_void_p),
-                ("N", ctypes.c_int32), ("taps", ctypes.c_int32), ("C", ctypes.c_int32), ("block0", ctypes.c_int32)]
+                ("N", ctypes.c_int32), ("taps", ctypes.c_int32), ("C", ctypes.c_int32), ("block0", ctypes.c_int32),
+                ("Np", ctypes.c_int32), ("Cg", ctypes.c_int32), ("Cgp", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class UnpadJob(ctypes.Structure):
+    """gwd_unpad_job (include/gwdepth.h)."""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("N", ctypes.c_int32), ("taps", ctypes.c_int32), ("G", ctypes.c_int32),
+                ("Cg", ctypes.c_int32), ("Cgp", ctypes.c_int32), ("block0", ctypes.c_int32)]
+
+
+UNPAD_BATCH = 24
 
 
 class ColsumJob(ctypes.Structure):
@@ -142,8 +152,9 @@ class HipLibrary:
         L.gwd_anchor_depth_forward.argtypes = [vp, vp, vp, i32, i64, i32, i32, vp]
         L.gwd_anchor_depth_backward.argtypes = [vp, vp, vp, vp, vp, i32, i64, i32, i32, vp]
         L.gwd_colsum_batch.argtypes = [ctypes.POINTER(ColsumJob), i32, i32, vp]
-        L.gwd_layernorm_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
-        L.gwd_layernorm_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
+        L.gwd_layernorm_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
+        L.gwd_layernorm_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
+        L.gwd_unpad_add_batch.argtypes = [ctypes.POINTER(UnpadJob), i32, vp]
         L.gwd_softmax_forward.argtypes = [vp, vp, i64, i32, i32, vp]
         L.gwd_softmax_backward.argtypes = [vp, vp, vp, i64, i32, i32, vp]
         L.gwd_silog_sums.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -276,15 +287,33 @@ class HipLibrary:
         vec = 8 if g.dtype == torch.bfloat16 else 4
         return C % vec == 0 and C // vec <= 256
 
-    def layernorm_forward(self, x, gamma, beta, y, mean, rstd, rows, C, gelu, residual=None):
+    def layernorm_forward(self, x, gamma, beta, y, mean, rstd, rows, C, gelu, residual=None, ld=0):
+        """ld: row pitch in elements (0 = C); channels C..ld-1 are zero padding, written as zeros."""
         self._check(self.lib.gwd_layernorm_forward(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(y), _ptr(mean), _ptr(rstd),
-                                                   rows, C, int(gelu), dtype_code(x), self._stream(x, y)),
+                                                   rows, C, ld, int(gelu), dtype_code(x), self._stream(x, y)),
                     "gwd_layernorm_forward")
 
-    def layernorm_backward(self, gy, x, gamma, beta, mean, rstd, gx, dgamma, dbeta, rows, C, gelu):
+    def layernorm_backward(self, gy, x, gamma, beta, mean, rstd, gx, dgamma, dbeta, rows, C, gelu, ld=0):
         self._check(self.lib.gwd_layernorm_backward(_ptr(gy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd),
-                                                    _ptr(gx), _ptr(dgamma), _ptr(dbeta), rows, C, int(gelu),
+                                                    _ptr(gx), _ptr(dgamma), _ptr(dbeta), rows, C, ld, int(gelu),
                                                     dtype_code(x), self._stream(gy, x, gx)), "gwd_layernorm_backward")
+
+    def unpad_add_batch(self, jobs):
+        """jobs: tuples (src, dst, N, taps, G, Cg, Cgp): dst (N, taps, G*Cg) += src (.., taps, G*Cgp), fp32; one launch per
+        UNPAD_BATCH jobs (gwd_unpad_add_batch)."""
+        for i0 in range(0, len(jobs), UNPAD_BATCH):
+            part = jobs[i0:i0 + UNPAD_BATCH]
+            recs = (UnpadJob * len(part))()
+            ts = []
+            for i, (src, dst, N, taps, G, Cg, Cgp) in enumerate(part):
+                if src.dtype != torch.float32 or dst.dtype != torch.float32 or not src.is_contiguous() or not dst.is_contiguous():
+                    raise ValueError("unpad_add_batch: contiguous fp32 tensors expected")
+                if dst.numel() != N * taps * G * Cg or src.numel() < N * taps * G * Cgp:
+                    raise ValueError("unpad_add_batch: shapes do not match the job")
+                r = recs[i]
+                r.src, r.dst, r.N, r.taps, r.G, r.Cg, r.Cgp, r.block0 = src.data_ptr(), dst.data_ptr(), N, taps, G, Cg, Cgp, 0
+                ts += [src, dst]
+            self._check(self.lib.gwd_unpad_add_batch(recs, len(part), self._stream(*ts)), "gwd_unpad_add_batch")
 
     def softmax_forward(self, x, y, rows, L):
         self._check(self.lib.gwd_softmax_forward(_ptr(x), _ptr(y), rows, L, dtype_code(x), self._stream(x, y)),

@@ -561,7 +561,9 @@ class ConvLn(nn.Module):
         self.layer_norm = LayerNorm(cout)
         self.pad = k // 2
 
-    def forward(self, x, gelu=False, residual=None):
+    def forward(self, x, gelu=False, residual=None, geom=None):
+        if geom is not None:                # zero-padded channel counts (PyramidLayer.padded_width); the LayerNorm sees the pitch
+            return self.layer_norm(ops.conv2d_padded(x, self.conv.weight, self.pad, geom), gelu, residual=residual)
         return self.layer_norm(ops.conv2d(x, self.conv.weight, pad=self.pad), gelu, residual=residual)
 
 
@@ -573,8 +575,8 @@ class PyrBlock(nn.Module):
         self.conv1 = Seq(_0=ConvLn(c, c, 3))
         self.conv2 = ConvLn(c, c, 3)
 
-    def forward(self, x):
-        return self.conv2(self.conv1[0](x, True), residual=x)            # the skip is added in the LayerNorm kernel
+    def forward(self, x, geom=None):
+        return self.conv2(self.conv1[0](x, True, geom=geom), residual=x, geom=geom)      # the skip is added in the LayerNorm kernel
 
 
 class PyramidLayer(nn.Module):
@@ -593,7 +595,22 @@ class PyramidLayer(nn.Module):
             setattr(self, f"branch{i}", Seq(_1=ConvLn(c2, c2, 3)))
         self.lastconv = Seq(_0=ConvLn(5 * c2, 2 * c2, 3), _2=Conv(2 * c2, c, 1))
 
+    FORCE_PAD = False           # tests: the padded route on the CPU stand-in too
+
+    def padded_width(self, ref):
+        """Width of the map this pyramid wants: c, or c rounded up to 32 when c is not a multiple of 8 (the 30-point pyramid: 30 / 60 /
+        300 / 120 channels are rows of 60 - 600 bytes, which keep every conv on the register-staged odd-width kernels at 80 - 190
+        TFLOP/s and the weight gradients out of the grouped launches; as 32 / 64 / 320 / 128 they take the LDS-DMA route).  The
+        caller hands over a map of that width whose extra channels are ZERO and gets the result in the same width."""
+        c = self.firstconv[0].conv.weight.shape[0]
+        if c % 8 and ((ref.dtype == torch.bfloat16 and ref.is_cuda) or self.FORCE_PAD):
+            return (c + 31) // 32 * 32
+        return c
+
     def forward(self, x):
+        c = self.firstconv[0].conv.weight.shape[0]
+        if x.shape[-1] != c:
+            return self.forward_padded(x, c)
         x = self.firstconv[2](self.firstconv[0](x, True), True)
         x = self.layer3(self.layer2(self.layer1(x)))
         B, H, W, C = x.shape
@@ -606,6 +623,29 @@ class PyramidLayer(nn.Module):
             outs.append(ops.upsample_bilinear_ac(y, size))
         x = self.lastconv[0](torch.cat(outs, dim=-1), True)
         return ops.conv2d(x, self.lastconv[2].weight)
+
+    def forward_padded(self, x, c):
+        """The same layers on zero-padded channel counts (ops._PadConvFn); pooling, resampling and the concat are channel-agnostic
+        and keep zeros zero, the LayerNorms normalise the real channels and write zeros into the padding."""
+        r32 = lambda n: (n + 31) // 32 * 32
+        cp, c2, c2p, c4, c4p = r32(c), 2 * c, r32(2 * c), 4 * c, r32(4 * c)
+        if x.shape[-1] != cp:
+            raise ValueError("PyramidLayer: a map of %d or %d channels expected, got %d" % (c, cp, x.shape[-1]))
+        x = self.firstconv[2](self.firstconv[0](x, True, geom=(cp, c, cp)), True, geom=(c2p, c, cp))
+        g2 = (c2p, c2, c2p)
+        for layer in (self.layer1, self.layer2, self.layer3):
+            for blk in layer:
+                x = blk(x, g2)
+        B, H, W, C = x.shape
+        if H < self.pools[0] or W < self.pools[0]:
+            x = F.pad(x, (0, 0, 0, max(self.pools[0] - W, 0), 0, max(self.pools[0] - H, 0)))
+        size = x.shape[1:3]
+        outs = [x]
+        for i, k in enumerate(self.pools, start=1):
+            y = getattr(self, f"branch{i}")[1](ops.avg_pool(x, k), True, geom=g2)
+            outs.append(ops.upsample_bilinear_ac(y, size))
+        x = self.lastconv[0](torch.cat(outs, dim=-1), True, geom=(c4p, c2, c2p))       # five groups of c2 channels, each padded
+        return ops.conv2d_padded(x, self.lastconv[2].weight, 0, (cp, c4, c4p))
 
 
 class PointBasedPred(nn.Module):
@@ -625,9 +665,14 @@ class PointBasedPred(nn.Module):
         refer = ops.point_sample(xr.reshape(B, H, W, self.dim), coords) + ops.point_sample(pos, coords)   # (B, S, dim) fp32
         hp, wp = pre_depth.shape[-2:]
         anchor = ops.point_sample(pre_depth.float().reshape(B, hp, wp, 1), coords)       # (B, S, 1)
+        S = refer.shape[1]
+        Sp = self.pyramid.padded_width(xg)                   # S, or S rounded up to 32: zero rows in `refer` = zero channels of the map
+        if Sp != S:
+            refer = F.pad(refer, (0, 0, 0, Sp - S))
         rg = torch.bmm(xg, refer.transpose(1, 2).to(xg.dtype)) * (self.dim ** -2)       # (B, HW, S) = pixel-major map
         # NB: when H or W < 16 the pyramid zero-pads its map and the reference keeps the padded size (:94-125)
-        att = ops.softmax_lastdim(self.pyramid(rg.view(B, H, W, -1)))
+        logits = self.pyramid(rg.view(B, H, W, -1))
+        att = ops.softmax_lastdim(logits if Sp == S else logits[..., :S])
         Ho, Wo, R = att.shape[1], att.shape[2], att.shape[3]
         if R <= 256 and os.environ.get("GWD_ANCHOR_FUSED", "1") != "0":
             pred = ops.anchor_depth(att.view(B, Ho * Wo, R), anchor.view(B, R))          # sum_r att * anchor depth, one pass

@@ -41,28 +41,34 @@ class WeightCache:
         self._retired = []
 
     @staticmethod
-    def _key(w, rs):
-        return (w.data_ptr(), tuple(w.shape), 0 if rs is None else rs.data_ptr())
+    def _key(w, rs, geom=None):
+        return (w.data_ptr(), tuple(w.shape), 0 if rs is None else rs.data_ptr(), geom)
 
-    def get(self, w, rs, kind):
-        """kind 'fwd' | 't' -> cached tensor, or None when the cache is not in a pass / not applicable."""
+    def get(self, w, rs, kind, geom=None):
+        """kind 'fwd' | 't' -> cached tensor, or None when the cache is not in a pass / not applicable.
+        geom = (Np, Cg, Cgp): the zero-padded copies of padded_weight()."""
         if not self.active or not w.is_cuda or w.dtype != torch.float32:
             return None
         p = w.data_ptr()
         if not any(a <= p < b for a, b in self.ranges):
             return None
-        job = self.jobs.get(self._key(w, rs))
+        job = self.jobs.get(self._key(w, rs, geom))
         if job is not None and job[kind] is not None:
             return job[kind]        # refreshed by this pass's batch launch, or made earlier in this very pass
-        return self._add(w, rs, kind)
+        return self._add(w, rs, kind, geom)
 
-    def _add(self, w, rs, kind):
-        key = self._key(w, rs)
+    def _add(self, w, rs, kind, geom=None):
+        key = self._key(w, rs, geom)
         job = self.jobs.get(key)
         if job is None:
-            job = self.jobs[key] = {"w": w.detach(), "rs": rs, "fwd": None, "t": None}
+            job = self.jobs[key] = {"w": w.detach(), "rs": rs, "fwd": None, "t": None, "geom": geom}
         N, C = w.shape[0], w.shape[-1]
         taps = w.numel() // (N * C)
+        if geom is not None:
+            # the padding is written here, once; the per-step batch launch refreshes the real entries only
+            job[kind] = padded_weight(w.detach(), geom, kind, torch.bfloat16)
+            self.dirty = True
+            return job[kind]
         if kind == "fwd":
             out = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
             _lib().weight_prep(w.detach(), rs, out, None, N, taps, C, hip.BF16)
@@ -85,6 +91,7 @@ class WeightCache:
                 r.w_fwd = 0 if job["fwd"] is None else job["fwd"].data_ptr()
                 r.w_dgrad = 0 if job["t"] is None else job["t"].data_ptr()
                 r.N, r.taps, r.C, r.block0 = N, w.numel() // (N * C), C, b0
+                r.Np, r.Cg, r.Cgp = job["geom"] if job.get("geom") is not None else (0, 0, 0)
                 b0 += (w.numel() // (N * C)) * ((N + 31) // 32) * ((C + 31) // 32)
             raw = torch.frombuffer(bytearray(bytes(recs)), dtype=torch.uint8)
             dev = next(iter(self.jobs.values()))["w"].device
@@ -160,13 +167,17 @@ class WgradQueue:
     def __init__(self):
         self.jobs, self.active = [], False
 
-    def add(self, x, dv, dw, dims, kw, hook=None):
+    def add(self, x, dv, dw, dims, kw, hook=None, unpad=None):
+        """unpad = (dst, N, taps, G, Cg, Cgp): dw is a zeroed scratch tensor in the PADDED weight shape; after the launch its real
+        entries are added to dst (the parameter's slot of the flat gradient buffer) by gwd_unpad_add_batch, then the hook fires."""
         if not self.active:
             _lib().conv_wgrad(x, dv, dw, dims, **kw)
+            if unpad is not None:
+                _lib().unpad_add_batch([(dw,) + tuple(unpad)])
             if hook is not None:
                 hook()
             return
-        self.jobs.append((x, dv, dw, dims, kw, hook))
+        self.jobs.append((x, dv, dw, dims, kw, hook, unpad))
         if len(self.jobs) == self.BATCH:
             self.flush()
 
@@ -175,6 +186,9 @@ class WgradQueue:
             return
         jobs, self.jobs = self.jobs, []
         _lib().conv_wgrad_batch([j[:5] for j in jobs])
+        folds = [(j[2],) + tuple(j[6]) for j in jobs if j[6] is not None]
+        if folds:
+            _lib().unpad_add_batch(folds)
         for j in jobs:
             if j[5] is not None:
                 j[5]()
@@ -226,6 +240,89 @@ def _weight_transposed(w, row_scale, dtype):
     out = torch.empty((C,) + tuple(w.shape[1:-1]) + (N,), dtype=dtype, device=w.device)
     _lib().weight_prep(w.detach(), row_scale, None, out, N, taps, C, hip.F32 if dtype == torch.float32 else hip.BF16)
     return out
+
+
+def padded_weight(w, geom, kind, dtype):
+    """Zero-padded kernel-side copy of w (N, KH, KW, C), geom = (Np, Cg, Cgp): rows N -> Np and each of the G = C / Cg groups of
+    input channels Cg -> Cgp.  kind 'fwd': (Np, KH, KW, G*Cgp); 't' (data gradient): (G*Cgp, KH, KW, Np)."""
+    Np, Cg, Cgp = geom
+    N, KH, KW, C = w.shape
+    G = C // Cg
+    if G * Cg != C or Np < N or Cgp < Cg:
+        raise ValueError("padded_weight: geometry %r does not fit a weight of shape %r" % (geom, tuple(w.shape)))
+    src = w.view(N, KH * KW, G, Cg)
+    if kind == "fwd":
+        out = torch.zeros((Np, KH, KW, G * Cgp), dtype=dtype, device=w.device)
+        out.view(Np, KH * KW, G, Cgp)[:N, :, :, :Cg] = src
+    else:
+        out = torch.zeros((G * Cgp, KH, KW, Np), dtype=dtype, device=w.device)
+        out.view(G, Cgp, KH * KW, Np)[:, :Cg, :, :N] = src.permute(2, 3, 1, 0)
+    return out
+
+
+def _padded_weight_for(w, geom, kind, dtype):
+    if dtype == torch.bfloat16 and _ACTIVE_WEIGHTS is not None:
+        cached = _ACTIVE_WEIGHTS.get(w, None, kind, geom)
+        if cached is not None:
+            return cached
+    return padded_weight(w.detach(), geom, kind, dtype)
+
+
+class _PadConvFn(torch.autograd.Function):
+    """Stride-1 convolution (no bias, no activation) of a layer whose channel counts are not multiples of the MFMA / LDS-DMA
+    granule, run on ZERO-PADDED channel counts: x (B, H, W, G*Cgp) holds G groups of Cg real channels each padded to Cgp with zeros,
+    the result (B, Ho, Wo, Np) has its Cout real channels followed by zeros.  The kernels see an ordinary (G*Cgp -> Np) layer (the
+    padding lives in the kernel-side weight copies: WeightCache / gwd_weight_prep_batch write the real entries into zeroed
+    copies), the parameter and its gradient keep their own shape: the weight gradient is formed in the padded shape and folded
+    back by gwd_unpad_add_batch.  User: the 30 / 60 / 300-channel pyramid of points_sample.py:45-125 (32 / 64 / 320 here)."""
+
+    @staticmethod
+    def forward(ctx, x, w, pad, geom, sink):
+        lib = _lib()
+        Np, Cg, Cgp = geom
+        B, Hi, Wi, Cin = x.shape
+        N, KH, KW, C = w.shape
+        G = C // Cg
+        if Cin != G * Cgp:
+            raise ValueError("conv2d_padded: input has %d channels, the padded weight expects %d" % (Cin, G * Cgp))
+        Ho, Wo = Hi + 2 * pad - KH + 1, Wi + 2 * pad - KW + 1
+        x = x.contiguous()
+        y = torch.empty((B, Ho, Wo, Np), dtype=x.dtype, device=x.device)
+        dims = (B, Hi, Wi, Cin, Ho, Wo, Np, KH, KW)
+        lib.conv_forward(x, _padded_weight_for(w, geom, "fwd", x.dtype), y, dims, stride=1, pad=pad)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (dims, pad, geom, sink)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib()
+        x, w = ctx.saved_tensors
+        dims, pad, geom, sink = ctx.cfg
+        B, Hi, Wi, Cin, Ho, Wo, Np, KH, KW = dims
+        _, Cg, Cgp = geom
+        N, C = w.shape[0], w.shape[-1]
+        gy = gy.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            lib.conv_forward(gy, _padded_weight_for(w, geom, "t", x.dtype), gx, (B, Ho, Wo, Np, Hi, Wi, Cin, KH, KW), stride=1, pad=pad,
+                             gather=GATHER_TRANSPOSED)
+        if ctx.needs_input_grad[1]:
+            tmp = torch.zeros((Np, KH, KW, Cin), dtype=torch.float32, device=x.device)
+            fold = (N, KH * KW, C // Cg, Cg, Cgp)
+            if sink is not None:
+                WGRADS.add(x, gy, tmp, dims, dict(stride=1, pad=pad), sink[1], unpad=(sink[0].view(-1),) + fold)
+            else:
+                lib.conv_wgrad(x, gy, tmp, dims, stride=1, pad=pad)
+                gw = torch.zeros(w.shape, dtype=torch.float32, device=w.device)
+                lib.unpad_add_batch([(tmp, gw.view(-1)) + fold])
+        return gx, gw, None, None, None
+
+
+def conv2d_padded(x, w, pad, geom):
+    """See _PadConvFn.  x (B, H, W, G*Cgp) zero-padded, w (Cout, KH, KW, G*Cg) fp32 master, geom = (Np, Cg, Cgp)."""
+    return _PadConvFn.apply(x, w, int(pad), tuple(int(v) for v in geom), _sink(w))
 
 
 class _ConvFn(torch.autograd.Function):
@@ -385,14 +482,16 @@ class _LayerNormFn(torch.autograd.Function):
         ctx.sinks = sinks
         ctx.has_res = residual is not None
         x = x.contiguous()
-        C = x.shape[-1]
-        rows = x.numel() // C
+        ld = x.shape[-1]
+        C = gamma.shape[0] if gamma is not None else ld       # fewer affine entries than channels: the rest is zero padding (_PadConvFn)
+        rows = x.numel() // ld
         y = torch.empty_like(x)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         g = gamma.detach() if gamma is not None else None
         b = beta.detach() if beta is not None else None
-        lib.layernorm_forward(x, g, b, y, mean, rstd, rows, C, gelu, residual=None if residual is None else residual.contiguous())
+        lib.layernorm_forward(x, g, b, y, mean, rstd, rows, C, gelu, residual=None if residual is None else residual.contiguous(),
+                              ld=0 if ld == C else ld)
         ctx.save_for_backward(x, g, b, mean, rstd)
         ctx.gelu = gelu
         return y
@@ -401,8 +500,9 @@ class _LayerNormFn(torch.autograd.Function):
     def backward(ctx, gy):
         lib = _lib()
         x, g, b, mean, rstd = ctx.saved_tensors
-        C = x.shape[-1]
-        rows = x.numel() // C
+        ld = x.shape[-1]
+        C = g.shape[0] if g is not None else ld
+        rows = x.numel() // ld
         gy = gy.contiguous()
         gx = torch.empty_like(x)
         dg = db = None
@@ -412,7 +512,7 @@ class _LayerNormFn(torch.autograd.Function):
         elif g is not None:
             dg = torch.zeros(C, dtype=torch.float32, device=x.device)
             db = torch.zeros(C, dtype=torch.float32, device=x.device)
-        lib.layernorm_backward(gy, x, g, b, mean, rstd, gx, dg, db, rows, C, ctx.gelu)
+        lib.layernorm_backward(gy, x, g, b, mean, rstd, gx, dg, db, rows, C, ctx.gelu, ld=0 if ld == C else ld)
         gres = gy if ctx.has_res else None                # y = LN(x) + residual: the skip gets the incoming gradient as is
         if direct:
             for h in (h1, h2):

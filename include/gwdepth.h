@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GWD_VERSION 5
+#define GWD_VERSION 6
 
 enum { GWD_F32 = 0, GWD_BF16 = 1 };
 enum { GWD_ACT_NONE = 0, GWD_ACT_RELU = 1, GWD_ACT_GELU = 2, GWD_ACT_ELU = 3, GWD_ACT_SIGMOID = 4 };
@@ -130,11 +130,14 @@ int gwd_act_backward_colsum(const void *gy, const void *ref, void *gx, float *db
  * src/models/dense_upsample.py:125,138,166,177.                                                  */
 /* residual (may be NULL): [rows][C], added AFTER the normalisation / GELU: y = gelu?(LN(x)) + residual - the skip
  * connection of BasicBlock (src/models/points/points_sample.py:41-42); its gradient is gy itself.              */
+/* ld: row pitch in elements of x, residual, y (forward) / gy, x, gx (backward); 0 = C.  With ld > C the channels C..ld-1 are
+ * zero padding: never read, WRITTEN as zeros in y / gx (statistics, gamma, beta and their gradients cover the C real channels);
+ * needs ld to be a multiple of 16 bytes, else -4 (C itself may be anything).                                      */
 int gwd_layernorm_forward(const void *x, const float *gamma, const float *beta, const void *residual, void *y, float *mean,
-                          float *rstd, int64_t rows, int32_t C, int32_t gelu, int32_t dtype, void *stream);
+                          float *rstd, int64_t rows, int32_t C, int32_t ld, int32_t gelu, int32_t dtype, void *stream);
 int gwd_layernorm_backward(const void *gy, const void *x, const float *gamma, const float *beta,
                            const float *mean, const float *rstd, void *gx, float *dgamma, float *dbeta,
-                           int64_t rows, int32_t C, int32_t gelu, int32_t dtype, void *stream);
+                           int64_t rows, int32_t C, int32_t ld, int32_t gelu, int32_t dtype, void *stream);
 
 /* Softmax over the last dim (row length L <= 1024), forward and backward.
  * Replaces F.softmax in src/models/multi_head_attention.py:366, multiscale_transformerr.py:307,
@@ -264,8 +267,25 @@ typedef struct gwd_prep_job {
     void *w_dgrad;           /* bf16 (C, taps, N) or NULL                                */
     int32_t N, taps, C;
     int32_t block0;
+    int32_t Np, Cg, Cgp;     /* Np > 0: ZERO-PADDED copies - w_fwd is (Np, taps, G*Cgp), w_dgrad (G*Cgp, taps, Np), where the C */
+    int32_t reserved;        /* input channels are G = C / Cg groups of Cg, each padded to Cgp; the caller zeroes the copies     */
+                             /* once, the launch writes the N x taps x C real entries only.  Np = 0: dense copies as above.      */
 } gwd_prep_job;
 int gwd_weight_prep_batch(const gwd_prep_job *jobs, int32_t n_jobs, int32_t total_blocks, void *stream);
+
+/* The other half of the zero-padded copies: a layer that ran on padded channel counts (its activations keep the padded width, so every
+ * conv / Linear on them takes the LDS-DMA route; the 30 / 60 / 300-channel pyramid of src/models/points/points_sample.py:45-125
+ * is the user) gets its weight gradient in the padded shape; this folds it back: dst (N, taps, G*Cg) += src (.., taps, G*Cgp)
+ * rows 0..N-1, group g channels 0..Cg-1.  Up to GWD_UNPAD_BATCH jobs per call = ONE launch; jobs are read on the host (by value
+ * in the kernel arguments); block0 is filled in by the library.                                                              */
+#define GWD_UNPAD_BATCH 24
+typedef struct gwd_unpad_job {
+    const float *src;        /* fp32 (>= N, taps, G*Cgp)                                */
+    float *dst;              /* fp32 (N, taps, G*Cg), accumulated                       */
+    int32_t N, taps, G, Cg, Cgp;
+    int32_t block0;
+} gwd_unpad_job;
+int gwd_unpad_add_batch(const gwd_unpad_job *jobs, int32_t n_jobs, void *stream);
 
 /* y = a + gelu((u - mean_bc(u)) * rsqrt(var_bc(u) + eps)), statistics over the L positions of image b for channel c;
  * a, u, y are (B, L, C), channel innermost (src/models/multiscale_transformerr.py:299-302: conv -> instance

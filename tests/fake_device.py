@@ -285,7 +285,15 @@ class FakeDevice:
     def colsum(self, g, out, rows, C):
         out.add_(g.reshape(rows, C).float().sum(0))
 
-    def layernorm_forward(self, x, gamma, beta, y, mean, rstd, rows, C, gelu, residual=None):
+    def layernorm_forward(self, x, gamma, beta, y, mean, rstd, rows, C, gelu, residual=None, ld=0):
+        if ld and ld != C:                      # padded rows: the real channels are normalised, the padding is written as zeros
+            yv = y.view(rows, ld)
+            yv.zero_()
+            yc = torch.empty(rows, C, dtype=y.dtype)
+            self.layernorm_forward(x.reshape(rows, ld)[:, :C].contiguous(), gamma, beta, yc, mean, rstd, rows, C, gelu,
+                                   None if residual is None else residual.reshape(rows, ld)[:, :C].contiguous())
+            yv[:, :C] = yc
+            return
         xf = x.reshape(rows, C).float()
         mu = xf.mean(1)
         rs = (xf.var(1, unbiased=False) + 1e-5).rsqrt()
@@ -300,7 +308,19 @@ class FakeDevice:
         mean.copy_(mu)
         rstd.copy_(rs)
 
-    def layernorm_backward(self, gy, x, gamma, beta, mean, rstd, gx, dgamma, dbeta, rows, C, gelu):
+    def unpad_add_batch(self, jobs):
+        for src, dst, N, taps, G, Cg, Cgp in jobs:
+            dst.view(N, taps, G, Cg).add_(src.view(-1, taps, G, Cgp)[:N, :, :, :Cg])
+
+    def layernorm_backward(self, gy, x, gamma, beta, mean, rstd, gx, dgamma, dbeta, rows, C, gelu, ld=0):
+        if ld and ld != C:
+            gxv = gx.view(rows, ld)
+            gxv.zero_()
+            gc = torch.empty(rows, C, dtype=gx.dtype)
+            self.layernorm_backward(gy.reshape(rows, ld)[:, :C].contiguous(), x.reshape(rows, ld)[:, :C].contiguous(), gamma, beta, mean, rstd,
+                                    gc, dgamma, dbeta, rows, C, gelu)
+            gxv[:, :C] = gc
+            return
         xf = x.reshape(rows, C).float().requires_grad_(True)
         ga = gamma.clone().requires_grad_(True) if gamma is not None else None
         be = beta.clone().requires_grad_(True) if beta is not None else None

@@ -777,3 +777,99 @@ def test_anchor_depth(dev, shape, dtype):
     dev.anchor_depth_backward(att.cuda(), anchor.cuda(), g.cuda(), datt, dan, B, P, R)
     torch.cuda.synchronize()
     assert rel(pred, pred_r) < 2e-5 and rel(datt, datt_r) < TOL[dtype] and rel(dan, dan_r) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,C,ld,gelu", [(777, 60, 64, True), (4800, 30, 32, True), (130, 120, 128, False), (65, 60, 64, False)])
+def test_layernorm_with_row_pitch_writes_zero_padding(dev, rows, C, ld, gelu, dtype):
+    """LayerNorm over the C real channels of rows that are ld wide: padding never read (poisoned here), written as zeros."""
+    fake = FakeDevice()
+    x = rnd(rows, ld, dtype=dtype, seed=1, scale=2.0)
+    x[:, C:] = float("nan")
+    res = rnd(rows, ld, dtype=dtype, seed=5)
+    gy = rnd(rows, ld, dtype=dtype, seed=4)
+    gy[:, C:] = float("nan")
+    ga, be = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    y_r, m_r, r_r = torch.empty_like(x), torch.empty(rows), torch.empty(rows)
+    fake.layernorm_forward(x, ga, be, y_r, m_r, r_r, rows, C, gelu, residual=res, ld=ld)
+    gx_r, dg_r, db_r = torch.empty_like(x), torch.zeros(C), torch.zeros(C)
+    fake.layernorm_backward(gy, x, ga, be, m_r, r_r, gx_r, dg_r, db_r, rows, C, gelu, ld=ld)
+    y, m, r = torch.full_like(x, 7.0).cuda(), torch.empty(rows).cuda(), torch.empty(rows).cuda()
+    dev.layernorm_forward(x.cuda(), ga.cuda(), be.cuda(), y, m, r, rows, C, gelu, residual=res.cuda(), ld=ld)
+    gx, dg, db = torch.full_like(x, 7.0).cuda(), torch.zeros(C).cuda(), torch.zeros(C).cuda()
+    dev.layernorm_backward(gy.cuda(), x.cuda(), ga.cuda(), be.cuda(), m, r, gx, dg, db, rows, C, gelu, ld=ld)
+    torch.cuda.synchronize()
+    assert float(y[:, C:].abs().max()) == 0.0 and float(gx[:, C:].abs().max()) == 0.0
+    assert rel(y[:, :C], y_r[:, :C]) < TOL[dtype] and rel(m, m_r) < 1e-5 and rel(r, r_r) < 1e-5
+    assert rel(gx[:, :C], gx_r[:, :C]) < TOL[dtype] and rel(dg, dg_r) < TOL[dtype] and rel(db, db_r) < TOL[dtype]
+
+
+def test_unpad_add_batch(dev):
+    torch.manual_seed(5)
+    specs = [(60, 9, 1, 60, 64, 64), (120, 9, 5, 60, 64, 128), (30, 1, 1, 120, 128, 32), (30, 9, 1, 30, 32, 32), (7, 3, 2, 5, 8, 7)] * 6   # 30 jobs: two launches
+    jobs, want = [], []
+    for N, taps, G, Cg, Cgp, Np in specs:
+        src = torch.randn(Np, taps, G * Cgp, device="cuda")
+        dst = torch.randn(N, taps, G * Cg, device="cuda")
+        want.append(dst + src.view(Np, taps, G, Cgp)[:N, :, :, :Cg].reshape(N, taps, G * Cg))
+        jobs.append((src, dst.view(-1), N, taps, G, Cg, Cgp))
+    dev.unpad_add_batch(jobs)
+    torch.cuda.synchronize()
+    for (src, dst, N, taps, G, Cg, Cgp), w in zip(jobs, want):
+        assert torch.equal(dst.view_as(w), w)
+
+
+def test_padded_weight_copies_refreshed_by_the_batch_launch(dev):
+    """WeightCache with a padding geometry: first pass = torch-built zero-padded copies, later passes = ONE gwd_weight_prep_batch
+    launch that rewrites the real entries of the same buffers (padding stays zero)."""
+    from gw_depth_amd import ops
+    torch.manual_seed(4)
+    cases = [((60, 3, 3, 60), (64, 60, 64)), ((120, 3, 3, 300), (128, 60, 64)), ((30, 1, 1, 120), (32, 120, 128)), ((30, 3, 3, 30), (32, 30, 32))]
+    ws = [torch.randn(s, device="cuda") for s, _ in cases]
+    plain = torch.randn(64, 3, 3, 32, device="cuda")
+    cache = ops.WeightCache([(w.data_ptr(), w.data_ptr() + w.numel() * 4) for w in ws + [plain]])
+    cache.begin_pass()
+    first = [(cache.get(w, None, "fwd", g), cache.get(w, None, "t", g)) for w, (_, g) in zip(ws, cases)]
+    assert cache.get(plain, None, "t") is not None
+    cache.end_pass()
+    for w, (_, g), (f, t) in zip(ws, cases, first):
+        assert torch.equal(f, ops.padded_weight(w, g, "fwd", torch.bfloat16)) and torch.equal(t, ops.padded_weight(w, g, "t", torch.bfloat16))
+    for w in ws + [plain]:
+        w.mul_(-0.75).add_(0.125)
+    cache.begin_pass()
+    for w, (_, g), (f, t) in zip(ws, cases, first):
+        assert cache.get(w, None, "fwd", g) is f and cache.get(w, None, "t", g) is t          # same buffers, refreshed in place
+        assert torch.equal(f, ops.padded_weight(w, g, "fwd", torch.bfloat16)) and torch.equal(t, ops.padded_weight(w, g, "t", torch.bfloat16))
+    cache.end_pass()
+
+
+@pytest.mark.parametrize("spec", [(2, 20, 24, 60, 60, 3, (64, 60, 64), 1), (1, 20, 24, 300, 120, 3, (128, 60, 64), 5), (2, 20, 24, 120, 30, 1, (32, 120, 128), 1),
+                                  (8, 60, 80, 60, 60, 3, (64, 60, 64), 1)])
+def test_padded_conv_equals_the_plain_conv(dev, spec):
+    """ops.conv2d_padded on zero-padded activations == ops.conv2d on the real channels: output (padding zero), input gradient
+    (padding zero), weight gradient in the parameter's own shape."""
+    from gw_depth_amd import ops
+    B, H, W, Ci, Co, K, geom, G = spec
+    Np, Cg, Cgp = geom
+    torch.manual_seed(6)
+    w = (torch.randn(Co, K, K, Ci, device="cuda") * (K * K * Ci) ** -0.5).requires_grad_(True)
+    x = torch.randn(B, H, W, Ci, device="cuda").bfloat16()
+    xp = torch.zeros(B, H, W, G * Cgp, device="cuda", dtype=torch.bfloat16)
+    xp.view(B, H, W, G, Cgp)[..., :Cg] = x.view(B, H, W, G, Cg)
+    x.requires_grad_(True)
+    xp.requires_grad_(True)
+    gy = torch.randn(B, H, W, Co, device="cuda").bfloat16()
+    y = ops.conv2d(x, w, pad=K // 2)
+    y.backward(gy)
+    gw0, gx0 = w.grad.clone(), x.grad.clone()
+    w.grad = None
+    yp = ops.conv2d_padded(xp, w, K // 2, geom)
+    gyp = torch.zeros(B, H, W, Np, device="cuda", dtype=torch.bfloat16)
+    gyp[..., :Co] = gy
+    yp.backward(gyp)
+    torch.cuda.synchronize()
+    assert yp.shape[-1] == Np and float(yp[..., Co:].abs().max()) == 0.0
+    assert rel(yp[..., :Co], y) < 2e-3                            # same products, another summation order
+    gxp = xp.grad.view(B, H, W, G, Cgp)
+    assert float(gxp[..., Cg:].abs().max()) == 0.0 and rel(gxp[..., :Cg].reshape(B, H, W, Ci), gx0) < 2e-3
+    assert w.grad.shape == gw0.shape and rel(w.grad, gw0) < 2e-3

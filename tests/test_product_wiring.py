@@ -87,3 +87,38 @@ def test_sync_free_criterion_equals_reference_criterion(fake):
     assert set(want) == set(got)
     for k in want:
         assert abs(float(want[k]) - float(got[k])) <= 1e-5 * max(1.0, abs(float(want[k]))), k
+
+
+def test_padded_pyramid_equals_the_plain_one(fake):
+    """PointBasedPred with the 30-point pyramid on zero-padded channel counts (32 / 64 / 320 / 128: ops._PadConvFn, LayerNorm with a
+    row pitch, weight gradients folded back by unpad_add_batch) == the same module on its own widths: output and every gradient."""
+    from gw_depth_amd.model import PointBasedPred, PyramidLayer
+    torch.manual_seed(0)
+    m = PointBasedPred(32, 16, 30)
+    for p in m.parameters():
+        torch.nn.init.normal_(p, std=0.2)
+    B, H, W = 2, 18, 20
+    x = torch.randn(B, H * W, 32, requires_grad=True)
+    dtok = torch.randn(B, H * W, 16, requires_grad=True)
+    pre = torch.rand(B, 1, 9, 10)
+    coords = torch.rand(B, 30, 1, 2) * 2 - 1
+    pos = torch.randn(B, H, W, 32)
+
+    def run(force):
+        PyramidLayer.FORCE_PAD = force
+        try:
+            for p in m.parameters():
+                p.grad = None
+            x.grad = dtok.grad = None
+            out = m(x, dtok, pre, coords, H, W, pos)
+            (out * torch.linspace(-1, 1, out.numel()).view_as(out)).sum().backward()
+            return out.detach().clone(), x.grad.clone(), dtok.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            PyramidLayer.FORCE_PAD = False
+
+    o0, gx0, gd0, gp0 = run(False)
+    o1, gx1, gd1, gp1 = run(True)
+    assert rel(o1, o0) < 1e-5 and rel(gx1, gx0) < 1e-4 and rel(gd1, gd0) < 1e-4
+    assert set(gp0) == set(gp1)
+    for n in gp0:
+        assert gp1[n].shape == gp0[n].shape and rel(gp1[n], gp0[n]) < 1e-4, n
