@@ -31,7 +31,7 @@ ENTRY_POINTS = [
     "gwd_softmax_masked_forward", "gwd_softmax_scaled_backward", "gwd_query_workspace", "gwd_eval_accumulate", "gwd_colsum_batch", "gwd_conv_wgrad_batch",
     "gwd_plane_loss_forward", "gwd_plane_loss_backward", "gwd_collate",
     "gwd_anchor_depth_forward", "gwd_anchor_depth_backward", "gwd_mha_flash_forward", "gwd_mha_flash_backward",
-    "gwd_ref_scores_forward", "gwd_ref_scores_backward", "gwd_ref_mix_forward", "gwd_ref_mix_backward", "gwd_unpad_add_batch",
+    "gwd_ref_scores_forward", "gwd_ref_scores_backward", "gwd_ref_mix_forward", "gwd_ref_mix_backward", "gwd_unpad_add_batch", "gwd_stem_pack", "gwd_stem_forward",
 ]
 
 
@@ -62,6 +62,12 @@ class UnpadJob(ctypes.Structure):
 
 
 UNPAD_BATCH = 24
+STEM_PACKED_ELEMS = 14 * 2 * 64 * 8
+
+
+def stem_out(n):
+    """Output size of conv 7/2/3 followed by max-pool 3/2/1 along one axis."""
+    return ((n - 1) // 2 + 1 - 1) // 2 + 1
 
 
 class ColsumJob(ctypes.Structure):
@@ -155,6 +161,8 @@ class HipLibrary:
         L.gwd_layernorm_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
         L.gwd_layernorm_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
         L.gwd_unpad_add_batch.argtypes = [ctypes.POINTER(UnpadJob), i32, vp]
+        L.gwd_stem_pack.argtypes = [vp, vp, vp, vp]
+        L.gwd_stem_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
         L.gwd_softmax_forward.argtypes = [vp, vp, i64, i32, i32, vp]
         L.gwd_softmax_backward.argtypes = [vp, vp, vp, i64, i32, i32, vp]
         L.gwd_silog_sums.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -297,6 +305,21 @@ class HipLibrary:
         self._check(self.lib.gwd_layernorm_backward(_ptr(gy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd),
                                                     _ptr(gx), _ptr(dgamma), _ptr(dbeta), rows, C, ld, int(gelu),
                                                     dtype_code(x), self._stream(gy, x, gx)), "gwd_layernorm_backward")
+
+    def stem_pack(self, w, scale, packed):
+        """w fp32 (64,7,7,3) [* scale (64)] -> packed bf16 (STEM_PACKED_ELEMS,) in gwd_stem_forward's operand order."""
+        if tuple(w.shape) != (64, 7, 7, 3) or w.dtype != torch.float32 or packed.numel() != STEM_PACKED_ELEMS or packed.dtype != torch.bfloat16:
+            raise ValueError("stem_pack: w fp32 (64,7,7,3) and a bf16 buffer of %d values expected" % STEM_PACKED_ELEMS)
+        self._check(self.lib.gwd_stem_pack(_ptr(w), _ptr(scale), _ptr(packed), self._stream(w, packed)), "gwd_stem_pack")
+
+    def stem_forward(self, x, packed, shift, y):
+        """conv 7x7 s2 p3 (3 -> 64) + shift + ReLU + max-pool 3x3 s2 p1: x bf16 (B,H,W,3) -> y bf16 (B,Hp,Wp,64)."""
+        B, H, W, C = x.shape
+        Hp, Wp = stem_out(H), stem_out(W)
+        if C != 3 or tuple(y.shape) != (B, Hp, Wp, 64) or not x.is_contiguous() or not y.is_contiguous():
+            raise ValueError("stem_forward: x (B,H,W,3) and y (B,%d,%d,64) contiguous expected" % (Hp, Wp))
+        self._check(self.lib.gwd_stem_forward(_ptr(x), _ptr(packed), _ptr(shift), _ptr(y), B, H, W, dtype_code(x), self._stream(x, packed, y)),
+                    "gwd_stem_forward")
 
     def unpad_add_batch(self, jobs):
         """jobs: tuples (src, dst, N, taps, G, Cg, Cgp): dst (N, taps, G*Cg) += src (.., taps, G*Cgp), fp32; one launch per

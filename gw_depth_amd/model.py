@@ -123,8 +123,12 @@ class ResNetBody(nn.Module):
 
     def forward(self, x):
         s, b = self.bn1.folded()
-        x = ops.conv2d(x, self.conv1.weight, stride=2, pad=3, row_scale=s, shift=b, act=ACT_RELU)
-        x = to_pixel_major(F.max_pool2d(to_nchw(x), 3, 2, 1))
+        if x.is_cuda and x.dtype == torch.bfloat16 and not (self.conv1.weight.requires_grad and torch.is_grad_enabled()) \
+                and not x.requires_grad and os.environ.get("GWD_FUSED_STEM", "1") != "0":
+            x = ops.stem(x, self.conv1.weight, s, b)             # conv1 + bn1 + relu + maxpool, one forward-only kernel
+        else:
+            x = ops.conv2d(x, self.conv1.weight, stride=2, pad=3, row_scale=s, shift=b, act=ACT_RELU)
+            x = to_pixel_major(F.max_pool2d(to_nchw(x), 3, 2, 1))
         feats = []
         for li in range(1, 5):
             x = getattr(self, f"layer{li}")(x)

@@ -242,6 +242,26 @@ def _weight_transposed(w, row_scale, dtype):
     return out
 
 
+_STEM_PACKED = {}
+
+
+def stem(x, w, scale, shift):
+    """ResNet stem (conv 7x7 s2 p3, 3 -> 64, folded FrozenBN, ReLU, max-pool 3x3 s2 p1) as ONE forward-only kernel
+    (gwd_stem_forward); x bf16 (B,H,W,3) -> (B,Hp,Wp,64).  The stem is frozen on this path (backbone.py:62-64): no gradient.
+    The operand-order copy of the weights is rebuilt when the weight or the scale changes (load_state_dict)."""
+    lib = _lib()
+    key = (w.data_ptr(), w._version, scale.data_ptr(), scale._version, str(w.device))
+    ent = _STEM_PACKED.get(w.data_ptr())
+    if ent is None or ent[0] != key:
+        packed = torch.empty(hip.STEM_PACKED_ELEMS, dtype=torch.bfloat16, device=w.device)
+        lib.stem_pack(w.detach(), scale.detach().float().contiguous(), packed)
+        ent = _STEM_PACKED[w.data_ptr()] = (key, packed)
+    B, H, W, _ = x.shape
+    y = torch.empty((B, hip.stem_out(H), hip.stem_out(W), 64), dtype=x.dtype, device=x.device)
+    lib.stem_forward(x.detach().contiguous(), ent[1], shift.detach().float().contiguous(), y)
+    return y
+
+
 def padded_weight(w, geom, kind, dtype):
     """Zero-padded kernel-side copy of w (N, KH, KW, C), geom = (Np, Cg, Cgp): rows N -> Np and each of the G = C / Cg groups of
     input channels Cg -> Cgp.  kind 'fwd': (Np, KH, KW, G*Cgp); 't' (data gradient): (G*Cgp, KH, KW, Np)."""

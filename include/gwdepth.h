@@ -273,6 +273,16 @@ typedef struct gwd_prep_job {
 } gwd_prep_job;
 int gwd_weight_prep_batch(const gwd_prep_job *jobs, int32_t n_jobs, int32_t total_blocks, void *stream);
 
+/* The ResNet stem in one forward-only kernel: conv 7x7 / stride 2 / pad 3 (3 -> 64 channels) + folded FrozenBatchNorm + ReLU +
+ * max-pool 3x3 / stride 2 / pad 1 - conv1 / bn1 / relu / maxpool of torchvision's resnet50 as src/models/backbone.py:65-92 runs
+ * them (frozen there: backbone.py:62-64).  x bf16 [B][H][W][3] -> y bf16 [B][Hp][Wp][64], Hc = (H-1)/2+1, Hp = (Hc-1)/2+1 (W alike).
+ * `packed` = the weights as gwd_stem_pack leaves them (w fp32 [64][7][7][3], times scale[64] when given: the BN scale), i.e.
+ * GWD_STEM_PACKED_ELEMS bf16 values in the kernel's operand order; shift fp32 [64] (BN shift) or NULL.  dtype: GWD_BF16 only (-2). */
+#define GWD_STEM_PACKED_ELEMS (14 * 2 * 64 * 8)
+int gwd_stem_pack(const float *w, const float *scale, void *packed, void *stream);
+int gwd_stem_forward(const void *x, const void *packed, const float *shift, void *y, int32_t B, int32_t H, int32_t W, int32_t dtype,
+                     void *stream);
+
 /* The other half of the zero-padded copies: a layer that ran on padded channel counts (its activations keep the padded width, so every
  * conv / Linear on them takes the LDS-DMA route; the 30 / 60 / 300-channel pyramid of src/models/points/points_sample.py:45-125
  * is the user) gets its weight gradient in the padded shape; this folds it back: dst (N, taps, G*Cg) += src (.., taps, G*Cgp)

@@ -308,6 +308,25 @@ class FakeDevice:
         mean.copy_(mu)
         rstd.copy_(rs)
 
+    def stem_pack(self, w, scale, packed):
+        ws = w * scale.view(64, 1, 1, 1) if scale is not None else w
+        i = torch.arange(14 * 2 * 64 * 8)
+        j, lane, mt, s = i & 7, (i >> 3) & 63, (i >> 9) & 1, i >> 10
+        co, kh, kw, c = 32 * mt + (lane & 31), s >> 1, 4 * (s & 1) + 2 * (lane >> 5) + (j >> 2), j & 3
+        ok = (kw < 7) & (c < 3)
+        v = ws[co, kh, kw.clamp(max=6), c.clamp(max=2)]
+        packed.copy_(torch.where(ok, v, torch.zeros_like(v)).to(packed.dtype))
+        self._stem_weights = getattr(self, "_stem_weights", {})
+        self._stem_weights[packed.data_ptr()] = ws.to(torch.bfloat16).float()
+
+    def stem_forward(self, x, packed, shift, y):
+        w = self._stem_weights[packed.data_ptr()]                       # (64,7,7,3), bf16-rounded like the kernel's operands
+        v = F.conv2d(x.float().permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), None, stride=2, padding=3)
+        if shift is not None:
+            v = v + shift.view(1, -1, 1, 1)
+        v = F.max_pool2d(F.relu(v), 3, 2, 1)
+        y.copy_(v.permute(0, 2, 3, 1))
+
     def unpad_add_batch(self, jobs):
         for src, dst, N, taps, G, Cg, Cgp in jobs:
             dst.view(N, taps, G, Cg).add_(src.view(-1, taps, G, Cgp)[:N, :, :, :Cg])

@@ -873,3 +873,26 @@ def test_padded_conv_equals_the_plain_conv(dev, spec):
     gxp = xp.grad.view(B, H, W, G, Cgp)
     assert float(gxp[..., Cg:].abs().max()) == 0.0 and rel(gxp[..., :Cg].reshape(B, H, W, Ci), gx0) < 2e-3
     assert w.grad.shape == gw0.shape and rel(w.grad, gw0) < 2e-3
+
+
+@pytest.mark.parametrize("shape", [(2, 96, 128), (1, 97, 131), (3, 50, 33), (8, 480, 640), (1, 7, 9)])
+def test_fused_stem_equals_conv_bn_relu_maxpool(dev, shape):
+    """gwd_stem_forward (conv 7x7 s2 p3 + folded BN + ReLU + max-pool 3x3 s2 p1 in one kernel) against the same chain in torch on
+    the same bf16-rounded operands; ragged sizes exercise the conv and the pool padding on every border."""
+    B, H, W = shape
+    fake = FakeDevice()
+    torch.manual_seed(7)
+    w = torch.randn(64, 7, 7, 3) * 0.1
+    scale, shift = torch.rand(64) + 0.5, torch.randn(64) * 0.2
+    x = torch.randn(B, H, W, 3).bfloat16()
+    Hp, Wp = hip.stem_out(H), hip.stem_out(W)
+    pk_r, y_r = torch.empty(hip.STEM_PACKED_ELEMS, dtype=torch.bfloat16), torch.empty(B, Hp, Wp, 64, dtype=torch.bfloat16)
+    fake.stem_pack(w, scale, pk_r)
+    fake.stem_forward(x, pk_r, shift, y_r)
+    pk, y = torch.empty(hip.STEM_PACKED_ELEMS, dtype=torch.bfloat16, device="cuda"), torch.full((B, Hp, Wp, 64), -1.0, dtype=torch.bfloat16, device="cuda")
+    dev.stem_pack(w.cuda(), scale.cuda(), pk)
+    dev.stem_forward(x.cuda(), pk, shift.cuda(), y)
+    torch.cuda.synchronize()
+    assert torch.equal(pk.cpu(), pk_r)
+    assert float(y.min()) >= 0.0 and rel(y, y_r) < 5e-3
+    assert float((y.float().cpu() - y_r.float()).abs().max()) < 0.05 * float(y_r.float().abs().max())
