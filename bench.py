@@ -281,34 +281,38 @@ def main():
 
 
 def in_step_kernel_time(step, batch, gflop, peak):
-    """Average duration of the dominant kernel's launches inside ONE train step, from the profiler's device trace.  The tracer does
-    not see the kernels of a HIP-graph replay, so the step is run once eagerly on the graph stream (same kernels, same order, same
-    operands; rocprofv3 on the replayed graph gives the same figure: profiles/r02_one_step_by_category.txt)."""
-    from torch.profiler import ProfilerActivity, profile
-    key = "igemm_dma_kernel<256, 160, 8, 1, 3, 0"
+    """Duration of the dominant kernel's launches inside ONE train step: the step runs once eagerly on the graph stream (same kernels,
+    same order, same operands as the replayed graph) with a HIP event pair around every conv launch of exactly the dominant shape
+    (3x3, 160 -> 160 channels at 8 x 120 x 160: 10 forward + 10 data-gradient launches).  Matching by kernel NAME would average over
+    other layers that run the same template (the 800 -> 320 layer takes 7x longer) - tools/instep_time.py is the stand-alone version."""
+    from gw_depth_amd import hip
+    lib = hip.library()
+    orig = lib.conv_forward
+    rec = []
 
-    def durations(fn):
+    def spy(x, w, y, dims, **kw):
+        hit = tuple(dims) == (8, 120, 160, 160, 120, 160, 160, 3, 3)
+        if hit:
+            a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(torch.cuda.current_stream())
+        orig(x, w, y, dims, **kw)
+        if hit:
+            e.record(torch.cuda.current_stream())
+            rec.append((a, e))
+
+    lib.conv_forward = spy
+    try:
+        if step.use_graph:
+            step._on_graph_stream(batch, None)
+        else:
+            step.forward_backward(batch)
         torch.cuda.synchronize()
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-            fn()
-            torch.cuda.synchronize()
-        d = []
-        try:                                            # kineto's own records: kernel name + duration in ns
-            for ev in prof.profiler.kineto_results.events():
-                if key in ev.name().replace("(anonymous namespace)::", ""):
-                    d.append(ev.duration_ns() / 1e3)
-        except Exception:
-            d = []
-        if not d:
-            for e in prof.events():
-                if key in e.name.replace("(anonymous namespace)::", ""):
-                    d.append(getattr(e, "device_time_total", 0) or getattr(e, "cuda_time_total", 0) or getattr(e, "self_device_time_total", 0))
-        return [v for v in d if 0 < v < 400.0]           # the 160 -> 160 launches (the 800 -> 320 layer runs the same template 6x longer)
-
-    d = durations(lambda: step._on_graph_stream(batch, None) if step.use_graph else step.forward_backward(batch))
+    finally:
+        del lib.conv_forward                               # back to the class's method
+    d = [a.elapsed_time(e) for a, e in rec]
     if not d:
-        return {"in_step_error": "kernel not found in the trace"}
-    ms = sum(d) / len(d) / 1e3
+        return {"in_step_error": "no launch of the dominant shape in the step"}
+    ms = sum(d) / len(d)
     ach = gflop / ms                                   # GFLOP per ms = TFLOP/s
     return {"in_step_launch_ms": round(ms, 4), "in_step_launches": len(d), "in_step_achieved": round(ach, 2), "in_step_frac": round(ach / peak, 4)}
 
