@@ -136,6 +136,19 @@ extern "C" int gwd_silog_sums(const void *pred, const float *gt, double *sums, i
     return 0;
 }
 
+// loss = scale * sqrt(E[d^2] - lambda E[d]^2) from the three sums, in f64 as the torch expression it replaces (eight scalar launches)
+__global__ void silog_finalize_kernel(const double *__restrict__ sums, double lambda, double scale, float *__restrict__ loss) {
+    const double n = sums[2], mean = sums[0] / n;
+    *loss = (float)(sqrt(sums[1] / n - lambda * mean * mean) * scale);
+}
+
+extern "C" int gwd_silog_finalize(const double *sums, float lambda, float scale, float *loss, void *stream) {
+    if (!sums || !loss) return -1;
+    silog_finalize_kernel<<<1, 1, 0, (hipStream_t)stream>>>(sums, (double)lambda, (double)scale, loss);
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int gwd_silog_backward(const void *pred, const float *gt, const double *sums, const float *gloss,
                                   float loss_weight, float lambda, void *gpred, int32_t B, int32_t h, int32_t w,
                                   int32_t H, int32_t W, int32_t log_depth_error, int32_t dtype, void *stream) {

@@ -592,7 +592,8 @@ __global__ void act_bwd_vec_kernel(const T *__restrict__ gy, const T *__restrict
 // of gx (= dBias of the layer) accumulated in registers, reduced through LDS, one atomic per channel per workgroup.
 template <typename T>
 __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const T *__restrict__ gy, const T *__restrict__ ref, T *__restrict__ gx,
-                                                             float *__restrict__ dbias, int64_t rows, int C, int act, float act_scale) {
+                                                             float *__restrict__ dbias, int64_t rows, int C, int act, float act_scale,
+                                                             const T *__restrict__ mult) {
     constexpr int VEC = VecOf<T>::N;
     __shared__ float red[256 * VEC];
     const int vpr = C / VEC, rpb = 256 / vpr;
@@ -606,12 +607,16 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const T *__restrict
             const uint4 rg = *(const uint4 *)(gy + o);
             uint4 rr = make_uint4(0u, 0u, 0u, 0u);
             if (ref) rr = *(const uint4 *)(ref + o);
+            uint4 rm = make_uint4(0u, 0u, 0u, 0u);
+            if (mult) rm = *(const uint4 *)(mult + o);
             const T *pg = (const T *)&rg;
             const T *pr = (const T *)&rr;
+            const T *pm = (const T *)&rm;
             alignas(16) T outv[VEC];
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 float g = to_f32(pg[e]);
+                if (mult) g = to_f32(from_f32<T>(g * to_f32(pm[e])));      // rounded as the separate multiply it replaces
                 const float rv = to_f32(pr[e]);
                 switch (act) {
                     case GWD_ACT_RELU: g = rv > 0.f ? g : 0.f; break;
@@ -880,7 +885,7 @@ extern "C" int gwd_colsum_batch(const gwd_colsum_job *jobs, int32_t n_jobs, int3
 }
 
 extern "C" int gwd_act_backward_colsum(const void *gy, const void *ref, void *gx, float *dbias, int64_t rows, int32_t C,
-                                       int32_t act, float act_scale, int32_t dtype, void *stream) {
+                                       int32_t act, float act_scale, const void *mult, int32_t dtype, void *stream) {
     if (!gy || !gx || !dbias || rows < 0 || C <= 0) return -1;
     if (act != GWD_ACT_NONE && !ref) return -1;
     if (rows == 0) return 0;
@@ -892,9 +897,9 @@ extern "C" int gwd_act_backward_colsum(const void *gy, const void *ref, void *gx
     int64_t nb = (rows + (int64_t)rpb * 8 - 1) / ((int64_t)rpb * 8);
     const int grid = (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
     if (dtype == GWD_BF16)
-        act_bwd_colsum_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)gy, (const __bf16 *)ref, (__bf16 *)gx, dbias, rows, C, act, act_scale);
+        act_bwd_colsum_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)gy, (const __bf16 *)ref, (__bf16 *)gx, dbias, rows, C, act, act_scale, (const __bf16 *)mult);
     else
-        act_bwd_colsum_kernel<float><<<grid, 256, 0, s>>>((const float *)gy, (const float *)ref, (float *)gx, dbias, rows, C, act, act_scale);
+        act_bwd_colsum_kernel<float><<<grid, 256, 0, s>>>((const float *)gy, (const float *)ref, (float *)gx, dbias, rows, C, act, act_scale, (const float *)mult);
     GWD_CHECK_LAUNCH();
     return 0;
 }

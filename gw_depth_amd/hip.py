@@ -31,7 +31,7 @@ ENTRY_POINTS = [
     "gwd_softmax_masked_forward", "gwd_softmax_scaled_backward", "gwd_query_workspace", "gwd_eval_accumulate", "gwd_colsum_batch", "gwd_conv_wgrad_batch",
     "gwd_plane_loss_forward", "gwd_plane_loss_backward", "gwd_collate",
     "gwd_anchor_depth_forward", "gwd_anchor_depth_backward", "gwd_mha_flash_forward", "gwd_mha_flash_backward",
-    "gwd_ref_scores_forward", "gwd_ref_scores_backward", "gwd_ref_mix_forward", "gwd_ref_mix_backward", "gwd_unpad_add_batch", "gwd_stem_pack", "gwd_stem_forward",
+    "gwd_ref_scores_forward", "gwd_ref_scores_backward", "gwd_ref_mix_forward", "gwd_ref_mix_backward", "gwd_unpad_add_batch", "gwd_stem_pack", "gwd_stem_forward", "gwd_pos_sine", "gwd_silog_finalize",
 ]
 
 
@@ -161,6 +161,8 @@ class HipLibrary:
         L.gwd_layernorm_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
         L.gwd_layernorm_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
         L.gwd_unpad_add_batch.argtypes = [ctypes.POINTER(UnpadJob), i32, vp]
+        L.gwd_silog_finalize.argtypes = [vp, f32, f32, vp, vp]
+        L.gwd_pos_sine.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_stem_pack.argtypes = [vp, vp, vp, vp]
         L.gwd_stem_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
         L.gwd_softmax_forward.argtypes = [vp, vp, i64, i32, i32, vp]
@@ -192,7 +194,7 @@ class HipLibrary:
         L.gwd_softmax_masked_forward.argtypes = [vp, vp, vp, i64, i32, i64, ctypes.c_float, i32, vp]
         L.gwd_softmax_scaled_backward.argtypes = [vp, vp, vp, i64, i32, ctypes.c_float, i32, vp]
         L.gwd_resample_backward_sep.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
-        L.gwd_act_backward_colsum.argtypes = [vp, vp, vp, vp, i64, i32, i32, ctypes.c_float, i32, vp]
+        L.gwd_act_backward_colsum.argtypes = [vp, vp, vp, vp, i64, i32, i32, ctypes.c_float, vp, i32, vp]
         L.gwd_point_sample_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_point_sample_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_weight_prep_batch.argtypes = [vp, i32, i32, vp]
@@ -268,9 +270,10 @@ class HipLibrary:
         self._check(self.lib.gwd_act_backward(_ptr(gy), _ptr(ref), _ptr(gx), _ptr(scale), rows, C, act, act_scale,
                                               dtype_code(gy), self._stream(gy, ref, gx)), "gwd_act_backward")
 
-    def act_backward_colsum(self, gy, ref, gx, dbias, rows, C, act, act_scale):
-        """Fused activation backward + bias gradient; False when the shape is not supported (use the two separate calls)."""
-        rc = self.lib.gwd_act_backward_colsum(_ptr(gy), _ptr(ref), _ptr(gx), _ptr(dbias), rows, C, act, act_scale,
+    def act_backward_colsum(self, gy, ref, gx, dbias, rows, C, act, act_scale, mult=None):
+        """Fused activation backward + bias gradient (gy first multiplied by `mult` when given); False when the shape is not
+        supported (use the separate calls)."""
+        rc = self.lib.gwd_act_backward_colsum(_ptr(gy), _ptr(ref), _ptr(gx), _ptr(dbias), rows, C, act, act_scale, _ptr(mult),
                                               dtype_code(gy), self._stream(gy, ref, gx))
         if rc == -4:
             return False
@@ -305,6 +308,24 @@ class HipLibrary:
         self._check(self.lib.gwd_layernorm_backward(_ptr(gy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd),
                                                     _ptr(gx), _ptr(dgamma), _ptr(dbeta), rows, C, ld, int(gelu),
                                                     dtype_code(x), self._stream(gy, x, gx)), "gwd_layernorm_backward")
+
+    def pos_counts(self, mask_full, mask_level, counts):
+        """mask_full (B,H,W) bool/u8 -> mask_level (B,h,w) bool (nearest), counts (B,h,w,2) int16 (gwd_pos_sine, first stage)."""
+        B, H, W = mask_full.shape
+        _, h, w = mask_level.shape
+        if tuple(counts.shape) != (B, h, w, 2) or counts.dtype != torch.int16 or mask_full.element_size() != 1 or mask_level.element_size() != 1:
+            raise ValueError("pos_counts: byte masks and int16 counts (B,h,w,2) expected")
+        self._check(self.lib.gwd_pos_sine(_ptr(mask_full), _ptr(mask_level), _ptr(counts), None, None, B, H, W, h, w, 0, 0,
+                                          self._stream(mask_full, mask_level, counts)), "gwd_pos_sine")
+
+    def pos_emit(self, counts, dim_t, out, normalize):
+        """counts (B,h,w,2) int16 + dim_t (F) fp32 -> out (B,h,w,2F) fp32 (gwd_pos_sine, second stage)."""
+        B, h, w, _ = counts.shape
+        F = dim_t.numel()
+        if tuple(out.shape) != (B, h, w, 2 * F) or out.dtype != torch.float32 or dim_t.dtype != torch.float32:
+            raise ValueError("pos_emit: out fp32 (B,h,w,2F) expected")
+        self._check(self.lib.gwd_pos_sine(None, None, _ptr(counts), _ptr(dim_t), _ptr(out), B, 0, 0, h, w, F, int(bool(normalize)),
+                                          self._stream(counts, dim_t, out)), "gwd_pos_sine")
 
     def stem_pack(self, w, scale, packed):
         """w fp32 (64,7,7,3) [* scale (64)] -> packed bf16 (STEM_PACKED_ELEMS,) in gwd_stem_forward's operand order."""
@@ -422,6 +443,9 @@ class HipLibrary:
     def silog_sums(self, pred, gt, sums, B, h, w, H, W, log_err):
         self._check(self.lib.gwd_silog_sums(_ptr(pred), _ptr(gt), _ptr(sums), B, h, w, H, W, int(log_err),
                                             dtype_code(pred), self._stream(pred, gt, sums)), "gwd_silog_sums")
+
+    def silog_finalize(self, sums, lam, scale, loss):
+        self._check(self.lib.gwd_silog_finalize(_ptr(sums), lam, scale, _ptr(loss), self._stream(sums, loss)), "gwd_silog_finalize")
 
     def silog_backward(self, pred, gt, sums, gloss, weight, lam, gpred, B, h, w, H, W, log_err):
         self._check(self.lib.gwd_silog_backward(_ptr(pred), _ptr(gt), _ptr(sums), _ptr(gloss), weight, lam, _ptr(gpred),

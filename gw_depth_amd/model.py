@@ -64,6 +64,8 @@ def to_pixel_major(x):
 
 def pos_sine(mask, num_pos_feats, normalize):
     """PositionEmbeddingSine (/root/reference/src/models/position_encoding.py:28-48) -> (B,h,w,2F) fp32."""
+    if hasattr(mask, "_gwd_counts"):                      # level mask from ops.mask_levels: one kernel (csrc/posenc.hip)
+        return ops.pos_sine(mask, num_pos_feats, normalize)
     not_mask = ~mask
     y = not_mask.cumsum(1, dtype=torch.float32)
     x = not_mask.cumsum(2, dtype=torch.float32)
@@ -165,7 +167,10 @@ class Joiner(nn.Module):
 
     def forward(self, images_pm, pad_mask):
         feats = self._modules["0"].body(images_pm)
-        masks = [F.interpolate(pad_mask[None].float(), size=f.shape[1:3]).to(torch.bool)[0] for f in feats]
+        if pad_mask.is_cuda and os.environ.get("GWD_FUSED_POS", "1") != "0":
+            masks = ops.mask_levels(pad_mask, [tuple(f.shape[1:3]) for f in feats])      # + the counts pos_sine() builds on
+        else:
+            masks = [F.interpolate(pad_mask[None].float(), size=f.shape[1:3]).to(torch.bool)[0] for f in feats]
         return feats, masks
 
 
@@ -435,14 +440,14 @@ class WindowAttention(WindowAttnBase):
         B_, N, C = xw.shape
         hd = C // HEADS
         qkv = self.qkv(xw).view(B_, N, 3, HEADS, hd)
-        rqk = self.ref_qk(x_ref)
-        rB = rqk.shape[0]
-        ref_k = ops.row_affine(rqk[..., :C], self.diff_mu, self.diff_logsigma)      # mu + exp(logsigma) * x, (rB, nrf, C), :289-292
+        rq, rv = self.ref_qk(x_ref).split(C, dim=-1)       # split, not two slices: its backward is ONE cat (two slices = 2 fills + 2 copies + 1 add)
+        rB = rq.shape[0]
+        ref_k = ops.row_affine(rq, self.diff_mu, self.diff_logsigma)              # mu + exp(logsigma) * x, (rB, nrf, C), :289-292
         ra = ops.ref_scores(qkv, ref_k, rB, self.scale)                          # (rB, nWin*N, nrf, heads): pixel-major map, :295-298
         for _ in range(3):                                                        # :299-302
             upd = ops.conv2d(ra, self.ref_attn_diffusion.weight, self.ref_attn_diffusion.bias, pad=1)
             ra = ops.inorm_gelu_residual(ra, upd, 1e-5)
-        q_new = ops.ref_mix(ra, rqk[..., C:], HEADS).view(B_, N, HEADS, hd)      # softmax over the ref tokens, . ref_v; second *scale: in-kernel
+        q_new = ops.ref_mix(ra, rv, HEADS).view(B_, N, HEADS, hd)      # softmax over the ref tokens, . ref_v; second *scale: in-kernel
         wpi = regions.shape[0] if regions is not None else 1
         x = ops.window_attention_qkv(q_new, qkv, self.relative_position_bias_table, self.rel_index(), regions, wpi, self.scale)
         return self.proj(x)
@@ -665,7 +670,7 @@ class PointBasedPred(nn.Module):
     def forward(self, x, dtok, pre_depth, coords, H, W, pos):
         B = x.shape[0]
         xg_xr = self.refer_proj(self.pre_proj(torch.cat([x, dtok], dim=-1)))
-        xg, xr = xg_xr[..., : self.dim], xg_xr[..., self.dim:]
+        xg, xr = xg_xr.split(self.dim, dim=-1)
         refer = ops.point_sample(xr.reshape(B, H, W, self.dim), coords) + ops.point_sample(pos, coords)   # (B, S, dim) fp32
         hp, wp = pre_depth.shape[-2:]
         anchor = ops.point_sample(pre_depth.float().reshape(B, hp, wp, 1), coords)       # (B, S, 1)

@@ -242,6 +242,40 @@ def _weight_transposed(w, row_scale, dtype):
     return out
 
 
+_DIM_T = {}
+
+
+def mask_levels(pad_mask, sizes):
+    """Padding masks of the feature levels (F.interpolate(mask[None].float(), size).to(bool), backbone.py:81-88) with the cumulative
+    counts of their un-masked pixels attached (`_gwd_counts`, what pos_sine needs): one launch per level."""
+    lib = _lib()
+    B = pad_mask.shape[0]
+    full = pad_mask.contiguous().view(torch.uint8) if pad_mask.dtype == torch.bool else pad_mask.contiguous()
+    out = []
+    for h, w in sizes:
+        lvl = torch.empty((B, h, w), dtype=torch.uint8, device=pad_mask.device)
+        counts = torch.empty((B, h, w, 2), dtype=torch.int16, device=pad_mask.device)
+        lib.pos_counts(full, lvl, counts)
+        m = lvl.view(torch.bool)
+        m._gwd_counts = counts
+        out.append(m)
+    return out
+
+
+def pos_sine(mask, num_pos_feats, normalize, temperature=10000.0):
+    """PositionEmbeddingSine (position_encoding.py:28-48) of a level mask from mask_levels(): (B,h,w,2F) fp32, one launch."""
+    counts = mask._gwd_counts
+    key = (num_pos_feats, float(temperature), str(mask.device))
+    dim_t = _DIM_T.get(key)
+    if dim_t is None:
+        t = torch.arange(num_pos_feats, dtype=torch.float32, device=mask.device)
+        dim_t = _DIM_T[key] = temperature ** (2 * torch.div(t, 2, rounding_mode="floor") / num_pos_feats)
+    B, h, w, _ = counts.shape
+    out = torch.empty((B, h, w, 2 * num_pos_feats), dtype=torch.float32, device=mask.device)
+    _lib().pos_emit(counts, dim_t, out, normalize)
+    return out
+
+
 _STEM_PACKED = {}
 
 
@@ -393,22 +427,33 @@ class _ConvFn(torch.autograd.Function):
         B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW = dims
         gy = gy.contiguous()
         g_skip = gy                                    # the post-dropout skip connection gets the incoming gradient as is
-        if mult is not None:
-            gy = gy * mult
         rows = B * Ho * Wo
         w_sink, b_sink = ctx.sinks if ctx.sinks is not None else (None, None)
         bias_done = False
-        if act != ACT_NONE or act_scale != 1.0:
+        dv = None
+        if mult is not None and has_bias and ctx.needs_input_grad[2] and b_sink is not None:
+            # dropout multiplier, activation backward and the bias gradient in ONE pass (was: an ATen multiply, then the rest)
             dv = torch.empty_like(gy)
-            if has_bias and ctx.needs_input_grad[2] and b_sink is not None:
-                # activation backward and the bias gradient (column sums of dv) in one pass, straight into the flat gradient
-                bias_done = lib.act_backward_colsum(gy, ref, dv, b_sink[0], rows, Cout, act, act_scale)
-                if bias_done and b_sink[1] is not None:
+            bias_done = lib.act_backward_colsum(gy, ref, dv, b_sink[0], rows, Cout, act, act_scale, mult=mult)
+            if bias_done:
+                if b_sink[1] is not None:
                     b_sink[1]()
-            if not bias_done:
-                lib.act_backward(gy, ref, dv, None, rows, Cout, act, act_scale)
-        else:
-            dv = gy
+            else:
+                dv = None
+        if dv is None:
+            if mult is not None:
+                gy = gy * mult
+            if act != ACT_NONE or act_scale != 1.0:
+                dv = torch.empty_like(gy)
+                if has_bias and ctx.needs_input_grad[2] and b_sink is not None:
+                    # activation backward and the bias gradient (column sums of dv) in one pass, straight into the flat gradient
+                    bias_done = lib.act_backward_colsum(gy, ref, dv, b_sink[0], rows, Cout, act, act_scale)
+                    if bias_done and b_sink[1] is not None:
+                        b_sink[1]()
+                if not bias_done:
+                    lib.act_backward(gy, ref, dv, None, rows, Cout, act, act_scale)
+            else:
+                dv = gy
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             wt = _weight_transposed(w, row_scale, x.dtype)
@@ -682,9 +727,8 @@ class _SilogFn(torch.autograd.Function):
         H, W = gt.shape[-2], gt.shape[-1]
         sums = torch.zeros(3, dtype=torch.float64, device=pred.device)
         lib.silog_sums(pred, gt, sums, B, h, w, H, W, log_err)
-        n = sums[2]
-        mean = sums[0] / n
-        loss = (torch.sqrt(sums[1] / n - lam * mean * mean) * (10.0 * weight)).float()
+        loss = torch.empty((), dtype=torch.float32, device=pred.device)
+        lib.silog_finalize(sums, lam, 10.0 * weight, loss)       # 10 w sqrt(E[d^2] - lam E[d]^2), one launch
         ctx.save_for_backward(pred, gt, sums)
         ctx.cfg = (B, h, w, H, W, weight, lam, log_err)
         return loss

@@ -120,8 +120,10 @@ int gwd_colsum_batch(const gwd_colsum_job *jobs, int32_t n_jobs, int32_t dtype, 
 /* gwd_act_backward and gwd_colsum of its result in one pass (activation backward of a biased layer: dBias is the column
  * sum of gx).  dbias is ACCUMULATED into.  Returns -4 when C is not a multiple of 16 bytes / wider than 256 vectors:
  * the caller then uses the two separate entry points.                                                            */
+/* mult (may be NULL): [rows][C] element-wise multiplier of gy applied first (the dropout multiplier of gwd_conv_desc.mult: the
+ * layer computed act(v) * mult, so gx = act'(ref) * (gy * mult)).                                                   */
 int gwd_act_backward_colsum(const void *gy, const void *ref, void *gx, float *dbias, int64_t rows, int32_t C, int32_t act,
-                            float act_scale, int32_t dtype, void *stream);
+                            float act_scale, const void *mult, int32_t dtype, void *stream);
 
 
 /* LayerNorm over the last dim (C <= 512), eps 1e-5, optional fused exact GELU on the output.
@@ -160,6 +162,8 @@ int gwd_softmax_scaled_backward(const void *gy, const void *y, void *gx, int64_t
  * receive sum d, sum d^2, count.  log_depth_error selects d = log p - log g, else (p+log p)-(g+log g). */
 int gwd_silog_sums(const void *pred, const float *gt, double *sums, int32_t B, int32_t h, int32_t w,
                    int32_t H, int32_t W, int32_t log_depth_error, int32_t dtype, void *stream);
+/* loss (one fp32) = scale * sqrt(sums[1]/n - lambda (sums[0]/n)^2), n = sums[2]: the scalar tail of SiLog as one launch.  */
+int gwd_silog_finalize(const double *sums, float lambda, float scale, float *loss, void *stream);
 /* gpred = gloss * d loss / d pred, loss = 10*sqrt(E[d^2] - lambda*E[d]^2); reads the sums.        */
 int gwd_silog_backward(const void *pred, const float *gt, const double *sums, const float *gloss,
                        float loss_weight, float lambda, void *gpred, int32_t B, int32_t h, int32_t w,
@@ -272,6 +276,16 @@ typedef struct gwd_prep_job {
                              /* once, the launch writes the N x taps x C real entries only.  Np = 0: dense copies as above.      */
 } gwd_prep_job;
 int gwd_weight_prep_batch(const gwd_prep_job *jobs, int32_t n_jobs, int32_t total_blocks, void *stream);
+
+/* Padding mask of one feature level + sine position embeddings from it (src/models/backbone.py:81-88: F.interpolate(nearest) of the
+ * batch mask; src/models/position_encoding.py:28-48: PositionEmbeddingSine).  Two stages, either may be skipped:
+ *   mask_full != NULL: mask_level (B,h,w) u8 = nearest-resized mask_full (B,H,W) u8 (non-zero = padding), counts (B,h,w,2) int16 =
+ *                      cumulative counts of un-masked pixels along y and along x;
+ *   out != NULL:       out (B,h,w,2F) fp32 = [sin|cos interleaved of y / dim_t[c]] | [the same of x], from `counts`; normalize: counts
+ *                      scaled to 2 pi by the last row / column (eps 1e-6); dim_t (F) fp32 = temperature^(2 (c/2) / F) from the caller.
+ * One level's counts serve any number of embeddings (the reference builds several widths from one mask).                          */
+int gwd_pos_sine(const uint8_t *mask_full, uint8_t *mask_level, int16_t *counts, const float *dim_t, float *out, int32_t B, int32_t H,
+                 int32_t W, int32_t h, int32_t w, int32_t F, int32_t normalize, void *stream);
 
 /* The ResNet stem in one forward-only kernel: conv 7x7 / stride 2 / pad 3 (3 -> 64 channels) + folded FrozenBatchNorm + ReLU +
  * max-pool 3x3 / stride 2 / pad 1 - conv1 / bn1 / relu / maxpool of torchvision's resnet50 as src/models/backbone.py:65-92 runs

@@ -5,6 +5,8 @@ that the host logic of the product (module wiring, layouts, autograd plumbing, s
 flat optimizer buffers, DDP bucket plan) can be checked against the oracle without a GPU.  The
 numerical behaviour of the real kernels is checked on the GPU box by the `-m gpu` tests.
 """
+import math
+
 import torch
 import torch.nn.functional as F
 
@@ -308,6 +310,23 @@ class FakeDevice:
         mean.copy_(mu)
         rstd.copy_(rs)
 
+    def pos_counts(self, mask_full, mask_level, counts):
+        h, w = mask_level.shape[1:]
+        m = F.interpolate(mask_full.bool()[None].float(), size=(h, w)).to(torch.bool)[0]
+        mask_level.copy_(m.to(mask_level.dtype))
+        counts[..., 0] = (~m).cumsum(1).to(torch.int16)
+        counts[..., 1] = (~m).cumsum(2).to(torch.int16)
+
+    def pos_emit(self, counts, dim_t, out, normalize):
+        y, x = counts[..., 0].float(), counts[..., 1].float()
+        if normalize:
+            y = y / (y[:, -1:, :] + 1e-6) * (2 * math.pi)
+            x = x / (x[:, :, -1:] + 1e-6) * (2 * math.pi)
+        px, py = x[..., None] / dim_t, y[..., None] / dim_t
+        px = torch.stack((px[..., 0::2].sin(), px[..., 1::2].cos()), dim=4).flatten(3)
+        py = torch.stack((py[..., 0::2].sin(), py[..., 1::2].cos()), dim=4).flatten(3)
+        out.copy_(torch.cat((py, px), dim=3))
+
     def stem_pack(self, w, scale, packed):
         ws = w * scale.view(64, 1, 1, 1) if scale is not None else w
         i = torch.arange(14 * 2 * 64 * 8)
@@ -372,6 +391,11 @@ class FakeDevice:
     def silog_sums(self, pred, gt, sums, B, h, w, H, W, log_err):
         _, m, d = self._silog_terms(pred, gt, B, h, w, H, W, log_err)
         sums.add_(torch.stack([d.double().sum(), (d.double() ** 2).sum(), m.double().sum()]))
+
+    def silog_finalize(self, sums, lam, scale, loss):
+        n = sums[2]
+        mean = sums[0] / n
+        loss.copy_((torch.sqrt(sums[1] / n - lam * mean * mean) * scale).float().reshape(loss.shape))
 
     def silog_backward(self, pred, gt, sums, gloss, weight, lam, gpred, B, h, w, H, W, log_err):
         p, m, d = self._silog_terms(pred, gt, B, h, w, H, W, log_err)
@@ -567,7 +591,9 @@ class FakeDevice:
             r.backward(gout.reshape(B, S, C).permute(0, 2, 1).reshape(B, C, S, 1))
         gmap.add_(x.grad.permute(0, 2, 3, 1).reshape(gmap.shape).to(gmap.dtype))
 
-    def act_backward_colsum(self, gy, ref, gx, dbias, rows, C, act, act_scale):
+    def act_backward_colsum(self, gy, ref, gx, dbias, rows, C, act, act_scale, mult=None):
+        if mult is not None:
+            gy = (gy.float() * mult.float()).to(gy.dtype)
         self.act_backward(gy, ref, gx, None, rows, C, act, act_scale)
         dbias.add_(gx.reshape(rows, C).float().sum(0))
         return True

@@ -529,6 +529,14 @@ def test_act_backward_colsum(dev, rows, C, act, dtype):
     assert rel(gx, gx_r) < TOL[dtype] and rel(db, db_r) < TOL[dtype]
     assert dev.act_backward_colsum(gy.cuda()[:, :6].contiguous(), ref.cuda()[:, :6].contiguous(), gx[:, :6].contiguous(), db[:6].contiguous(),
                                    rows, 6, act, 1.0) is False
+    # with the dropout multiplier of the layer (gx = act'(ref) * (gy * mult)), also behind no activation at all
+    mult = ((torch.rand(rows, C, generator=torch.Generator().manual_seed(13)) > 0.1).float() / 0.9).to(dtype)
+    for a in (act, hip.ACT_NONE):
+        gx_r, db_r = torch.empty(rows, C, dtype=dtype), torch.zeros(C)
+        fake.act_backward_colsum(gy, ref, gx_r, db_r, rows, C, a, 1.0, mult=mult)
+        gx, db = torch.empty(rows, C, dtype=dtype).cuda(), torch.zeros(C).cuda()
+        assert dev.act_backward_colsum(gy.cuda(), ref.cuda(), gx, db, rows, C, a, 1.0, mult=mult.cuda())
+        assert rel(gx, gx_r) < TOL[dtype] and rel(db, db_r) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -896,3 +904,26 @@ def test_fused_stem_equals_conv_bn_relu_maxpool(dev, shape):
     assert torch.equal(pk.cpu(), pk_r)
     assert float(y.min()) >= 0.0 and rel(y, y_r) < 5e-3
     assert float((y.float().cpu() - y_r.float()).abs().max()) < 0.05 * float(y_r.float().abs().max())
+
+
+@pytest.mark.parametrize("shape", [(8, 480, 640, 120, 160, 16), (8, 480, 640, 15, 20, 128), (2, 96, 128, 3, 4, 64), (3, 100, 131, 25, 33, 32), (1, 960, 1280, 240, 320, 16)])
+@pytest.mark.parametrize("normalize", [False, True])
+def test_mask_levels_and_sine_position_embedding(dev, shape, normalize):
+    """gwd_pos_sine (level mask by nearest resize, cumulative counts, sin / cos embedding) against the torch chain of the reference
+    (backbone.py:81-88, position_encoding.py:28-48) on ragged per-image paddings."""
+    from gw_depth_amd import ops
+    from gw_depth_amd.model import pos_sine
+    import torch.nn.functional as F
+    B, H, W, h, w, npf = shape
+    pad = torch.zeros(B, H, W, dtype=torch.bool)
+    g = torch.Generator().manual_seed(B * H + w)
+    for b in range(1, B):                                         # image 0 unpadded, the others padded on the right / bottom
+        pad[b, int(H * (0.5 + 0.5 * torch.rand(1, generator=g))):, :] = True
+        pad[b, :, int(W * (0.5 + 0.5 * torch.rand(1, generator=g))):] = True
+    m_ref = F.interpolate(pad[None].float(), size=(h, w)).to(torch.bool)[0]
+    p_ref = pos_sine(m_ref, npf, normalize)                       # torch path (no counts attached)
+    (m,) = ops.mask_levels(pad.cuda(), [(h, w)])
+    p = pos_sine(m, npf, normalize)
+    torch.cuda.synchronize()
+    assert m.dtype == torch.bool and torch.equal(m.cpu(), m_ref)
+    assert p.shape == p_ref.shape and float((p.cpu() - p_ref).abs().max()) < 2e-5

@@ -19,6 +19,16 @@ batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
 batch["targets"] = [{k: v.cuda() for k, v in t.items()} for t in b["targets"]]
 st = {k: batch[k].clone() for k in ("images", "pad_mask", "depth", "seg")}
 st["packed"] = pack_targets(batch["targets"], "cuda")
+def _scoped(name, fwd):
+    def run(*a, **k):
+        with torch.profiler.record_function("M:" + name):
+            return fwd(*a, **k)
+    return run
+
+
+for owner, root in (("model", model), ("crit", crits[0])):
+    for name, m in root.named_modules():
+        m.forward = _scoped(owner + "." + name + "<" + type(m).__name__ + ">", m.forward)
 for _ in range(2):
     step._sync_free_fb(st)
 torch.cuda.synchronize()
@@ -37,12 +47,14 @@ for e in prof.events():
             break
         p = p.cpu_parent
     if who is None:
-        fr = [s for s in (e.stack or []) if "gw_depth_amd" in s]
-        who = "fwd " + (fr[0].split("gw_depth_amd/")[-1] if fr else "?")
+        p = e.cpu_parent
+        while p is not None and not p.name.startswith("M:"):
+            p = p.cpu_parent
+        who = "fwd " + (p.name[2:] if p is not None else "?")
     k = (e.name, who, str(e.input_shapes)[:70])
     agg[k][0] += e.self_device_time_total
     agg[k][1] += 1
 rows = sorted(((v[0], v[1], k) for k, v in agg.items()), reverse=True)
 print("aten device time %.2f ms, %d ops" % (sum(r[0] for r in rows) / 1e3, sum(r[1] for r in rows)))
-for t, n, (name, who, sh) in rows[:110]:
-    print("%8.1f us %4d x %-22s %-46s %s" % (t, n, name, who[:46], sh))
+for t, n, (name, who, sh) in rows:
+    print("%8.1f us %4d x %-22s %-70s %s" % (t, n, name, who[-70:], sh))
