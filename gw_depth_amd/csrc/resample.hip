@@ -135,7 +135,7 @@ __global__ void resample_nearest_bwd_vec_kernel(const T *__restrict__ gy, T *__r
 
 template <typename T, int VB>
 __global__ void resample_fwd_vec_kernel(const T *__restrict__ x, T *__restrict__ y, int B, int Hs, int Ws, int Ho, int Wo, int C,
-                                        int mode) {
+                                        int mode, int ldy) {
     constexpr int VEC = VB / (int)sizeof(T);
     typedef typename RsRaw<VB>::type Raw;
     const int CV = C / VEC;
@@ -166,7 +166,7 @@ __global__ void resample_fwd_vec_kernel(const T *__restrict__ x, T *__restrict__
             for (int e = 0; e < VEC; ++e)
                 out[e] = from_f32<T>(hy * (hx * to_f32(p00[e]) + lx * to_f32(p01[e])) + ly * (hx * to_f32(p10[e]) + lx * to_f32(p11[e])));
         }
-        *(Raw *)(y + (((size_t)b * Ho + oy) * Wo + ox) * C + cv * VEC) = *(const Raw *)out;
+        *(Raw *)(y + (((size_t)b * Ho + oy) * Wo + ox) * ldy + cv * VEC) = *(const Raw *)out;       // ldy >= C: a channel slice of a wider map
     }
 }
 
@@ -175,7 +175,7 @@ __global__ void resample_fwd_vec_kernel(const T *__restrict__ x, T *__restrict__
 // a source pixel's footprint of (2 ry + 2)(2 rx + 2) taps becomes two loops of 2 r + 2 - at the 16x pyramid branches
 // that is 1 300 taps per thread over 90 K threads versus 35 taps over 190 K wide threads.
 template <typename T, int VB>
-__global__ void resample_bwd_x_kernel(const T *__restrict__ gy, float *__restrict__ tmp, int B, int Ws, int Ho, int Wo, int C, int mode) {
+__global__ void resample_bwd_x_kernel(const T *__restrict__ gy, float *__restrict__ tmp, int B, int Ws, int Ho, int Wo, int C, int mode, int ldg) {
     constexpr int VEC = VB / (int)sizeof(T);
     typedef typename RsRaw<VB>::type Raw;
     const int CV = C / VEC;
@@ -191,14 +191,14 @@ __global__ void resample_bwd_x_kernel(const T *__restrict__ gy, float *__restric
             xlo = max(0, (int)floorf((sx - 1) / sw) - 1);
             xhi = min(Wo - 1, (int)ceilf((sx + 1) / sw) + 1);
         } else { xlo = 0; xhi = Wo - 1; }
-        const T *row = gy + (size_t)r * Wo * C + cv * VEC;
+        const T *row = gy + (size_t)r * Wo * ldg + cv * VEC;
         float acc[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
         for (int ox = xlo; ox <= xhi; ++ox) {
             const float wx = tap_weight(ox, sx, Ws, sw, mode);
             if (wx != 0.f) {
-                const Raw raw = *(const Raw *)(row + (size_t)ox * C);
+                const Raw raw = *(const Raw *)(row + (size_t)ox * ldg);
                 const T *p = (const T *)&raw;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) acc[e] += wx * to_f32(p[e]);
@@ -355,20 +355,24 @@ inline int flat_grid(int64_t total) {
     return 0;
 
 extern "C" int gwd_resample_forward(const void *x, void *y, int32_t B, int32_t Hs, int32_t Ws, int32_t Ho, int32_t Wo,
-                                    int32_t C, int32_t mode, int32_t dtype, void *stream) {
+                                    int32_t C, int32_t mode, int32_t ldy, int32_t dtype, void *stream) {
     if (!x || !y || B <= 0 || Hs <= 0 || Ws <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || mode < 0 || mode > 1) return -1;
+    if (ldy == 0) ldy = C;
+    if (ldy < C) return -1;
+    if (ldy != C && (C % 4 || ldy % 4 || (dtype == GWD_BF16 && C % 8 == 0 && ldy % 8))) return -4;     // pitched output: vector kernels only
     const int64_t total = (int64_t)B * Ho * Wo * C;
     if (dtype == GWD_BF16 && C % 4 == 0) {
-        if (C % 8 == 0) resample_fwd_vec_kernel<__bf16, 16><<<flat_grid(total / 8), 256, 0, (hipStream_t)stream>>>((const __bf16 *)x, (__bf16 *)y, B, Hs, Ws, Ho, Wo, C, mode);
-        else resample_fwd_vec_kernel<__bf16, 8><<<flat_grid(total / 4), 256, 0, (hipStream_t)stream>>>((const __bf16 *)x, (__bf16 *)y, B, Hs, Ws, Ho, Wo, C, mode);
+        if (C % 8 == 0) resample_fwd_vec_kernel<__bf16, 16><<<flat_grid(total / 8), 256, 0, (hipStream_t)stream>>>((const __bf16 *)x, (__bf16 *)y, B, Hs, Ws, Ho, Wo, C, mode, ldy);
+        else resample_fwd_vec_kernel<__bf16, 8><<<flat_grid(total / 4), 256, 0, (hipStream_t)stream>>>((const __bf16 *)x, (__bf16 *)y, B, Hs, Ws, Ho, Wo, C, mode, ldy);
         GWD_CHECK_LAUNCH();
         return 0;
     }
     if (dtype == GWD_F32 && C % 4 == 0) {
-        resample_fwd_vec_kernel<float, 16><<<flat_grid(total / 4), 256, 0, (hipStream_t)stream>>>((const float *)x, (float *)y, B, Hs, Ws, Ho, Wo, C, mode);
+        resample_fwd_vec_kernel<float, 16><<<flat_grid(total / 4), 256, 0, (hipStream_t)stream>>>((const float *)x, (float *)y, B, Hs, Ws, Ho, Wo, C, mode, ldy);
         GWD_CHECK_LAUNCH();
         return 0;
     }
+    if (ldy != C) return -4;
     if (dtype == GWD_BF16) resample_fwd_kernel<__bf16><<<flat_grid(total), 256, 0, (hipStream_t)stream>>>((const __bf16 *)x, (__bf16 *)y, B, Hs, Ws, Ho, Wo, C, mode);
     else if (dtype == GWD_F32) resample_fwd_kernel<float><<<flat_grid(total), 256, 0, (hipStream_t)stream>>>((const float *)x, (float *)y, B, Hs, Ws, Ho, Wo, C, mode);
     else return -2;
@@ -434,19 +438,21 @@ extern "C" int gwd_avgpool_backward(const void *gy, void *gx, int32_t B, int32_t
 }
 
 extern "C" int gwd_resample_backward_sep(const void *gy, float *tmp, void *gx, int32_t B, int32_t Hs, int32_t Ws, int32_t Ho,
-                                         int32_t Wo, int32_t C, int32_t mode, int32_t dtype, void *stream) {
+                                         int32_t Wo, int32_t C, int32_t mode, int32_t ldg, int32_t dtype, void *stream) {
     if (!gy || !tmp || !gx || B <= 0 || Hs <= 0 || Ws <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || mode < 0 || mode > 1) return -1;
     if (dtype != GWD_BF16 && dtype != GWD_F32) return -2;
-    if (C % 4) return -4;                                     // caller uses gwd_resample_backward
+    if (ldg == 0) ldg = C;
+    if (ldg < C) return -1;
+    if (C % 4 || ldg % 4 || (dtype == GWD_BF16 && C % 8 == 0 && ldg % 8)) return -4;       // caller uses gwd_resample_backward
     hipStream_t st = (hipStream_t)stream;
     const int vec = (dtype == GWD_BF16 && C % 8 == 0) ? 8 : 4;
     const int64_t t1 = (int64_t)B * Ho * Ws * (C / vec), t2 = (int64_t)B * Hs * Ws * (C / 4);
     if (dtype == GWD_BF16) {
-        if (vec == 8) resample_bwd_x_kernel<__bf16, 16><<<flat_grid(t1), 256, 0, st>>>((const __bf16 *)gy, tmp, B, Ws, Ho, Wo, C, mode);
-        else resample_bwd_x_kernel<__bf16, 8><<<flat_grid(t1), 256, 0, st>>>((const __bf16 *)gy, tmp, B, Ws, Ho, Wo, C, mode);
+        if (vec == 8) resample_bwd_x_kernel<__bf16, 16><<<flat_grid(t1), 256, 0, st>>>((const __bf16 *)gy, tmp, B, Ws, Ho, Wo, C, mode, ldg);
+        else resample_bwd_x_kernel<__bf16, 8><<<flat_grid(t1), 256, 0, st>>>((const __bf16 *)gy, tmp, B, Ws, Ho, Wo, C, mode, ldg);
         resample_bwd_y_kernel<__bf16><<<flat_grid(t2), 256, 0, st>>>(tmp, (__bf16 *)gx, B, Hs, Ws, Ho, C, mode);
     } else {
-        resample_bwd_x_kernel<float, 16><<<flat_grid(t1), 256, 0, st>>>((const float *)gy, tmp, B, Ws, Ho, Wo, C, mode);
+        resample_bwd_x_kernel<float, 16><<<flat_grid(t1), 256, 0, st>>>((const float *)gy, tmp, B, Ws, Ho, Wo, C, mode, ldg);
         resample_bwd_y_kernel<float><<<flat_grid(t2), 256, 0, st>>>(tmp, (float *)gx, B, Hs, Ws, Ho, C, mode);
     }
     GWD_CHECK_LAUNCH();

@@ -119,6 +119,11 @@ def dtype_code(t):
     raise TypeError("gw_depth_amd kernels take float32 or bfloat16, got %s" % t.dtype)
 
 
+def _ptr_pitched(t):
+    """Address of an operand whose pixel pitch the entry point takes separately (a channel slice of a pixel-major map)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
 def _ptr(t):
     if t is None:
         return None
@@ -171,7 +176,7 @@ class HipLibrary:
         L.gwd_silog_backward.argtypes = [vp, vp, vp, vp, f32, f32, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_seg_ce_sum.argtypes = [vp, vp, vp, i64, i32, vp]
         L.gwd_seg_ce_backward.argtypes = [vp, vp, vp, f32, vp, i64, i32, vp]
-        L.gwd_resample_forward.argtypes = [vp, vp] + [i32] * 8 + [vp]
+        L.gwd_resample_forward.argtypes = [vp, vp] + [i32] * 9 + [vp]
         L.gwd_resample_backward.argtypes = [vp, vp] + [i32] * 8 + [vp]
         L.gwd_avgpool_forward.argtypes = [vp, vp] + [i32] * 6 + [vp]
         L.gwd_avgpool_backward.argtypes = [vp, vp] + [i32] * 6 + [vp]
@@ -193,7 +198,7 @@ class HipLibrary:
         L.gwd_eval_accumulate.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp, vp, vp, vp, i32, i64, f32, f32, i32, i32, vp]
         L.gwd_softmax_masked_forward.argtypes = [vp, vp, vp, i64, i32, i64, ctypes.c_float, i32, vp]
         L.gwd_softmax_scaled_backward.argtypes = [vp, vp, vp, i64, i32, ctypes.c_float, i32, vp]
-        L.gwd_resample_backward_sep.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+        L.gwd_resample_backward_sep.argtypes = [vp, vp, vp] + [i32] * 9 + [vp]
         L.gwd_act_backward_colsum.argtypes = [vp, vp, vp, vp, i64, i32, i32, ctypes.c_float, vp, i32, vp]
         L.gwd_point_sample_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_point_sample_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -460,8 +465,17 @@ class HipLibrary:
         self._check(self.lib.gwd_seg_ce_backward(_ptr(logits), _ptr(target), _ptr(gloss), scale, _ptr(glogits), P,
                                                  dtype_code(logits), self._stream(logits, glogits)), "gwd_seg_ce_backward")
 
+    @staticmethod
+    def _pixel_pitch(t, H, W, C):
+        """Element pitch between pixels of a (B,H,W,C) tensor that may be a channel slice of a wider pixel-major map."""
+        ld = t.stride(2) if t.dim() == 4 and W > 1 else C
+        if t.dim() == 4 and (t.stride(3) != 1 or (H > 1 and t.stride(1) != W * ld) or (t.shape[0] > 1 and t.stride(0) != H * W * ld)):
+            raise ValueError("pixel-major tensor or a channel slice of one expected, got strides %r" % (t.stride(),))
+        return ld
+
     def resample_forward(self, x, y, B, Hs, Ws, Ho, Wo, C, mode):
-        self._check(self.lib.gwd_resample_forward(_ptr(x), _ptr(y), B, Hs, Ws, Ho, Wo, C, mode, dtype_code(x),
+        """y may be a channel slice of a wider (B,Ho,Wo,*) map: the result is written in place there."""
+        self._check(self.lib.gwd_resample_forward(_ptr(x), _ptr_pitched(y), B, Hs, Ws, Ho, Wo, C, mode, self._pixel_pitch(y, Ho, Wo, C), dtype_code(x),
                                                   self._stream(x, y)), "gwd_resample_forward")
 
     def resample_backward(self, gy, gx, B, Hs, Ws, Ho, Wo, C, mode):
@@ -470,8 +484,8 @@ class HipLibrary:
 
     def resample_backward_sep(self, gy, tmp, gx, B, Hs, Ws, Ho, Wo, C, mode):
         """Separable backward through the fp32 scratch `tmp` (B,Ho,Ws,C); False when C is not vector-sized."""
-        rc = self.lib.gwd_resample_backward_sep(_ptr(gy), _ptr(tmp), _ptr(gx), B, Hs, Ws, Ho, Wo, C, mode, dtype_code(gy),
-                                                self._stream(gy, gx))
+        rc = self.lib.gwd_resample_backward_sep(_ptr_pitched(gy), _ptr(tmp), _ptr(gx), B, Hs, Ws, Ho, Wo, C, mode, self._pixel_pitch(gy, Ho, Wo, C),
+                                                dtype_code(gy), self._stream(gy, gx))
         if rc == -4:
             return False
         self._check(rc, "gwd_resample_backward_sep")

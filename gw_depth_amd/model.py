@@ -625,12 +625,8 @@ class PyramidLayer(nn.Module):
         B, H, W, C = x.shape
         if H < self.pools[0] or W < self.pools[0]:
             x = F.pad(x, (0, 0, 0, max(self.pools[0] - W, 0), 0, max(self.pools[0] - H, 0)))
-        size = x.shape[1:3]
-        outs = [x]
-        for i, k in enumerate(self.pools, start=1):
-            y = getattr(self, f"branch{i}")[1](ops.avg_pool(x, k), True)
-            outs.append(ops.upsample_bilinear_ac(y, size))
-        x = self.lastconv[0](torch.cat(outs, dim=-1), True)
+        ys = [getattr(self, f"branch{i}")[1](ops.avg_pool(x, k), True) for i, k in enumerate(self.pools, start=1)]
+        x = self.lastconv[0](ops.pyramid_concat(x, ys), True)      # the up-sampling kernels write the concat's channel slices
         return ops.conv2d(x, self.lastconv[2].weight)
 
     def forward_padded(self, x, c):
@@ -648,12 +644,8 @@ class PyramidLayer(nn.Module):
         B, H, W, C = x.shape
         if H < self.pools[0] or W < self.pools[0]:
             x = F.pad(x, (0, 0, 0, max(self.pools[0] - W, 0), 0, max(self.pools[0] - H, 0)))
-        size = x.shape[1:3]
-        outs = [x]
-        for i, k in enumerate(self.pools, start=1):
-            y = getattr(self, f"branch{i}")[1](ops.avg_pool(x, k), True, geom=g2)
-            outs.append(ops.upsample_bilinear_ac(y, size))
-        x = self.lastconv[0](torch.cat(outs, dim=-1), True, geom=(c4p, c2, c2p))       # five groups of c2 channels, each padded
+        ys = [getattr(self, f"branch{i}")[1](ops.avg_pool(x, k), True, geom=g2) for i, k in enumerate(self.pools, start=1)]
+        x = self.lastconv[0](ops.pyramid_concat(x, ys), True, geom=(c4p, c2, c2p))      # five groups of c2 channels, each padded
         return ops.conv2d_padded(x, self.lastconv[2].weight, 0, (cp, c4, c4p))
 
 

@@ -797,6 +797,54 @@ class _ResampleFn(torch.autograd.Function):
         return gx, None, None
 
 
+class _PyramidCatFn(torch.autograd.Function):
+    """cat([x, up(y_1), ..., up(y_n)], channels) with up = bilinear(align_corners) to x's size (the PSP tail of
+    points_sample.py:114-122) WITHOUT the concat pass: the up-sampling kernels write their channel slice of the result directly
+    (pixel pitch = (n + 1) C), only x itself is copied; backward reads the slices in place (no .contiguous() copies) and hands
+    x its slice of the gradient as a view."""
+
+    @staticmethod
+    def forward(ctx, x, *ys):
+        lib = _lib()
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        n = len(ys)
+        out = torch.empty((B, H, W, (n + 1) * C), dtype=x.dtype, device=x.device)
+        out[..., :C].copy_(x)
+        shapes = []
+        for k, y in enumerate(ys):
+            y = y.contiguous()
+            if y.shape[0] != B or y.shape[3] != C:
+                raise ValueError("pyramid_concat: branch %d has shape %r" % (k, tuple(y.shape)))
+            lib.resample_forward(y, out[..., (k + 1) * C:(k + 2) * C], B, y.shape[1], y.shape[2], H, W, C, hip.RESAMPLE_BILINEAR_AC)
+            shapes.append((y.shape[1], y.shape[2]))
+        ctx.cfg = (B, H, W, C, shapes)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib()
+        B, H, W, C, shapes = ctx.cfg
+        g = g.contiguous()
+        grads = [g[..., :C]]
+        for k, (h, w) in enumerate(shapes):
+            gk = g[..., (k + 1) * C:(k + 2) * C]
+            gy = torch.empty((B, h, w, C), dtype=g.dtype, device=g.device)
+            tmp = torch.empty(lib.workspace_bytes(hip.WS_RESAMPLE_BWD, B, H, w, C) // 4, dtype=torch.float32, device=g.device)
+            if not lib.resample_backward_sep(gk, tmp, gy, B, h, w, H, W, C, hip.RESAMPLE_BILINEAR_AC):
+                lib.resample_backward(gk.contiguous(), gy, B, h, w, H, W, C, hip.RESAMPLE_BILINEAR_AC)
+            grads.append(gy)
+        return tuple(grads)
+
+
+def pyramid_concat(x, ys):
+    """x (B,H,W,C) and low-resolution maps ys[k] (B,h_k,w_k,C) -> (B,H,W,(1+len(ys)) C) = [x | bilinear_ac(ys[k] -> H,W) ...]."""
+    C = x.shape[-1]
+    if C % 8 or not ys or os.environ.get("GWD_PYRAMID_CAT", "1") == "0":
+        return torch.cat([x] + [upsample_bilinear_ac(y, x.shape[1:3]) for y in ys], dim=-1)
+    return _PyramidCatFn.apply(x, *ys)
+
+
 def upsample_bilinear_ac(x, size):
     """(B,Hs,Ws,C) -> (B,H,W,C), bilinear with align_corners=True."""
     return _ResampleFn.apply(x, tuple(size), hip.RESAMPLE_BILINEAR_AC)

@@ -333,15 +333,18 @@ int gwd_window_map(const void *src, void *dst, const void *residual, int32_t B, 
  * floor(dst*in/out) (src/models/multiscale_transformerr.py:1193,1230,1240,1267).  The backward kernels are
  * gathers over each source pixel's footprint (no atomics, bitwise reproducible).                    */
 enum { GWD_RESAMPLE_BILINEAR_AC = 0, GWD_RESAMPLE_NEAREST = 1 };
+/* ldy: pixel pitch of y in elements (0 = C).  ldy > C writes the result into a channel slice of a wider map (the PSP concat of
+ * points_sample.py:114-122 without a concat pass); vector-sized C and ldy only, else -4.                          */
 int gwd_resample_forward(const void *x, void *y, int32_t B, int32_t Hs, int32_t Ws, int32_t Ho, int32_t Wo,
-                         int32_t C, int32_t mode, int32_t dtype, void *stream);
+                         int32_t C, int32_t mode, int32_t ldy, int32_t dtype, void *stream);
 int gwd_resample_backward(const void *gy, void *gx, int32_t B, int32_t Hs, int32_t Ws, int32_t Ho, int32_t Wo,
                           int32_t C, int32_t mode, int32_t dtype, void *stream);
 /* gwd_resample_backward as two separable passes (x, then y) through a caller-provided fp32 scratch tmp[B][Ho][Ws][C]:
  * the same sums in the same order, but 2r+2 taps per thread instead of (2r+2)^2 (13x faster at the 16x pyramid
  * branches).  Returns -4 when C is not a multiple of 16 bytes (use gwd_resample_backward).                       */
+/* ldg: pixel pitch of gy in elements (0 = C): the gradient of a channel slice read in place.                        */
 int gwd_resample_backward_sep(const void *gy, float *tmp, void *gx, int32_t B, int32_t Hs, int32_t Ws, int32_t Ho, int32_t Wo,
-                              int32_t C, int32_t mode, int32_t dtype, void *stream);
+                              int32_t C, int32_t mode, int32_t ldg, int32_t dtype, void *stream);
 
 /* k x k / stride k average pooling (nn.AvgPool2d(k, stride=k), points_sample.py:61-75), floor mode.  */
 int gwd_avgpool_forward(const void *x, void *y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,

@@ -927,3 +927,26 @@ def test_mask_levels_and_sine_position_embedding(dev, shape, normalize):
     torch.cuda.synchronize()
     assert m.dtype == torch.bool and torch.equal(m.cpu(), m_ref)
     assert p.shape == p_ref.shape and float((p.cpu() - p_ref).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 30, 40, 64, (16, 8, 4, 2)), (8, 120, 160, 160, (16, 8, 4, 2)), (1, 17, 23, 8, (4, 2))])
+def test_pyramid_concat_equals_cat_of_upsampled_branches(dev, shape):
+    """ops.pyramid_concat (up-sampling kernels write their channel slice of the concat, backward reads the slices in place) ==
+    torch.cat of the separately up-sampled branches, forward bit for bit, gradients to the same tolerance as the resample tests."""
+    from gw_depth_amd import ops
+    B, H, W, C, pools = shape
+    torch.manual_seed(9)
+    x = torch.randn(B, H, W, C, device="cuda").bfloat16().requires_grad_(True)
+    ys = [torch.randn(B, max(H // k, 1), max(W // k, 1), C, device="cuda").bfloat16().requires_grad_(True) for k in pools]
+    ref = torch.cat([x] + [ops.upsample_bilinear_ac(y, (H, W)) for y in ys], dim=-1)
+    g = torch.randn_like(ref)
+    ref.backward(g)
+    want = [t.grad.clone() for t in [x] + ys]
+    for t in [x] + ys:
+        t.grad = None
+    out = ops.pyramid_concat(x, ys)
+    out.backward(g)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    for t, wv in zip([x] + ys, want):
+        assert torch.equal(t.grad, wv)
