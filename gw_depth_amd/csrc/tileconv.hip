@@ -63,21 +63,25 @@ template <int CIN, int COUT, int TH, bool UP, bool FLIP>
 __global__ __launch_bounds__(32 * TH) void tconv_fwd_kernel(const gwd_conv_desc d, int tiles_y, int tiles_x, int ntiles) {
     using H = Halo<CIN, TH>;
     constexpr int NT = H::NT;
+    constexpr int NTL = (COUT + 31) / 32, COUTP = 32 * NTL;  // output-channel tiles; rows COUT..COUTP-1 of the weight image are zero
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
-    __bf16 *halo = lds, *wl = lds + H::HPIX * H::PS;        // weights [tap][COUT][PS]
+    __bf16 *halo = lds, *wl = lds + H::HPIX * H::PS;        // weights [tap][COUTP][PS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const __bf16 *x = (const __bf16 *)d.x, *w = (const __bf16 *)d.w;
     __bf16 *y = (__bf16 *)d.y;
     const int Hv = d.Ho, Wv = d.Wo, Hs = d.Hi, Ws = d.Wi;   // same-size convolution on the (virtual) grid Hv x Wv
+    if constexpr (COUTP != COUT)
+        for (int c = tid; c < 9 * COUTP * (CIN / 8); c += NT) *(u32x4 *)(wl + (c / (CIN / 8)) * H::PS + (c % (CIN / 8)) * 8) = u32x4{0u, 0u, 0u, 0u};
+    if constexpr (COUTP != COUT) __syncthreads();
     for (int c = tid; c < 9 * COUT * (CIN / 8); c += NT) {
         const int part = c % (CIN / 8), row = c / (CIN / 8), co = row / 9, tap = row - co * 9;      // source row = (co, tap)
-        *(u32x4 *)(wl + (tap * COUT + co) * H::PS + part * 8) = *(const u32x4 *)(w + (size_t)row * CIN + part * 8);
+        *(u32x4 *)(wl + (tap * COUTP + co) * H::PS + part * 8) = *(const u32x4 *)(w + (size_t)row * CIN + part * 8);
     }
-    float sh[COUT / 32][16];
+    float sh[NTL][16];
 #pragma unroll
-    for (int nt = 0; nt < COUT / 32; ++nt)
+    for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sh[nt][i] = d.shift ? d.shift[32 * nt + acc_row(i, h)] : 0.f;
+        for (int i = 0; i < 16; ++i) sh[nt][i] = (d.shift && 32 * nt + acc_row(i, h) < COUT) ? d.shift[32 * nt + acc_row(i, h)] : 0.f;
 
     u32x4 pre[H::NCH];
     int tile = blockIdx.x;
@@ -107,11 +111,11 @@ __global__ __launch_bounds__(32 * TH) void tconv_fwd_kernel(const gwd_conv_desc 
 #pragma unroll
             for (int i = 0; i < H::NCH; ++i) pre[i] = halo_fetch<CIN, TH, UP>(x, tid + NT * i, nb, ny, nx, Hs, Ws, Hv, Wv);
         }
-        f32x16 acc[2][COUT / 32];
+        f32x16 acc[2][NTL];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < COUT / 32; ++nt)
+            for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 #pragma unroll
@@ -125,8 +129,8 @@ __global__ __launch_bounds__(32 * TH) void tconv_fwd_kernel(const gwd_conv_desc 
                 for (int mt = 0; mt < 2; ++mt)
                     bf[mt] = *(const bf16x8 *)(halo + ((2 * wave + mt + dy) * HW + r + dx) * H::PS + 16 * s + 8 * h);
 #pragma unroll
-                for (int nt = 0; nt < COUT / 32; ++nt) {
-                    const bf16x8 af = *(const bf16x8 *)(wl + (tap * COUT + 32 * nt + r) * H::PS + 16 * s + 8 * h);
+                for (int nt = 0; nt < NTL; ++nt) {
+                    const bf16x8 af = *(const bf16x8 *)(wl + (tap * COUTP + 32 * nt + r) * H::PS + 16 * s + 8 * h);
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = mma(af, bf[mt], acc[mt][nt]);
                 }
@@ -139,9 +143,10 @@ __global__ __launch_bounds__(32 * TH) void tconv_fwd_kernel(const gwd_conv_desc 
             if (oy < Hv && ox < Wv) {
                 __bf16 *dst = y + (((size_t)b * Hv + oy) * Wv + ox) * COUT;
 #pragma unroll
-                for (int nt = 0; nt < COUT / 32; ++nt)
+                for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
+                        if (32 * nt + 8 * g + 4 * h >= COUT) continue;         // COUT = 16: the upper half of the channel tile is padding
                         union { uint2 u; __bf16 e[4]; } v;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v.e[j] = (__bf16)(apply_act(acc[mt][nt][4 * g + j] + sh[nt][4 * g + j], d.act) * d.act_scale);
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(32 * TH) void tconv_fwd_kernel(const gwd_conv_desc 
 }
 
 template <int CIN, int COUT, int TH>
-size_t fwd_lds() { return (size_t)(Halo<CIN, TH>::HPIX * Halo<CIN, TH>::PS + 9 * COUT * Halo<CIN, TH>::PS) * 2; }
+size_t fwd_lds() { return (size_t)(Halo<CIN, TH>::HPIX * Halo<CIN, TH>::PS + 9 * ((COUT + 31) / 32 * 32) * Halo<CIN, TH>::PS) * 2; }
 
 static bool enabled() {                      // A/B switch (GWD_TILE_CONV=0: the tap-by-tap implicit GEMM for these layers as well)
     static int v = -1;
@@ -205,7 +210,8 @@ __global__ __launch_bounds__(192) void tconv_wgrad_kernel(const gwd_conv_desc d,
     using H = Halo<CX, TH>;
     constexpr int GS = CG + 8;                              // gy image pixel stride
     constexpr int GCH = TH * TW * (CG / 8), NG = (GCH + 191) / 192, NX = (H::CHUNKS + 191) / 192;
-    constexpr int TX = CX / 32, TG = CG / 32;
+    constexpr int TX = (CX + 31) / 32, TG = (CG + 31) / 32;   // 16 channels: the column gathers of a 32-wide tile run on into the next
+                                                             // pixel's bytes - those rows / columns of the product are never flushed
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
     __bf16 *halo = lds, *gimg = lds + HPIX * H::PS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -293,6 +299,7 @@ __global__ __launch_bounds__(192) void tconv_wgrad_kernel(const gwd_conv_desc d,
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int cg = 32 * b + acc_row(i, h), cx = 32 * c + r;
+                    if (cg >= CG || cx >= CX) continue;
                     const float sc = d.scale ? d.scale[cg] : 1.0f;
                     unsafeAtomicAdd(dw + ((size_t)cg * 9 + tap) * CX + cx, acc[a][b][c][i] * sc);
                 }
@@ -304,7 +311,7 @@ int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s) {
     constexpr int TH = 8;
     const int ty = (d->Ho + TH - 1) / TH, tx = (d->Wo + TW - 1) / TW;
     const long ntiles = (long)d->B * ty * tx;
-    const size_t lds = (size_t)(Halo<CX, TH>::HPIX * Halo<CX, TH>::PS + TH * TW * (CG + 8)) * 2;
+    const size_t lds = (size_t)(Halo<CX, TH>::HPIX * Halo<CX, TH>::PS + TH * TW * (CG + 8) + 64) * 2;      // + slack for the run-on gathers of the 16-channel case
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void *)tconv_wgrad_kernel<CX, CG, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -342,7 +349,7 @@ int gwd_tile_conv_forward(const gwd_conv_desc *d, hipStream_t s) {
         if (flip) return launch_fwd<CI, CO, false, true>(d, s);                                     \
         return launch_fwd<CI, CO, false, false>(d, s);                                              \
     }
-    TC(32, 32) TC(32, 64) TC(64, 32) TC(64, 64)
+    TC(32, 32) TC(32, 64) TC(64, 32) TC(64, 64) TC(16, 16)
 #undef TC
     return 0;
 }
@@ -360,7 +367,7 @@ int gwd_tile_conv_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s) {
     const int cx = d->Cin, cg = d->Cout;
 #define TW_(CX_, CG_)                                                                               \
     if (cx == CX_ && cg == CG_) return up ? launch_wgrad<CX_, CG_, true>(d, dw, s) : launch_wgrad<CX_, CG_, false>(d, dw, s);
-    TW_(32, 32) TW_(64, 32)
+    TW_(32, 32) TW_(64, 32) TW_(16, 16)
 #undef TW_
     return 0;
 }
