@@ -340,6 +340,138 @@ __global__ void avgpool_bwd_vec_kernel(const T *__restrict__ gy, T *__restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The four average pools of the PSP module (k = 16, 8, 4, 2; points_sample.py:107-113) from ONE pass over the map: a workgroup owns a
+// 16 x 16 pixel block, a thread sums a 2 x 2 patch, the coarser levels are sums of four finer sums (fp32, through LDS) - the same
+// means as four separate F.avg_pool2d calls (floor semantics: an output exists only where its whole k x k window does).
+template <typename T>
+__global__ __launch_bounds__(256) void psp_pool_fwd_kernel(const T *__restrict__ x, T *__restrict__ p16, T *__restrict__ p8, T *__restrict__ p4,
+                                                           T *__restrict__ p2, int B, int H, int W, int C, int bx_n, int by_n) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    __shared__ float s2[64][4][VEC], s4[16][4][VEC], s8[4][4][VEC];
+    const int t = threadIdx.x, q = t & 63, cg = t >> 6;       // q = 2x2 patch of the block (8 x 8 of them), cg = channel-vector lane
+    int blk = blockIdx.x;
+    const int bx = blk % bx_n;
+    blk /= bx_n;
+    const int by = blk % by_n, b = blk / by_n;
+    const int CV = C / VEC;
+    const int qy = q >> 3, qx = q & 7;
+    const int y0 = by * 16 + qy * 2, x0 = bx * 16 + qx * 2;
+    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8, H16 = H / 16, W16 = W / 16;
+    for (int cv0 = 0; cv0 < CV; cv0 += 4) {
+        const int cv = cv0 + cg;
+        float a[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] = 0.f;
+        if (cv < CV) {
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx)
+                    if (y0 + dy < H && x0 + dx < W) {
+                        const uint4 raw = *(const uint4 *)(x + (((size_t)b * H + y0 + dy) * W + x0 + dx) * C + cv * VEC);
+                        const T *pv = (const T *)&raw;
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) a[e] += to_f32(pv[e]);
+                    }
+            const int oy = y0 >> 1, ox = x0 >> 1;
+            if (oy < H2 && ox < W2) {
+                alignas(16) T o[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o[e] = from_f32<T>(a[e] * 0.25f);
+                *(uint4 *)(p2 + (((size_t)b * H2 + oy) * W2 + ox) * C + cv * VEC) = *(const uint4 *)o;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s2[q][cg][e] = a[e];
+        __syncthreads();
+        if (q < 16) {                                          // 4 x 4 outputs of the 4-pool
+            const int ry = q >> 2, rx = q & 3;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                a[e] = s2[(2 * ry) * 8 + 2 * rx][cg][e] + s2[(2 * ry) * 8 + 2 * rx + 1][cg][e] + s2[(2 * ry + 1) * 8 + 2 * rx][cg][e] +
+                       s2[(2 * ry + 1) * 8 + 2 * rx + 1][cg][e];
+            const int oy = by * 4 + ry, ox = bx * 4 + rx;
+            if (cv < CV && oy < H4 && ox < W4) {
+                alignas(16) T o[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o[e] = from_f32<T>(a[e] * (1.f / 16.f));
+                *(uint4 *)(p4 + (((size_t)b * H4 + oy) * W4 + ox) * C + cv * VEC) = *(const uint4 *)o;
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s4[q][cg][e] = a[e];
+        }
+        __syncthreads();
+        if (q < 4) {
+            const int ry = q >> 1, rx = q & 1;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                a[e] = s4[(2 * ry) * 4 + 2 * rx][cg][e] + s4[(2 * ry) * 4 + 2 * rx + 1][cg][e] + s4[(2 * ry + 1) * 4 + 2 * rx][cg][e] +
+                       s4[(2 * ry + 1) * 4 + 2 * rx + 1][cg][e];
+            const int oy = by * 2 + ry, ox = bx * 2 + rx;
+            if (cv < CV && oy < H8 && ox < W8) {
+                alignas(16) T o[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o[e] = from_f32<T>(a[e] * (1.f / 64.f));
+                *(uint4 *)(p8 + (((size_t)b * H8 + oy) * W8 + ox) * C + cv * VEC) = *(const uint4 *)o;
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s8[q][cg][e] = a[e];
+        }
+        __syncthreads();
+        if (q == 0 && cv < CV && by < H16 && bx < W16) {
+            alignas(16) T o[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = from_f32<T>((s8[0][cg][e] + s8[1][cg][e] + s8[2][cg][e] + s8[3][cg][e]) * (1.f / 256.f));
+            *(uint4 *)(p16 + (((size_t)b * H16 + by) * W16 + bx) * C + cv * VEC) = *(const uint4 *)o;
+        }
+        __syncthreads();
+    }
+}
+
+// gx = g_pass (the gradient of the map itself, pixel pitch ldg; may be NULL) + sum over the four levels of g_k[y / k][x / k] / k^2
+template <typename T>
+__global__ void psp_pool_bwd_kernel(const T *__restrict__ gpass, const T *__restrict__ g16, const T *__restrict__ g8, const T *__restrict__ g4,
+                                    const T *__restrict__ g2, T *__restrict__ gx, int B, int H, int W, int C, int ldg) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int CV = C / VEC;
+    const int64_t total = (int64_t)B * H * W * CV;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        int64_t r = i / CV;
+        const int xx = (int)(r % W);
+        r /= W;
+        const int yy = (int)(r % H);
+        const int b = (int)(r / H);
+        float a[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] = 0.f;
+        if (gpass) {
+            const uint4 raw = *(const uint4 *)(gpass + (((size_t)b * H + yy) * W + xx) * ldg + cv * VEC);
+            const T *pv = (const T *)&raw;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) a[e] = to_f32(pv[e]);
+        }
+        auto level = [&](const T *g, int k, float inv) {
+            const int Hk = H / k, Wk = W / k, oy = yy / k, ox = xx / k;
+            if (g && oy < Hk && ox < Wk) {
+                const uint4 raw = *(const uint4 *)(g + (((size_t)b * Hk + oy) * Wk + ox) * C + cv * VEC);
+                const T *pv = (const T *)&raw;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) a[e] += to_f32(pv[e]) * inv;
+            }
+        };
+        level(g2, 2, 0.25f);
+        level(g4, 4, 1.f / 16.f);
+        level(g8, 8, 1.f / 64.f);
+        level(g16, 16, 1.f / 256.f);
+        alignas(16) T o[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = from_f32<T>(a[e]);
+        *(uint4 *)(gx + i * VEC) = *(const uint4 *)o;
+    }
+}
+
 inline int flat_grid(int64_t total) {
     int64_t b = (total + 255) / 256;
     return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
@@ -455,6 +587,39 @@ extern "C" int gwd_resample_backward_sep(const void *gy, float *tmp, void *gx, i
         resample_bwd_x_kernel<float, 16><<<flat_grid(t1), 256, 0, st>>>((const float *)gy, tmp, B, Ws, Ho, Wo, C, mode, ldg);
         resample_bwd_y_kernel<float><<<flat_grid(t2), 256, 0, st>>>(tmp, (float *)gx, B, Hs, Ws, Ho, C, mode);
     }
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gwd_psp_pool_forward(const void *x, void *p16, void *p8, void *p4, void *p2, int32_t B, int32_t H, int32_t W, int32_t C,
+                                    int32_t dtype, void *stream) {
+    if (!x || !p16 || !p8 || !p4 || !p2 || B <= 0 || H < 16 || W < 16 || C <= 0) return -1;
+    const int vec = dtype == GWD_BF16 ? 8 : (dtype == GWD_F32 ? 4 : 0);
+    if (!vec) return -2;
+    if (C % vec) return -4;
+    const int bx = (W + 15) / 16, by = (H + 15) / 16;
+    if ((int64_t)B * bx * by >= (1LL << 31)) return -7;
+    const int grid = B * bx * by;
+    if (dtype == GWD_BF16)
+        psp_pool_fwd_kernel<__bf16><<<grid, 256, 0, (hipStream_t)stream>>>((const __bf16 *)x, (__bf16 *)p16, (__bf16 *)p8, (__bf16 *)p4, (__bf16 *)p2, B, H, W, C, bx, by);
+    else
+        psp_pool_fwd_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float *)x, (float *)p16, (float *)p8, (float *)p4, (float *)p2, B, H, W, C, bx, by);
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gwd_psp_pool_backward(const void *gpass, const void *g16, const void *g8, const void *g4, const void *g2, void *gx,
+                                     int32_t B, int32_t H, int32_t W, int32_t C, int32_t ldg, int32_t dtype, void *stream) {
+    if (!gx || B <= 0 || H < 16 || W < 16 || C <= 0) return -1;
+    const int vec = dtype == GWD_BF16 ? 8 : (dtype == GWD_F32 ? 4 : 0);
+    if (!vec) return -2;
+    if (ldg == 0) ldg = C;
+    if (C % vec || ldg % vec || ldg < C) return -4;
+    const int64_t total = (int64_t)B * H * W * (C / vec);
+    if (dtype == GWD_BF16)
+        psp_pool_bwd_kernel<__bf16><<<flat_grid(total), 256, 0, (hipStream_t)stream>>>((const __bf16 *)gpass, (const __bf16 *)g16, (const __bf16 *)g8, (const __bf16 *)g4, (const __bf16 *)g2, (__bf16 *)gx, B, H, W, C, ldg);
+    else
+        psp_pool_bwd_kernel<float><<<flat_grid(total), 256, 0, (hipStream_t)stream>>>((const float *)gpass, (const float *)g16, (const float *)g8, (const float *)g4, (const float *)g2, (float *)gx, B, H, W, C, ldg);
     GWD_CHECK_LAUNCH();
     return 0;
 }

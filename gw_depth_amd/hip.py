@@ -31,7 +31,7 @@ ENTRY_POINTS = [
     "gwd_softmax_masked_forward", "gwd_softmax_scaled_backward", "gwd_query_workspace", "gwd_eval_accumulate", "gwd_colsum_batch", "gwd_conv_wgrad_batch",
     "gwd_plane_loss_forward", "gwd_plane_loss_backward", "gwd_collate",
     "gwd_anchor_depth_forward", "gwd_anchor_depth_backward", "gwd_mha_flash_forward", "gwd_mha_flash_backward",
-    "gwd_ref_scores_forward", "gwd_ref_scores_backward", "gwd_ref_mix_forward", "gwd_ref_mix_backward", "gwd_unpad_add_batch", "gwd_stem_pack", "gwd_stem_forward", "gwd_pos_sine", "gwd_silog_finalize",
+    "gwd_ref_scores_forward", "gwd_ref_scores_backward", "gwd_ref_mix_forward", "gwd_ref_mix_backward", "gwd_unpad_add_batch", "gwd_stem_pack", "gwd_stem_forward", "gwd_pos_sine", "gwd_silog_finalize", "gwd_psp_pool_forward", "gwd_psp_pool_backward",
 ]
 
 
@@ -167,6 +167,8 @@ class HipLibrary:
         L.gwd_layernorm_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
         L.gwd_unpad_add_batch.argtypes = [ctypes.POINTER(UnpadJob), i32, vp]
         L.gwd_silog_finalize.argtypes = [vp, f32, f32, vp, vp]
+        L.gwd_psp_pool_forward.argtypes = [vp] * 5 + [i32] * 5 + [vp]
+        L.gwd_psp_pool_backward.argtypes = [vp] * 6 + [i32] * 6 + [vp]
         L.gwd_pos_sine.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_stem_pack.argtypes = [vp, vp, vp, vp]
         L.gwd_stem_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
@@ -490,6 +492,22 @@ class HipLibrary:
             return False
         self._check(rc, "gwd_resample_backward_sep")
         return True
+
+    def psp_pool_forward(self, x, p16, p8, p4, p2):
+        """x (B,H,W,C) -> its 16/8/4/2 average pools in one pass; False when the shape is not supported (use avgpool_forward)."""
+        B, H, W, C = x.shape
+        rc = self.lib.gwd_psp_pool_forward(_ptr(x), _ptr(p16), _ptr(p8), _ptr(p4), _ptr(p2), B, H, W, C, dtype_code(x), self._stream(x, p16, p8, p4, p2))
+        if rc == -4:
+            return False
+        self._check(rc, "gwd_psp_pool_forward")
+        return True
+
+    def psp_pool_backward(self, g_pass, g16, g8, g4, g2, gx):
+        """gx (B,H,W,C) = g_pass (may be a channel slice of a wider map, or None) + the four pools' gradients spread back."""
+        B, H, W, C = gx.shape
+        ld = self._pixel_pitch(g_pass, H, W, C) if g_pass is not None else 0
+        self._check(self.lib.gwd_psp_pool_backward(_ptr_pitched(g_pass), _ptr(g16), _ptr(g8), _ptr(g4), _ptr(g2), _ptr(gx), B, H, W, C, ld,
+                                                   dtype_code(gx), self._stream(gx, g16, g8, g4, g2)), "gwd_psp_pool_backward")
 
     def avgpool_forward(self, x, y, B, H, W, C, k):
         self._check(self.lib.gwd_avgpool_forward(_ptr(x), _ptr(y), B, H, W, C, k, dtype_code(x), self._stream(x, y)),

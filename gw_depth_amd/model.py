@@ -625,7 +625,8 @@ class PyramidLayer(nn.Module):
         B, H, W, C = x.shape
         if H < self.pools[0] or W < self.pools[0]:
             x = F.pad(x, (0, 0, 0, max(self.pools[0] - W, 0), 0, max(self.pools[0] - H, 0)))
-        ys = [getattr(self, f"branch{i}")[1](ops.avg_pool(x, k), True) for i, k in enumerate(self.pools, start=1)]
+        x, pooled = ops.psp_pools(x, self.pools)                  # the four average pools in one pass
+        ys = [getattr(self, f"branch{i}")[1](p, True) for i, p in enumerate(pooled, start=1)]
         x = self.lastconv[0](ops.pyramid_concat(x, ys), True)      # the up-sampling kernels write the concat's channel slices
         return ops.conv2d(x, self.lastconv[2].weight)
 
@@ -644,7 +645,8 @@ class PyramidLayer(nn.Module):
         B, H, W, C = x.shape
         if H < self.pools[0] or W < self.pools[0]:
             x = F.pad(x, (0, 0, 0, max(self.pools[0] - W, 0), 0, max(self.pools[0] - H, 0)))
-        ys = [getattr(self, f"branch{i}")[1](ops.avg_pool(x, k), True, geom=g2) for i, k in enumerate(self.pools, start=1)]
+        x, pooled = ops.psp_pools(x, self.pools)
+        ys = [getattr(self, f"branch{i}")[1](p, True, geom=g2) for i, p in enumerate(pooled, start=1)]
         x = self.lastconv[0](ops.pyramid_concat(x, ys), True, geom=(c4p, c2, c2p))      # five groups of c2 channels, each padded
         return ops.conv2d_padded(x, self.lastconv[2].weight, 0, (cp, c4, c4p))
 

@@ -797,6 +797,42 @@ class _ResampleFn(torch.autograd.Function):
         return gx, None, None
 
 
+class _PspPoolFn(torch.autograd.Function):
+    """x -> (x itself, avg_pool 16, 8, 4, 2 of x): the pooling side of the PSP module (points_sample.py:107-113) as one pass forward
+    and one pass backward.  The first output is x again, for the consumer that takes the map itself (the concat): with it this node
+    is x's ONLY consumer, so the five gradients arrive together and leave as one tensor (was four pool backward kernels and four
+    accumulation passes over the full map)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, H, W, C = x.shape
+        outs = [torch.empty((B, H // k, W // k, C), dtype=x.dtype, device=x.device) for k in (16, 8, 4, 2)]
+        if not _lib().psp_pool_forward(x, *outs):
+            raise ValueError("psp_pools: unsupported shape %r" % (tuple(x.shape),))
+        ctx.shape = tuple(x.shape)
+        return (x.view_as(x),) + tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_pass, g16, g8, g4, g2):
+        B, H, W, C = ctx.shape
+        like = next(g for g in (g_pass, g16, g8, g4, g2) if g is not None)
+        gx = torch.empty((B, H, W, C), dtype=like.dtype, device=like.device)
+        con = lambda g: None if g is None else g.contiguous()
+        _lib().psp_pool_backward(g_pass, con(g16), con(g8), con(g4), con(g2), gx)
+        return gx
+
+
+def psp_pools(x, pools):
+    """(x, [avg_pool(x, k) for k in pools]); fused into one pass each way for the reference's pools (16, 8, 4, 2)."""
+    B, H, W, C = x.shape
+    vec = 8 if x.dtype == torch.bfloat16 else 4
+    if tuple(pools) == (16, 8, 4, 2) and H >= 16 and W >= 16 and C % vec == 0 and x.is_contiguous() \
+            and os.environ.get("GWD_PSP_POOL", "1") != "0":
+        outs = _PspPoolFn.apply(x)
+        return outs[0], list(outs[1:])
+    return x, [avg_pool(x, k) for k in pools]
+
+
 class _PyramidCatFn(torch.autograd.Function):
     """cat([x, up(y_1), ..., up(y_n)], channels) with up = bilinear(align_corners) to x's size (the PSP tail of
     points_sample.py:114-122) WITHOUT the concat pass: the up-sampling kernels write their channel slice of the result directly

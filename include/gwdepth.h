@@ -347,6 +347,14 @@ int gwd_resample_backward_sep(const void *gy, float *tmp, void *gx, int32_t B, i
                               int32_t C, int32_t mode, int32_t ldg, int32_t dtype, void *stream);
 
 /* k x k / stride k average pooling (nn.AvgPool2d(k, stride=k), points_sample.py:61-75), floor mode.  */
+/* The four average pools of the PSP module (F.avg_pool2d with k = 16, 8, 4, 2; src/models/points/points_sample.py:107-113) from
+ * ONE pass over x (B,H,W,C): p_k (B,H/k,W/k,C).  Backward in one pass as well: gx = g_pass + sum_k g_k[y/k][x/k] / k^2, where g_pass
+ * (may be NULL; pixel pitch ldg, 0 = C) is the gradient that reaches the map directly - on this path the first channel slice of the
+ * concat's gradient, read in place.  Any g_k may be NULL.  H, W >= 16; C (and ldg) multiples of 16 bytes, else -4.            */
+int gwd_psp_pool_forward(const void *x, void *p16, void *p8, void *p4, void *p2, int32_t B, int32_t H, int32_t W, int32_t C,
+                         int32_t dtype, void *stream);
+int gwd_psp_pool_backward(const void *g_pass, const void *g16, const void *g8, const void *g4, const void *g2, void *gx, int32_t B,
+                          int32_t H, int32_t W, int32_t C, int32_t ldg, int32_t dtype, void *stream);
 int gwd_avgpool_forward(const void *x, void *y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
                         int32_t dtype, void *stream);
 int gwd_avgpool_backward(const void *gy, void *gx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,

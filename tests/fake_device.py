@@ -444,6 +444,22 @@ class FakeDevice:
             (g,) = torch.autograd.grad(o, x0, gy.reshape(B, Ho, Wo, C).permute(0, 3, 1, 2).float())
         gx.copy_(g.permute(0, 2, 3, 1).reshape(gx.shape))
 
+    def psp_pool_forward(self, x, p16, p8, p4, p2):
+        B, H, W, C = x.shape
+        for k, out in ((16, p16), (8, p8), (4, p4), (2, p2)):
+            self.avgpool_forward(x, out, B, H, W, C, k)
+        return True
+
+    def psp_pool_backward(self, g_pass, g16, g8, g4, g2, gx):
+        B, H, W, C = gx.shape
+        acc = torch.zeros(B, H, W, C) if g_pass is None else g_pass.float().clone()
+        for k, g in ((16, g16), (8, g8), (4, g4), (2, g2)):
+            if g is not None:
+                tmp = torch.empty(B, H, W, C)
+                self.avgpool_backward(g.float(), tmp, B, H, W, C, k)
+                acc += tmp
+        gx.copy_(acc)
+
     def avgpool_forward(self, x, y, B, H, W, C, k):
         y.copy_(F.avg_pool2d(x.reshape(B, H, W, C).permute(0, 3, 1, 2).float(), k, k).permute(0, 2, 3, 1).reshape(y.shape))
 

@@ -950,3 +950,28 @@ def test_pyramid_concat_equals_cat_of_upsampled_branches(dev, shape):
     assert torch.equal(out, ref)
     for t, wv in zip([x] + ys, want):
         assert torch.equal(t.grad, wv)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(8, 120, 160, 160), (2, 60, 80, 64), (1, 16, 16, 8), (3, 37, 50, 24)])
+def test_psp_pools_equal_four_average_pools(dev, shape, dtype):
+    """ops.psp_pools (one pass forward, one pass backward incl. the gradient of the map itself read from a wider concat gradient)
+    against four F.avg_pool2d calls (floor semantics at ragged sizes) and autograd's sum of their gradients."""
+    from gw_depth_amd import ops
+    import torch.nn.functional as F
+    B, H, W, C = shape
+    torch.manual_seed(10)
+    x = torch.randn(B, H, W, C, device="cuda").to(dtype).requires_grad_(True)
+    xp, pooled = ops.psp_pools(x, (16, 8, 4, 2))
+    xr = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
+    ref = [F.avg_pool2d(xr, k, k) for k in (16, 8, 4, 2)]
+    wide = torch.randn(B, H, W, 3 * C, device="cuda").to(dtype)                     # the concat's gradient: x's share is a channel slice
+    gs = [torch.randn_like(p) for p in pooled]
+    torch.autograd.backward([xp] + pooled, [wide[..., :C]] + gs)
+    torch.autograd.backward(ref, [g.float().permute(0, 3, 1, 2) for g in gs])
+    want = xr.grad.permute(0, 2, 3, 1) + wide[..., :C].float()
+    torch.cuda.synchronize()
+    assert torch.equal(xp, x)
+    for p, r in zip(pooled, ref):
+        assert p.shape == r.permute(0, 2, 3, 1).shape and rel(p, r.permute(0, 2, 3, 1)) < TOL[dtype] * 0.3
+    assert rel(x.grad, want) < TOL[dtype] * 0.3
