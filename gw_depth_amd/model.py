@@ -96,7 +96,7 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         s, b = self.bn1.folded()
-        out = ops.conv2d(x, self.conv1.weight, row_scale=s, shift=b, act=ACT_RELU)
+        out, x = ops.conv2d(x, self.conv1.weight, row_scale=s, shift=b, act=ACT_RELU, fanout=True)     # x again, for the skip path
         s, b = self.bn2.folded()
         out = ops.conv2d(out, self.conv2.weight, stride=self.stride, pad=1, row_scale=s, shift=b, act=ACT_RELU)
         idt = x
@@ -570,10 +570,15 @@ class ConvLn(nn.Module):
         self.layer_norm = LayerNorm(cout)
         self.pad = k // 2
 
-    def forward(self, x, gelu=False, residual=None, geom=None):
+    def forward(self, x, gelu=False, residual=None, geom=None, fan=False):
+        """fan: also return the input again for its second consumer (the block's skip): ops._ConvFn fan-out."""
         if geom is not None:                # zero-padded channel counts (PyramidLayer.padded_width); the LayerNorm sees the pitch
-            return self.layer_norm(ops.conv2d_padded(x, self.conv.weight, self.pad, geom), gelu, residual=residual)
-        return self.layer_norm(ops.conv2d(x, self.conv.weight, pad=self.pad), gelu, residual=residual)
+            y = ops.conv2d_padded(x, self.conv.weight, self.pad, geom, fanout=fan)
+        else:
+            y = ops.conv2d(x, self.conv.weight, pad=self.pad, fanout=fan)
+        if fan:
+            return self.layer_norm(y[0], gelu, residual=residual), y[1]
+        return self.layer_norm(y, gelu, residual=residual)
 
 
 class PyrBlock(nn.Module):
@@ -585,7 +590,8 @@ class PyrBlock(nn.Module):
         self.conv2 = ConvLn(c, c, 3)
 
     def forward(self, x, geom=None):
-        return self.conv2(self.conv1[0](x, True, geom=geom), residual=x, geom=geom)      # the skip is added in the LayerNorm kernel
+        h, xs = self.conv1[0](x, True, geom=geom, fan=True)      # xs = x: both gradients of x then meet in conv1's data-gradient epilogue
+        return self.conv2(h, residual=xs, geom=geom)              # the skip is added in the LayerNorm kernel
 
 
 class PyramidLayer(nn.Module):
@@ -849,12 +855,23 @@ class DensePrediction(nn.Module):
         multiple of 32 channels, so the three GEMMs and their gradients run on the LDS-DMA kernels (the 136-wide version
         sat on the register-staged odd-width path: 284 us for one data gradient)."""
         fc1, fc2 = self.depth_token_fuse.fc1, self.depth_token_fuse.fc2
-        pad = (-x.shape[-1]) % 32
-        if pad == 0 or not x.is_cuda:
+        pad = x.shape[-1] - fc1.weight.shape[-1]            # forward() has already appended the zero channels (in its concat)
+        if pad == 0:
             return self.depth_token_fuse(x)
-        xp = F.pad(x, (0, pad))
-        h = ops.linear(xp, F.pad(fc1.weight, (0, pad, 0, pad)), F.pad(fc1.bias, (0, pad)), ACT_GELU)
+        h = ops.linear(x, F.pad(fc1.weight, (0, pad, 0, pad)), F.pad(fc1.bias, (0, pad)), ACT_GELU)
         return ops.linear(h, F.pad(fc2.weight, (0, pad)), fc2.bias)
+
+    _ZERO_BLOCKS = {}
+
+    @classmethod
+    def zero_channels(cls, like, n):
+        """A constant (B,H,W,n) block of zeros (cached per shape): concatenated behind the fuse input it makes the width a multiple
+        of 32 in the concat pass itself (was: concat, then F.pad = one more pass over the map, and its backward)."""
+        key = (tuple(like.shape[:3]), n, like.dtype, str(like.device))
+        z = cls._ZERO_BLOCKS.get(key)
+        if z is None:
+            z = cls._ZERO_BLOCKS[key] = torch.zeros(tuple(like.shape[:3]) + (n,), dtype=like.dtype, device=like.device)
+        return z
 
     def branch(self, fuse_in, tag, fuse, size, cast):
         B, H, W, _ = fuse_in.shape
@@ -870,7 +887,11 @@ class DensePrediction(nn.Module):
         cast = cast or (lambda stage, t: t)
         B, H, W, _ = feat.shape
         d3 = depth3.view(B, H, W, 1).to(feat.dtype)
-        d = self.branch(torch.cat([feat, d3, dtok], dim=-1), "depth", self.fuse_padded, size, cast)
+        parts = [feat, d3, dtok]
+        pad = (-sum(p.shape[-1] for p in parts)) % 32
+        if pad and feat.is_cuda:
+            parts.append(self.zero_channels(feat, pad))
+        d = self.branch(torch.cat(parts, dim=-1), "depth", self.fuse_padded, size, cast)
         depth = ops.conv2d(d, self.get_depth[0].weight, pad=1, act=ACT_SIGMOID, act_scale=float(self.max_depth))
         s = self.branch(torch.cat([feat, stok], dim=-1), "seg", self.seg_token_fuse, size, cast)
         seg = ops.conv2d(s, self.get_seg.weight, pad=1)

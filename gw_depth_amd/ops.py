@@ -166,6 +166,22 @@ class WgradQueue:
 
     def __init__(self):
         self.jobs, self.active = [], False
+        self._pool, self._used, self._want, self._dev = None, 0, 0, None
+
+    def scratch(self, shape, device):
+        """Zeroed fp32 scratch for a weight gradient formed in a padded shape.  Inside a backward pass the pieces come from ONE
+        buffer zeroed by one fill when the pass opens (sized by the previous pass; a piece that does not fit gets its own zeros)."""
+        n = 1
+        for v in shape:
+            n *= int(v)
+        n16 = (n + 15) // 16 * 16
+        self._want += n16
+        self._dev = device
+        if self.active and self._pool is not None and self._pool.device == device and self._used + n16 <= self._pool.numel():
+            out = self._pool[self._used:self._used + n].view(shape)
+            self._used += n16
+            return out
+        return torch.zeros(shape, dtype=torch.float32, device=device)
 
     def add(self, x, dv, dw, dims, kw, hook=None, unpad=None):
         """unpad = (dst, N, taps, G, Cg, Cgp): dw is a zeroed scratch tensor in the PADDED weight shape; after the launch its real
@@ -195,6 +211,9 @@ class WgradQueue:
 
     def __enter__(self):
         self.active = True
+        if self._pool is not None:
+            self._pool.zero_()
+        self._used = self._want = 0
         return self
 
     def __exit__(self, *exc):
@@ -203,6 +222,9 @@ class WgradQueue:
                 self.flush()
         finally:
             self.jobs, self.active = [], False
+            if self._want and self._dev is not None and (self._pool is None or self._pool.numel() < self._want) \
+                    and not torch.cuda.is_current_stream_capturing():
+                self._pool = torch.empty(self._want, dtype=torch.float32, device=self._dev)     # for the next pass
         return False
 
 
@@ -331,8 +353,9 @@ class _PadConvFn(torch.autograd.Function):
     back by gwd_unpad_add_batch.  User: the 30 / 60 / 300-channel pyramid of points_sample.py:45-125 (32 / 64 / 320 here)."""
 
     @staticmethod
-    def forward(ctx, x, w, pad, geom, sink):
+    def forward(ctx, x, w, pad, geom, sink, fanout=False):
         lib = _lib()
+        ctx.fan = bool(fanout)
         Np, Cg, Cgp = geom
         B, Hi, Wi, Cin = x.shape
         N, KH, KW, C = w.shape
@@ -346,11 +369,14 @@ class _PadConvFn(torch.autograd.Function):
         lib.conv_forward(x, _padded_weight_for(w, geom, "fwd", x.dtype), y, dims, stride=1, pad=pad)
         ctx.save_for_backward(x, w)
         ctx.cfg = (dims, pad, geom, sink)
+        if fanout:
+            return y, x.view_as(x)                   # as _ConvFn: the input again, for its second consumer
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, *g_fan):
         lib = _lib()
+        g_in = g_fan[0].contiguous() if (ctx.fan and g_fan and g_fan[0] is not None) else None
         x, w = ctx.saved_tensors
         dims, pad, geom, sink = ctx.cfg
         B, Hi, Wi, Cin, Ho, Wo, Np, KH, KW = dims
@@ -361,9 +387,11 @@ class _PadConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
             lib.conv_forward(gy, _padded_weight_for(w, geom, "t", x.dtype), gx, (B, Ho, Wo, Np, Hi, Wi, Cin, KH, KW), stride=1, pad=pad,
-                             gather=GATHER_TRANSPOSED)
+                             gather=GATHER_TRANSPOSED, residual=g_in)
+        elif g_in is not None:
+            gx = g_in
         if ctx.needs_input_grad[1]:
-            tmp = torch.zeros((Np, KH, KW, Cin), dtype=torch.float32, device=x.device)
+            tmp = WGRADS.scratch((Np, KH, KW, Cin), x.device)
             fold = (N, KH * KW, C // Cg, Cg, Cgp)
             if sink is not None:
                 WGRADS.add(x, gy, tmp, dims, dict(stride=1, pad=pad), sink[1], unpad=(sink[0].view(-1),) + fold)
@@ -371,12 +399,14 @@ class _PadConvFn(torch.autograd.Function):
                 lib.conv_wgrad(x, gy, tmp, dims, stride=1, pad=pad)
                 gw = torch.zeros(w.shape, dtype=torch.float32, device=w.device)
                 lib.unpad_add_batch([(tmp, gw.view(-1)) + fold])
-        return gx, gw, None, None, None
+        return gx, gw, None, None, None, None
 
 
-def conv2d_padded(x, w, pad, geom):
+def conv2d_padded(x, w, pad, geom, fanout=False):
     """See _PadConvFn.  x (B, H, W, G*Cgp) zero-padded, w (Cout, KH, KW, G*Cg) fp32 master, geom = (Np, Cg, Cgp)."""
-    return _PadConvFn.apply(x, w, int(pad), tuple(int(v) for v in geom), _sink(w))
+    if fanout and os.environ.get("GWD_FANOUT", "1") == "0":
+        return _PadConvFn.apply(x, w, int(pad), tuple(int(v) for v in geom), _sink(w), False), x
+    return _PadConvFn.apply(x, w, int(pad), tuple(int(v) for v in geom), _sink(w), bool(fanout))
 
 
 class _ConvFn(torch.autograd.Function):
@@ -384,8 +414,9 @@ class _ConvFn(torch.autograd.Function):
     dropout multiplier) y = act_scale * act(conv + shift) * mult + residual: the skip is added after the dropout."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual, row_scale, shift_const, stride, pad, act, act_scale, virt, shadow, sinks, mult=None):
+    def forward(ctx, x, w, bias, residual, row_scale, shift_const, stride, pad, act, act_scale, virt, shadow, sinks, mult=None, fanout=False):
         lib = _lib()
+        ctx.fan = bool(fanout)
         B, Hi, Wi, Cin = x.shape
         Cout, KH, KW, Cw = w.shape
         if Cw != Cin:
@@ -417,11 +448,17 @@ class _ConvFn(torch.autograd.Function):
         # ReLU's backward needs only the sign of the output: y * mult has the sign of relu(v) wherever mult > 0, and where
         # mult == 0 the incoming gradient is multiplied by zero anyway
         ctx.save_for_backward(x, w, row_scale, z if act == ACT_GELU else (y if act != ACT_NONE else None), mult)
+        if fanout:
+            # second output: x again, for a second consumer of the layer's input (a skip connection).  With it this node is x's only
+            # consumer, both gradients arrive in ONE backward call and the skip's joins the data gradient in the kernel epilogue -
+            # no accumulation pass over the map (PyrBlock, Bottleneck)
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, *g_fan):
         lib = _lib()
+        g_in = g_fan[0].contiguous() if (ctx.fan and g_fan and g_fan[0] is not None) else None
         x, w, row_scale, ref, mult = ctx.saved_tensors
         dims, stride, pad, act, act_scale, gather, vv, has_bias, has_res = ctx.cfg
         B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW = dims
@@ -462,10 +499,14 @@ class _ConvFn(torch.autograd.Function):
                 lib.conv_forward(dv, wt, gxv, (B, Ho, Wo, Cout, vv[0], vv[1], Cin, KH, KW), stride=1, pad=pad,
                                  gather=GATHER_TRANSPOSED)
                 gx = _nearest_upsample_backward(gxv, Hi, Wi)
+                if g_in is not None:
+                    gx = gx + g_in
             else:
                 gx = torch.empty_like(x)
                 lib.conv_forward(dv, wt, gx, (B, Ho, Wo, Cout, Hi, Wi, Cin, KH, KW), stride=stride, pad=pad,
-                                 gather=GATHER_TRANSPOSED)
+                                 gather=GATHER_TRANSPOSED, residual=g_in)
+        elif g_in is not None:
+            gx = g_in
         if ctx.needs_input_grad[1]:
             # row_scale (folded FrozenBN: the layer ran with w * scale) multiplies the gradient inside the kernel's epilogue
             if w_sink is not None:
@@ -481,7 +522,7 @@ class _ConvFn(torch.autograd.Function):
                 gb = torch.zeros(Cout, dtype=torch.float32, device=gy.device)
                 lib.colsum(dv, gb, rows, Cout)
         gres = (g_skip if mult is not None else dv) if (has_res and ctx.needs_input_grad[3]) else None
-        return gx, gw, gb, gres, None, None, None, None, None, None, None, None, None, None
+        return gx, gw, gb, gres, None, None, None, None, None, None, None, None, None, None, None
 
 
 def _nearest_upsample_backward(gv, Hi, Wi):
@@ -502,13 +543,17 @@ def _sink(p, shape=None):
 
 
 def conv2d(x, w, bias=None, *, stride=1, pad=0, act=ACT_NONE, act_scale=1.0, residual=None, row_scale=None,
-           shift=None, upsample_to=None, mult=None):
+           shift=None, upsample_to=None, mult=None, fanout=False):
     """x (B,H,W,Cin); w (Cout,KH,KW,Cin) fp32 master; bias fp32 parameter or None.
     row_scale / shift: constant per-Cout tensors of a folded FrozenBatchNorm.
-    upsample_to=(Hv,Wv): convolve a nearest-upsampled view of x without materialising it."""
+    upsample_to=(Hv,Wv): convolve a nearest-upsampled view of x without materialising it.
+    fanout: return (y, x'), x' = x for the OTHER consumer of the input (use x' instead of x there): see _ConvFn.forward."""
     sinks = (_sink(w), _sink(bias) if bias is not None else None)
+    if fanout and os.environ.get("GWD_FANOUT", "1") == "0":         # A/B: autograd's own accumulation of the two gradients
+        return _ConvFn.apply(x, w, bias, residual, row_scale, shift, stride, pad, act, float(act_scale), upsample_to,
+                             getattr(w, "_gwd_bf16", None), sinks if (sinks[0] or sinks[1]) else None, mult, False), x
     return _ConvFn.apply(x, w, bias, residual, row_scale, shift, stride, pad, act, float(act_scale), upsample_to,
-                         getattr(w, "_gwd_bf16", None), sinks if (sinks[0] or sinks[1]) else None, mult)
+                         getattr(w, "_gwd_bf16", None), sinks if (sinks[0] or sinks[1]) else None, mult, bool(fanout))
 
 
 def linear(x, w, bias=None, act=ACT_NONE, rows=None, residual=None, mult=None):
