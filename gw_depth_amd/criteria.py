@@ -2,6 +2,8 @@
 /root/reference/src/models/matcher.py).  The dense losses run on the fused HIP reductions; the line
 losses are a few hundred elements (latency class) and use torch tensor plumbing plus scipy's LSAP on
 the host exactly as the reference does."""
+import os
+
 import torch
 import torch.nn.functional as F
 from scipy.optimize import linear_sum_assignment
@@ -66,6 +68,44 @@ class HungarianMatcherLine(nn.Module):
         return self._solve(handle["host"][i], handle["sizes"])
 
 
+class _SetLossFn(torch.autograd.Function):
+    """Cost matrices of all decoder layers, device LSAP, weighted cross entropy and matched-pair L1 per layer - and their gradients -
+    as five launches (csrc/setloss.hip, csrc/lsap.hip); forward_packed's torch formulation (kept below as the A/B path) took ~65."""
+
+    @staticmethod
+    def forward(ctx, logits, lines, tgt_lines, tgt_labels, meta, class_weight, num_items, world, w_line, w_class):
+        from . import hip
+        lib = hip.library()
+        L_, B, Q, K = logits.shape
+        cap = tgt_lines.shape[0]
+        dev = logits.device
+        col_off, bidx, valid = meta[:B + 1], meta[B + 1:B + 1 + cap], meta[B + 1 + cap:]
+        cost = torch.empty((L_, B, Q, cap), dtype=torch.float32, device=dev)
+        lib.match_cost(logits, lines, tgt_lines, tgt_labels, cost, w_line, w_class)
+        qot = torch.empty((L_, cap), dtype=torch.int32, device=dev)
+        lib.lsap(cost, col_off.contiguous(), qot, hip.LSAP_MAX_TARGETS)      # padding columns come back as the dummy query Q
+        tc = torch.empty((L_, B, Q), dtype=torch.int32, device=dev)
+        out = torch.empty((3, L_), dtype=torch.float32, device=dev)           # ce | l1 | sum of class weights
+        bidx, valid = bidx.contiguous(), valid.contiguous()
+        cw = class_weight.float().contiguous()
+        lib.set_losses_forward(logits, lines, tgt_lines, tgt_labels, bidx, valid, qot, cw, num_items, world, tc, out[0], out[1], out[2])
+        ctx.save_for_backward(logits, lines, tgt_lines, bidx, valid, qot, cw, num_items, tc, out)
+        ctx.world = world
+        ctx.mark_non_differentiable(qot)
+        return out[0], out[1], qot
+
+    @staticmethod
+    def backward(ctx, g_ce, g_l1, _g_qot):
+        from . import hip
+        logits, lines, tgt_lines, bidx, valid, qot, cw, num_items, tc, out = ctx.saved_tensors
+        dlogits = torch.empty_like(logits)
+        dlines = torch.zeros_like(lines)
+        con = lambda g: None if g is None else g.contiguous().float()
+        hip.library().set_losses_backward(logits, lines, tgt_lines, bidx, valid, qot, cw, num_items, ctx.world, tc, out[2], con(g_ce), con(g_l1),
+                                          dlogits, dlines)
+        return dlogits, dlines, None, None, None, None, None, None, None, None
+
+
 class SetCriterion(nn.Module):
     """SetCriterion with losses ['lines_labels', 'lines'] (+ aux), glassrgbd.py:133-358."""
 
@@ -111,6 +151,15 @@ class SetCriterion(nn.Module):
         cap = packed["lines"].shape[0]
         meta = packed["meta"]                                                          # int32: col_off (B+1) | image of column (cap) | valid (cap)
         col_off, bidx, valid = meta[:B + 1], meta[B + 1:B + 1 + cap].long(), meta[B + 1 + cap:].float()
+        if os.environ.get("GWD_FUSED_SETLOSS", "1") != "0":
+            ce, l1, qi = _SetLossFn.apply(logits.contiguous(), lines.contiguous(), packed["lines"], packed["labels"], meta, self.empty_weight,
+                                          packed["num_items"], float(world), float(self.matcher.cost_line), float(self.matcher.cost_class))
+            self.last_query_of_target = qi.long()
+            losses = {"loss_ce": ce[0], "loss_line": l1[0]}
+            for i in range(L_ - 1):
+                losses[f"loss_ce_{i}"] = ce[i + 1]
+                losses[f"loss_line_{i}"] = l1[i + 1]
+            return losses
         with torch.no_grad():                                                          # matcher.py:52-70
             prob = logits.softmax(-1)
             # L1 distances as one broadcast |a - b| summed over the 6 coordinates (aten::cdist takes 158 us for this 48x100x56 problem)

@@ -32,6 +32,7 @@ ENTRY_POINTS = [
     "gwd_plane_loss_forward", "gwd_plane_loss_backward", "gwd_collate",
     "gwd_anchor_depth_forward", "gwd_anchor_depth_backward", "gwd_mha_flash_forward", "gwd_mha_flash_backward",
     "gwd_ref_scores_forward", "gwd_ref_scores_backward", "gwd_ref_mix_forward", "gwd_ref_mix_backward", "gwd_unpad_add_batch", "gwd_stem_pack", "gwd_stem_forward", "gwd_pos_sine", "gwd_silog_finalize", "gwd_psp_pool_forward", "gwd_psp_pool_backward",
+    "gwd_match_cost", "gwd_set_losses_forward", "gwd_set_losses_backward",
 ]
 
 
@@ -167,6 +168,9 @@ class HipLibrary:
         L.gwd_layernorm_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
         L.gwd_unpad_add_batch.argtypes = [ctypes.POINTER(UnpadJob), i32, vp]
         L.gwd_silog_finalize.argtypes = [vp, f32, f32, vp, vp]
+        L.gwd_match_cost.argtypes = [vp] * 5 + [i32] * 6 + [f32, f32, vp]
+        L.gwd_set_losses_forward.argtypes = [vp] * 9 + [f32] + [vp] * 4 + [i32] * 6 + [vp]
+        L.gwd_set_losses_backward.argtypes = [vp] * 8 + [f32] + [vp] * 6 + [i32] * 6 + [vp]
         L.gwd_psp_pool_forward.argtypes = [vp] * 5 + [i32] * 5 + [vp]
         L.gwd_psp_pool_backward.argtypes = [vp] * 6 + [i32] * 6 + [vp]
         L.gwd_pos_sine.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -581,6 +585,33 @@ class HipLibrary:
         self._check(self.lib.gwd_certain_sample(_ptr(small), _ptr(large), _ptr(coords), B, hs, ws, H, W, _ptr(edges),
                                                 edges.numel() - 1, sample_num, self._stream(small, large, coords)),
                     "gwd_certain_sample")
+
+    def match_cost(self, logits, lines, tgt_lines, tgt_labels, cost, w_line, w_class):
+        """cost (L,B,Q,cap) of matcher.py:52-70 from logits (L,B,Q,K), lines (L,B,Q,D), padded targets (cap,D) / (cap,) int64."""
+        L_, B, Q, K = logits.shape
+        D, cap = lines.shape[-1], tgt_lines.shape[0]
+        if tgt_labels.dtype != torch.int64 or tuple(cost.shape) != (L_, B, Q, cap) or any(t.dtype != torch.float32 for t in (logits, lines, tgt_lines, cost)):
+            raise ValueError("match_cost: fp32 tensors, int64 labels and cost (L,B,Q,cap) expected")
+        self._check(self.lib.gwd_match_cost(_ptr(logits), _ptr(lines), _ptr(tgt_lines), _ptr(tgt_labels), _ptr(cost), L_, B, Q, cap, K, D,
+                                            w_line, w_class, self._stream(logits, lines, cost)), "gwd_match_cost")
+
+    def set_losses_forward(self, logits, lines, tgt_lines, tgt_labels, bidx, valid, qot, class_weight, num_items, world, target_class, ce, l1, wsum):
+        L_, B, Q, K = logits.shape
+        D, cap = lines.shape[-1], tgt_lines.shape[0]
+        if any(t.dtype != torch.int32 for t in (bidx, valid, qot, target_class)) or tgt_labels.dtype != torch.int64:
+            raise ValueError("set_losses_forward: int32 bidx / valid / qot / target_class and int64 labels expected")
+        self._check(self.lib.gwd_set_losses_forward(_ptr(logits), _ptr(lines), _ptr(tgt_lines), _ptr(tgt_labels), _ptr(bidx), _ptr(valid), _ptr(qot),
+                                                    _ptr(class_weight), _ptr(num_items), float(world), _ptr(target_class), _ptr(ce), _ptr(l1), _ptr(wsum),
+                                                    L_, B, Q, cap, K, D, self._stream(logits, lines, ce, l1)), "gwd_set_losses_forward")
+
+    def set_losses_backward(self, logits, lines, tgt_lines, bidx, valid, qot, class_weight, num_items, world, target_class, wsum, g_ce, g_l1,
+                            dlogits, dlines):
+        L_, B, Q, K = logits.shape
+        D, cap = lines.shape[-1], tgt_lines.shape[0]
+        self._check(self.lib.gwd_set_losses_backward(_ptr(logits), _ptr(lines), _ptr(tgt_lines), _ptr(bidx), _ptr(valid), _ptr(qot), _ptr(class_weight),
+                                                     _ptr(num_items), float(world), _ptr(target_class), _ptr(wsum), _ptr(g_ce), _ptr(g_l1),
+                                                     _ptr(dlogits), _ptr(dlines), L_, B, Q, cap, K, D, self._stream(logits, lines, dlogits, dlines)),
+                    "gwd_set_losses_backward")
 
     def lsap(self, cost, col_offsets, out, max_targets):
         """cost (layers,B,Q,sumT) fp32; col_offsets (B+1,) int32 DEVICE data (image b owns columns [off[b], off[b+1]),

@@ -277,6 +277,26 @@ typedef struct gwd_prep_job {
 } gwd_prep_job;
 int gwd_weight_prep_batch(const gwd_prep_job *jobs, int32_t n_jobs, int32_t total_blocks, void *stream);
 
+/* The set criterion of the line branch around the device LSAP (gwd_lsap), on PADDED targets (cap columns: column t belongs to image
+ * bidx[t], valid[t] = 0 marks padding; the LSAP gives padding columns the dummy query Q).  All tensors fp32 unless noted; K = classes
+ * incl. "no object" (<= 8), D = line coordinates (<= 8), else -4.
+ *   gwd_match_cost: cost (L,B,Q,cap) = w_line * L1(lines (L,B,Q,D), tgt_lines (cap,D)) - w_class * softmax(logits (L,B,Q,K))[tgt_labels
+ *     (cap, int64)]  (HungarianMatcher_Line.forward, src/models/matcher.py:52-70).
+ *   gwd_set_losses_forward: per layer l: target_class (L,B,Q) int32 (the matched target's label at query qot[l][t], K-1 elsewhere),
+ *     ce[l] = sum(nll * w) / sum(w) with w = class_weight[target class], wsum[l] = sum(w), l1[l] = sum over valid t of
+ *     |lines[l, bidx[t], min(qot, Q-1)] - tgt_lines[t]|_1 / max(num_items[0] / world, 1)   (src/models/glassrgbd.py:160-170,231-244).
+ *   gwd_set_losses_backward: dlogits (fully written) and dlines (ADDED to: caller zeroes) from g_ce[L] / g_l1[L] (either may be NULL). */
+int gwd_match_cost(const float *logits, const float *lines, const float *tgt_lines, const int64_t *tgt_labels, float *cost, int32_t L,
+                   int32_t B, int32_t Q, int32_t cap, int32_t K, int32_t D, float w_line, float w_class, void *stream);
+int gwd_set_losses_forward(const float *logits, const float *lines, const float *tgt_lines, const int64_t *tgt_labels, const int32_t *bidx,
+                           const int32_t *valid, const int32_t *qot, const float *class_weight, const float *num_items, float world,
+                           int32_t *target_class, float *ce, float *l1, float *wsum, int32_t L, int32_t B, int32_t Q, int32_t cap,
+                           int32_t K, int32_t D, void *stream);
+int gwd_set_losses_backward(const float *logits, const float *lines, const float *tgt_lines, const int32_t *bidx, const int32_t *valid,
+                            const int32_t *qot, const float *class_weight, const float *num_items, float world,
+                            const int32_t *target_class, const float *wsum, const float *g_ce, const float *g_l1, float *dlogits,
+                            float *dlines, int32_t L, int32_t B, int32_t Q, int32_t cap, int32_t K, int32_t D, void *stream);
+
 /* Padding mask of one feature level + sine position embeddings from it (src/models/backbone.py:81-88: F.interpolate(nearest) of the
  * batch mask; src/models/position_encoding.py:28-48: PositionEmbeddingSine).  Two stages, either may be skipped:
  *   mask_full != NULL: mask_level (B,h,w) u8 = nearest-resized mask_full (B,H,W) u8 (non-zero = padding), counts (B,h,w,2) int16 =

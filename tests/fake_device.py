@@ -310,6 +310,44 @@ class FakeDevice:
         mean.copy_(mu)
         rstd.copy_(rs)
 
+    def match_cost(self, logits, lines, tgt_lines, tgt_labels, cost, w_line, w_class):
+        prob = logits.softmax(-1)
+        l1 = (lines[..., None, :] - tgt_lines).abs().sum(-1)
+        cost.copy_(w_line * l1 + w_class * (-prob[..., tgt_labels]))
+
+    def set_losses_forward(self, logits, lines, tgt_lines, tgt_labels, bidx, valid, qot, class_weight, num_items, world, target_class, ce, l1, wsum):
+        L_, B, Q, K = logits.shape
+        li, bi, qi = torch.arange(L_)[:, None], bidx.long()[None].expand(L_, -1), qot.long()
+        tc = torch.full((L_, B, Q + 1), K - 1, dtype=torch.int64)
+        tc[li, bi, qi] = tgt_labels[None].expand(L_, -1)
+        tc = tc[:, :, :Q]
+        nll = F.cross_entropy(logits.reshape(L_ * B, Q, K).transpose(1, 2), tc.reshape(L_ * B, Q), reduction="none")
+        w = class_weight[tc.reshape(L_ * B, Q)]
+        ce.copy_((nll * w).reshape(L_, -1).sum(1) / w.reshape(L_, -1).sum(1))
+        wsum.copy_(w.reshape(L_, -1).sum(1))
+        n = torch.clamp(num_items / world, min=1.0)
+        diff = (lines[li, bi, qi.clamp(max=Q - 1)] - tgt_lines[None]).abs().sum(-1)
+        l1.copy_((diff * valid.float()[None]).sum(1) / n)
+        target_class.copy_(tc.to(torch.int32))
+
+    def set_losses_backward(self, logits, lines, tgt_lines, bidx, valid, qot, class_weight, num_items, world, target_class, wsum, g_ce, g_l1,
+                            dlogits, dlines):
+        L_, B, Q, K = logits.shape
+        lg, ln = logits.detach().clone().requires_grad_(True), lines.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            tc = target_class.long()
+            nll = F.cross_entropy(lg.reshape(L_ * B, Q, K).transpose(1, 2), tc.reshape(L_ * B, Q), reduction="none")
+            w = class_weight[tc.reshape(L_ * B, Q)]
+            ce = (nll * w).reshape(L_, -1).sum(1) / w.reshape(L_, -1).sum(1)
+            n = torch.clamp(num_items / world, min=1.0)
+            li, bi, qi = torch.arange(L_)[:, None], bidx.long()[None].expand(L_, -1), qot.long()
+            diff = (ln[li, bi, qi.clamp(max=Q - 1)] - tgt_lines[None]).abs().sum(-1)
+            l1 = (diff * valid.float()[None]).sum(1) / n
+            tot = (ce * (g_ce if g_ce is not None else torch.zeros(L_))).sum() + (l1 * (g_l1 if g_l1 is not None else torch.zeros(L_))).sum()
+            gl, gn = torch.autograd.grad(tot, [lg, ln], allow_unused=True)
+        dlogits.copy_(gl if gl is not None else torch.zeros_like(logits))
+        dlines.add_(gn if gn is not None else torch.zeros_like(lines))
+
     def pos_counts(self, mask_full, mask_level, counts):
         h, w = mask_level.shape[1:]
         m = F.interpolate(mask_full.bool()[None].float(), size=(h, w)).to(torch.bool)[0]

@@ -975,3 +975,32 @@ def test_psp_pools_equal_four_average_pools(dev, shape, dtype):
     for p, r in zip(pooled, ref):
         assert p.shape == r.permute(0, 2, 3, 1).shape and rel(p, r.permute(0, 2, 3, 1)) < TOL[dtype] * 0.3
     assert rel(x.grad, want) < TOL[dtype] * 0.3
+
+
+@pytest.mark.parametrize("sizes", [[7] * 8, [1, 12, 0, 5], [64, 3]])
+def test_fused_set_criterion_equals_the_torch_formulation(dev, sizes, monkeypatch):
+    """gwd_match_cost + gwd_lsap + gwd_set_losses_* (one autograd node) against forward_packed's torch formulation (GWD_FUSED_SETLOSS=0):
+    same assignment, same 2 x layers loss terms, same gradients w.r.t. logits and lines - ragged target counts incl. an empty image."""
+    from gw_depth_amd.criteria import HungarianMatcherLine as HungarianMatcher, SetCriterion, pack_targets
+    torch.manual_seed(11)
+    L_, B, Q = 6, len(sizes), 100
+    crit = SetCriterion(1, {}, 0.1, ["lines_labels", "lines"], HungarianMatcher(1.0, 5.0)).cuda()
+    targets = [{"labels": torch.zeros(n, dtype=torch.int64, device="cuda"), "lines": torch.rand(n, 6, device="cuda")} for n in sizes]
+    packed = pack_targets(targets, "cuda")
+    logits0, lines0 = torch.randn(L_, B, Q, 2, device="cuda"), torch.rand(L_, B, Q, 6, device="cuda")
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GWD_FUSED_SETLOSS", mode)
+        lg, ln = logits0.clone().requires_grad_(True), lines0.clone().requires_grad_(True)
+        outs = {"pred_logits": lg[0], "pred_lines": ln[0], "aux_outputs": [{"pred_logits": lg[i], "pred_lines": ln[i]} for i in range(1, L_)]}
+        losses = crit.forward_packed(outs, packed)
+        total = sum(v * (1.0 + 0.1 * i) for i, (k, v) in enumerate(sorted(losses.items())))
+        total.backward()
+        torch.cuda.synchronize()
+        res[mode] = ({k: float(v) for k, v in losses.items()}, lg.grad.clone(), ln.grad.clone(), crit.last_query_of_target.clone())
+    a, b = res["1"], res["0"]
+    assert torch.equal(a[3], b[3])
+    assert set(a[0]) == set(b[0]) and len(a[0]) == 2 * L_
+    for k in a[0]:
+        assert abs(a[0][k] - b[0][k]) <= 1e-5 * max(1.0, abs(b[0][k])), (k, a[0][k], b[0][k])
+    assert rel(a[1], b[1]) < 1e-5 and rel(a[2], b[2]) < 1e-5
