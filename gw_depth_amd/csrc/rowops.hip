@@ -378,7 +378,9 @@ __global__ __launch_bounds__(NWV * 64) void layernorm_bwd_vec_kernel(const T *__
                                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                 const float *__restrict__ mean, const float *__restrict__ rstd,
                                                                 T *__restrict__ gx, float *__restrict__ dgamma,
-                                                                float *__restrict__ dbeta, int64_t rows, int C, int gelu, int ld) {
+                                                                float *__restrict__ dbeta, int64_t rows, int C, int gelu, int ld,
+                                                                const T *__restrict__ gskip) {
+    // gskip (may be NULL): a second gradient of x (x also feeds a skip connection: ops._LayerNormFn fan-out), added to gx here
     constexpr int VEC = VB / (int)sizeof(T), RPW = 64 / LPR;
     __shared__ float red[2][NWV][LPR * NCH * VEC];    // [gamma|beta][wave][channel slot]
     const int lane = threadIdx.x & 63, sub = lane % LPR, rsel = lane / LPR, wv = threadIdx.x >> 6;
@@ -434,9 +436,13 @@ __global__ __launch_bounds__(NWV * 64) void layernorm_bwd_vec_kernel(const T *__
         for (int c = 0; c < NCH; ++c) {
             if (!(okr && okc[c])) continue;
             alignas(16) T outv[VEC];
+            Raw<VB> rk = {};
+            if (gskip) rk = *(const Raw<VB> *)(gskip + r * ld + (sub + c * LPR) * VEC);
+            const T *pk = (const T *)&rk;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 float o = rs * (gw[c][e] - s1 - xh[c][e] * s2);
+                if (gskip) o += to_f32(pk[e]);
                 if (PAD && (sub + c * LPR) * VEC + e >= C) o = 0.f;
                 outv[e] = from_f32<T>(o);
             }
@@ -673,7 +679,7 @@ int launch_ln_fwd_vec(const T *x, const float *ga, const float *be, T *y, float 
 
 template <typename T, int VB, bool PAD = false>
 int launch_ln_bwd_vec(const T *gy, const T *x, const float *ga, const float *be, const float *mean, const float *rstd, T *gx,
-                      float *dg, float *db, int64_t rows, int C, int gelu, int ld, hipStream_t s) {
+                      float *dg, float *db, int64_t rows, int C, int gelu, int ld, const T *gskip, hipStream_t s) {
     constexpr int VEC = VB / (int)sizeof(T);
     if (ld % VEC) return -5;
     const int need = ld / VEC;
@@ -683,12 +689,12 @@ int launch_ln_bwd_vec(const T *gy, const T *x, const float *ga, const float *be,
         if (LPR * NCH * VEC <= 512 && dg) {                     /* narrow rows: 16-wave workgroups, one per CU */   \
             int grid = row_grid(wv, 16);                                                                            \
             if (grid > 256) grid = 256;                                                                             \
-            layernorm_bwd_vec_kernel<T, LPR, NCH, VB, 16, PAD><<<grid, 1024, 0, s>>>(gy, x, ga, be, mean, rstd, gx, dg, db, rows, C, gelu, ld); \
+            layernorm_bwd_vec_kernel<T, LPR, NCH, VB, 16, PAD><<<grid, 1024, 0, s>>>(gy, x, ga, be, mean, rstd, gx, dg, db, rows, C, gelu, ld, gskip); \
             return 0;                                                                                               \
         }                                                                                                           \
         int grid = row_grid(wv, 4);                                                                                 \
         if (grid > 768) grid = 768;                                                                                 \
-        layernorm_bwd_vec_kernel<T, LPR, NCH, VB, 4, PAD><<<grid, 256, 0, s>>>(gy, x, ga, be, mean, rstd, gx, dg, db, rows, C, gelu, ld); \
+        layernorm_bwd_vec_kernel<T, LPR, NCH, VB, 4, PAD><<<grid, 256, 0, s>>>(gy, x, ga, be, mean, rstd, gx, dg, db, rows, C, gelu, ld, gskip); \
         return 0;                                                                                                   \
     }
     if (need <= 8) LN_BWD(8, 1)
@@ -740,7 +746,7 @@ extern "C" int gwd_layernorm_forward(const void *x, const float *gamma, const fl
 
 extern "C" int gwd_layernorm_backward(const void *gy, const void *x, const float *gamma, const float *beta,
                                       const float *mean, const float *rstd, void *gx, float *dgamma, float *dbeta,
-                                      int64_t rows, int32_t C, int32_t ld, int32_t gelu, int32_t dtype, void *stream) {
+                                      int64_t rows, int32_t C, int32_t ld, int32_t gelu, const void *gskip, int32_t dtype, void *stream) {
     if (!gy || !x || !gx || !mean || !rstd || rows < 0 || C <= 0 || C > 64 * MAX_PER_LANE) return -1;
     if ((dgamma == nullptr) != (dbeta == nullptr)) return -1;
     if (ld == 0) ld = C;
@@ -749,19 +755,20 @@ extern "C" int gwd_layernorm_backward(const void *gy, const void *x, const float
     hipStream_t s = (hipStream_t)stream;
     if (ld != C) {
         int rc = -5;
-        if (dtype == GWD_BF16 && ld % 8 == 0) rc = launch_ln_bwd_vec<__bf16, 16, true>((const __bf16 *)gy, (const __bf16 *)x, gamma, beta, mean, rstd, (__bf16 *)gx, dgamma, dbeta, rows, C, gelu, ld, s);
-        else if (dtype == GWD_F32 && ld % 4 == 0) rc = launch_ln_bwd_vec<float, 16, true>((const float *)gy, (const float *)x, gamma, beta, mean, rstd, (float *)gx, dgamma, dbeta, rows, C, gelu, ld, s);
+        if (dtype == GWD_BF16 && ld % 8 == 0) rc = launch_ln_bwd_vec<__bf16, 16, true>((const __bf16 *)gy, (const __bf16 *)x, gamma, beta, mean, rstd, (__bf16 *)gx, dgamma, dbeta, rows, C, gelu, ld, (const __bf16 *)gskip, s);
+        else if (dtype == GWD_F32 && ld % 4 == 0) rc = launch_ln_bwd_vec<float, 16, true>((const float *)gy, (const float *)x, gamma, beta, mean, rstd, (float *)gx, dgamma, dbeta, rows, C, gelu, ld, (const float *)gskip, s);
         if (rc == 0) { GWD_CHECK_LAUNCH(); return 0; }
         return -4;
     }
     {
         int rc = -5;
-        if (dtype == GWD_BF16 && C % 8 == 0) rc = launch_ln_bwd_vec<__bf16, 16>((const __bf16 *)gy, (const __bf16 *)x, gamma, beta, mean, rstd, (__bf16 *)gx, dgamma, dbeta, rows, C, gelu, ld, s);
-        else if (dtype == GWD_BF16 && C % 4 == 0) rc = launch_ln_bwd_vec<__bf16, 8>((const __bf16 *)gy, (const __bf16 *)x, gamma, beta, mean, rstd, (__bf16 *)gx, dgamma, dbeta, rows, C, gelu, ld, s);
-        else if (dtype == GWD_F32 && C % 4 == 0) rc = launch_ln_bwd_vec<float, 16>((const float *)gy, (const float *)x, gamma, beta, mean, rstd, (float *)gx, dgamma, dbeta, rows, C, gelu, ld, s);
-        else if (dtype == GWD_F32 && C % 2 == 0) rc = launch_ln_bwd_vec<float, 8>((const float *)gy, (const float *)x, gamma, beta, mean, rstd, (float *)gx, dgamma, dbeta, rows, C, gelu, ld, s);
+        if (dtype == GWD_BF16 && C % 8 == 0) rc = launch_ln_bwd_vec<__bf16, 16>((const __bf16 *)gy, (const __bf16 *)x, gamma, beta, mean, rstd, (__bf16 *)gx, dgamma, dbeta, rows, C, gelu, ld, (const __bf16 *)gskip, s);
+        else if (dtype == GWD_BF16 && C % 4 == 0) rc = launch_ln_bwd_vec<__bf16, 8>((const __bf16 *)gy, (const __bf16 *)x, gamma, beta, mean, rstd, (__bf16 *)gx, dgamma, dbeta, rows, C, gelu, ld, (const __bf16 *)gskip, s);
+        else if (dtype == GWD_F32 && C % 4 == 0) rc = launch_ln_bwd_vec<float, 16>((const float *)gy, (const float *)x, gamma, beta, mean, rstd, (float *)gx, dgamma, dbeta, rows, C, gelu, ld, (const float *)gskip, s);
+        else if (dtype == GWD_F32 && C % 2 == 0) rc = launch_ln_bwd_vec<float, 8>((const float *)gy, (const float *)x, gamma, beta, mean, rstd, (float *)gx, dgamma, dbeta, rows, C, gelu, ld, (const float *)gskip, s);
         if (rc == 0) { GWD_CHECK_LAUNCH(); return 0; }
     }
+    if (gskip) return -4;                    // the generic kernel has no skip input: the caller adds it
     int grid = row_grid(rows, 4);
     if (grid > 1024) grid = 1024;
     DISPATCH_T(dtype,

@@ -165,7 +165,7 @@ class HipLibrary:
         L.gwd_anchor_depth_backward.argtypes = [vp, vp, vp, vp, vp, i32, i64, i32, i32, vp]
         L.gwd_colsum_batch.argtypes = [ctypes.POINTER(ColsumJob), i32, i32, vp]
         L.gwd_layernorm_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
-        L.gwd_layernorm_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
+        L.gwd_layernorm_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, i32, vp]
         L.gwd_unpad_add_batch.argtypes = [ctypes.POINTER(UnpadJob), i32, vp]
         L.gwd_silog_finalize.argtypes = [vp, f32, f32, vp, vp]
         L.gwd_match_cost.argtypes = [vp] * 5 + [i32] * 6 + [f32, f32, vp]
@@ -315,10 +315,18 @@ class HipLibrary:
                                                    rows, C, ld, int(gelu), dtype_code(x), self._stream(x, y)),
                     "gwd_layernorm_forward")
 
-    def layernorm_backward(self, gy, x, gamma, beta, mean, rstd, gx, dgamma, dbeta, rows, C, gelu, ld=0):
-        self._check(self.lib.gwd_layernorm_backward(_ptr(gy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd),
-                                                    _ptr(gx), _ptr(dgamma), _ptr(dbeta), rows, C, ld, int(gelu),
-                                                    dtype_code(x), self._stream(gy, x, gx)), "gwd_layernorm_backward")
+    def layernorm_backward(self, gy, x, gamma, beta, mean, rstd, gx, dgamma, dbeta, rows, C, gelu, ld=0, gskip=None):
+        """gskip: a second gradient of x, added to gx in the kernel; returns False when it could not be (no vector kernel for the
+        shape: the call has then run WITHOUT it and the caller adds it)."""
+        rc = self.lib.gwd_layernorm_backward(_ptr(gy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(gx), _ptr(dgamma),
+                                             _ptr(dbeta), rows, C, ld, int(gelu), _ptr(gskip), dtype_code(x), self._stream(gy, x, gx))
+        if rc == -4 and gskip is not None:
+            self._check(self.lib.gwd_layernorm_backward(_ptr(gy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(gx), _ptr(dgamma),
+                                                        _ptr(dbeta), rows, C, ld, int(gelu), None, dtype_code(x), self._stream(gy, x, gx)),
+                        "gwd_layernorm_backward")
+            return False
+        self._check(rc, "gwd_layernorm_backward")
+        return True
 
     def pos_counts(self, mask_full, mask_level, counts):
         """mask_full (B,H,W) bool/u8 -> mask_level (B,h,w) bool (nearest), counts (B,h,w,2) int16 (gwd_pos_sine, first stage)."""

@@ -515,7 +515,8 @@ class SwinBlock(nn.Module):
     def forward(self, x, H, W, ref_coors=None, ref_pos=None, dtok=None, stok=None):
         B, L, C = x.shape
         shift = self.shift
-        xn = self.norm1(x).view(B, H, W, C)
+        xn, x = self.norm1(x, fan=True)                      # x again, for the skip below (pre-norm block: x feeds the norm AND the skip)
+        xn = xn.view(B, H, W, C)
         Hp, Wp = (H + WS - 1) // WS * WS, (W + WS - 1) // WS * WS
         mask = shift_regions(Hp, Wp, x.device) if shift else None
         if dtok is None:
@@ -531,18 +532,20 @@ class SwinBlock(nn.Module):
             aw = self.attn(ops.window_gather(xn, shift), x_ref, mask)          # == window_partition(sx), one index-remapping copy
         else:
             tC = dtok.shape[-1]
-            dn = ops.window_gather(self.norm_depth1(dtok).view(B, H, W, tC), shift)
-            sn = ops.window_gather(self.norm_seg1(stok).view(B, H, W, tC), shift)
+            dn, dtok = self.norm_depth1(dtok, fan=True)
+            sn, stok = self.norm_seg1(stok, fan=True)
+            dn = ops.window_gather(dn.view(B, H, W, tC), shift)
+            sn = ops.window_gather(sn.view(B, H, W, tC), shift)
             aw, dw, sw = self.attn(ops.window_gather(xn, shift), dn, sn, mask)
             x = ops.window_scatter(aw, B, H, W, shift, residual=x).view(B, H * W, C)
-            x = self.mlp(self.norm2(x), residual=x)
+            x = self.mlp(*self.norm2(x, fan=True))
             d = ops.window_scatter(dw, B, H, W, shift, residual=dtok).view(B, H * W, tC)
-            d = self.mlp_depth(self.norm_depth2(d), residual=d)
+            d = self.mlp_depth(*self.norm_depth2(d, fan=True))
             s = ops.window_scatter(sw, B, H, W, shift, residual=stok).view(B, H * W, tC)
-            s = self.mlp_seg(self.norm_seg2(s), residual=s)
+            s = self.mlp_seg(*self.norm_seg2(s, fan=True))
             return x, d, s
         x = ops.window_scatter(aw, B, H, W, shift, residual=x).view(B, H * W, C)     # window reverse + un-shift + crop + skip
-        x = self.mlp(self.norm2(x), residual=x)
+        x = self.mlp(*self.norm2(x, fan=True))              # mlp(norm(x), residual = x)
         return x, None, None
 
 

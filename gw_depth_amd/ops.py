@@ -587,9 +587,10 @@ def linear(x, w, bias=None, act=ACT_NONE, rows=None, residual=None, mult=None):
 
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, gelu, sinks, residual):
+    def forward(ctx, x, gamma, beta, gelu, sinks, residual, fanout=False):
         lib = _lib()
         ctx.sinks = sinks
+        ctx.fan = bool(fanout)
         ctx.has_res = residual is not None
         x = x.contiguous()
         ld = x.shape[-1]
@@ -604,11 +605,14 @@ class _LayerNormFn(torch.autograd.Function):
                               ld=0 if ld == C else ld)
         ctx.save_for_backward(x, g, b, mean, rstd)
         ctx.gelu = gelu
+        if fanout:
+            return y, x.view_as(x)        # x again for its second consumer (the block's skip): see _ConvFn.forward
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, *g_fan):
         lib = _lib()
+        g_in = g_fan[0].contiguous() if (ctx.fan and g_fan and g_fan[0] is not None) else None
         x, g, b, mean, rstd = ctx.saved_tensors
         ld = x.shape[-1]
         C = g.shape[0] if g is not None else ld
@@ -622,23 +626,28 @@ class _LayerNormFn(torch.autograd.Function):
         elif g is not None:
             dg = torch.zeros(C, dtype=torch.float32, device=x.device)
             db = torch.zeros(C, dtype=torch.float32, device=x.device)
-        lib.layernorm_backward(gy, x, g, b, mean, rstd, gx, dg, db, rows, C, ctx.gelu, ld=0 if ld == C else ld)
+        if not lib.layernorm_backward(gy, x, g, b, mean, rstd, gx, dg, db, rows, C, ctx.gelu, ld=0 if ld == C else ld, gskip=g_in):
+            gx = gx + g_in
         gres = gy if ctx.has_res else None                # y = LN(x) + residual: the skip gets the incoming gradient as is
         if direct:
             for h in (h1, h2):
                 if h is not None:
                     h()
-            return gx, None, None, None, None, gres
-        return gx, dg, db, None, None, gres
+            return gx, None, None, None, None, gres, None
+        return gx, dg, db, None, None, gres, None
 
 
-def layer_norm(x, gamma, beta, gelu=False, residual=None):
-    """LayerNorm over the last dim (eps 1e-5) with optional fused exact GELU; residual (same shape) is added afterwards."""
+def layer_norm(x, gamma, beta, gelu=False, residual=None, fanout=False):
+    """LayerNorm over the last dim (eps 1e-5) with optional fused exact GELU; residual (same shape) is added afterwards.
+    fanout: return (y, x') with x' = x for the OTHER consumer of the input (the skip of a pre-norm block): x's two gradients then
+    meet inside the LayerNorm backward kernel instead of an accumulation pass."""
     sinks = None
     if gamma is not None:
         sg, sb = _sink(gamma), _sink(beta)
         sinks = (sg, sb) if (sg is not None and sb is not None) else None
-    return _LayerNormFn.apply(x, gamma, beta, bool(gelu), sinks, residual)
+    if fanout and os.environ.get("GWD_LN_FANOUT", "1") == "0":
+        return _LayerNormFn.apply(x, gamma, beta, bool(gelu), sinks, residual, False), x
+    return _LayerNormFn.apply(x, gamma, beta, bool(gelu), sinks, residual, bool(fanout))
 
 
 class _SoftmaxFn(torch.autograd.Function):

@@ -137,9 +137,11 @@ int gwd_act_backward_colsum(const void *gy, const void *ref, void *gx, float *db
  * needs ld to be a multiple of 16 bytes, else -4 (C itself may be anything).                                      */
 int gwd_layernorm_forward(const void *x, const float *gamma, const float *beta, const void *residual, void *y, float *mean,
                           float *rstd, int64_t rows, int32_t C, int32_t ld, int32_t gelu, int32_t dtype, void *stream);
+/* gskip (may be NULL): [rows][ld], a second gradient of x added to gx (x also feeds a skip connection); returns -4 when the shape
+ * has no vector kernel (the caller then adds it).                                                                   */
 int gwd_layernorm_backward(const void *gy, const void *x, const float *gamma, const float *beta,
                            const float *mean, const float *rstd, void *gx, float *dgamma, float *dbeta,
-                           int64_t rows, int32_t C, int32_t ld, int32_t gelu, int32_t dtype, void *stream);
+                           int64_t rows, int32_t C, int32_t ld, int32_t gelu, const void *gskip, int32_t dtype, void *stream);
 
 /* Softmax over the last dim (row length L <= 1024), forward and backward.
  * Replaces F.softmax in src/models/multi_head_attention.py:366, multiscale_transformerr.py:307,

@@ -388,7 +388,11 @@ class FakeDevice:
         for src, dst, N, taps, G, Cg, Cgp in jobs:
             dst.view(N, taps, G, Cg).add_(src.view(-1, taps, G, Cgp)[:N, :, :, :Cg])
 
-    def layernorm_backward(self, gy, x, gamma, beta, mean, rstd, gx, dgamma, dbeta, rows, C, gelu, ld=0):
+    def layernorm_backward(self, gy, x, gamma, beta, mean, rstd, gx, dgamma, dbeta, rows, C, gelu, ld=0, gskip=None):
+        if gskip is not None:
+            self.layernorm_backward(gy, x, gamma, beta, mean, rstd, gx, dgamma, dbeta, rows, C, gelu, ld)
+            gx.add_(gskip.reshape(gx.shape).to(gx.dtype))
+            return True
         if ld and ld != C:
             gxv = gx.view(rows, ld)
             gxv.zero_()

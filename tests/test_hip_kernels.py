@@ -185,6 +185,13 @@ def test_layernorm(dev, rows, C, gelu, affine, dtype):
     assert rel(gx, gx_r) < TOL[dtype]
     if affine:
         assert rel(dg, dg_r) < TOL[dtype] and rel(db, db_r) < TOL[dtype]
+    gsk = rnd(rows, C, dtype=dtype, seed=6)                      # second gradient of x (fan-out), added inside the kernel
+    gx2, dg2, db2 = torch.empty_like(x).cuda(), torch.zeros(C).cuda(), torch.zeros(C).cuda()
+    fused = dev.layernorm_backward(gy.cuda(), x.cuda(), cu(ga), cu(be), m, r, gx2, dg2 if affine else None, db2 if affine else None,
+                                   rows, C, gelu, gskip=gsk.cuda())
+    want = gx_r.float() + gsk.float()
+    assert rel(gx2.float() + (0 if fused else gsk.cuda().float()), want) < TOL[dtype]
+    assert fused == (C % (4 if dtype == torch.bfloat16 else 2) == 0)
     res = rnd(rows, C, dtype=dtype, seed=5)                      # skip connection added in the same kernel
     y2_r = torch.empty_like(x)
     fake.layernorm_forward(x, ga, be, y2_r, m_r, r_r, rows, C, gelu, residual=res)
