@@ -626,7 +626,8 @@ class _LayerNormFn(torch.autograd.Function):
         elif g is not None:
             dg = torch.zeros(C, dtype=torch.float32, device=x.device)
             db = torch.zeros(C, dtype=torch.float32, device=x.device)
-        if not lib.layernorm_backward(gy, x, g, b, mean, rstd, gx, dg, db, rows, C, ctx.gelu, ld=0 if ld == C else ld, gskip=g_in):
+        fused = lib.layernorm_backward(gy, x, g, b, mean, rstd, gx, dg, db, rows, C, ctx.gelu, ld=0 if ld == C else ld, gskip=g_in)
+        if g_in is not None and fused is False:            # no vector kernel for this width: the skip gradient is added here
             gx = gx + g_in
         gres = gy if ctx.has_res else None                # y = LN(x) + residual: the skip gets the incoming gradient as is
         if direct:
