@@ -42,8 +42,8 @@ class Linear(nn.Module):
         nn.init.trunc_normal_(self.weight, std=0.02)
         self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
 
-    def forward(self, x, act=ops.ACT_NONE, residual=None, mult=None):
-        return ops.linear(x, self.weight, self.bias, act, residual=residual, mult=mult)
+    def forward(self, x, act=ops.ACT_NONE, residual=None, mult=None, fan=False):
+        return ops.linear(x, self.weight, self.bias, act, residual=residual, mult=mult, fanout=fan)
 
 
 class LayerNorm(nn.Module):

@@ -232,7 +232,10 @@ class MultiheadAttention(nn.Module):
         amult = pool.take(B, H, L, S) if pool is not None else None
         if query is key:
             qk = ops.linear(query, W, b, rows=(0, 2 * E))
-            v = ops.linear(value, W, b, rows=(2 * E, 3 * E))
+            if residual is value:            # value also feeds the skip: both gradients of it meet in the v projection's data gradient
+                v, residual = ops.linear(value, W, b, rows=(2 * E, 3 * E), fanout=True)
+            else:
+                v = ops.linear(value, W, b, rows=(2 * E, 3 * E))
             fused = ops.mha_core(qk, None, v, H, key_padding_mask, self.dropout, self.training, scale, amult)
             q, k = qk[..., :E], qk[..., E:]
         else:
@@ -265,7 +268,7 @@ class EncoderLayer(nn.Module):
         qk = x + pos
         if pool is not None and pool.buf is not None:      # dropout multipliers + skips inside the producing GEMMs' epilogues
             x = self.norm1(self.self_attn(qk, qk, x, kpm, pool, residual=x, out_mult=pool.take(*x.shape)))
-            h = self.linear1(x, ACT_RELU, mult=pool.take(*x.shape[:-1], self.linear1.weight.shape[0]))
+            h, x = self.linear1(x, ACT_RELU, mult=pool.take(*x.shape[:-1], self.linear1.weight.shape[0]), fan=True)    # x again, for the skip
             return self.norm2(self.linear2(h, residual=x, mult=pool.take(*x.shape)))
         x = self.norm1(x + F.dropout(self.self_attn(qk, qk, x, kpm), self.p, self.training))
         ff = self.linear2(F.dropout(self.linear1(x, ACT_RELU), self.p, self.training))
@@ -287,7 +290,7 @@ class DecoderLayer(nn.Module):
         if pool is not None and pool.buf is not None:
             tgt = self.norm1(self.self_attn(qk, qk, tgt, None, pool, residual=tgt, out_mult=pool.take(*tgt.shape)))
             tgt = self.norm2(self.multihead_attn(tgt + qpos, mem_pos, memory, kpm, pool, residual=tgt, out_mult=pool.take(*tgt.shape)))
-            h = self.linear1(tgt, ACT_RELU, mult=pool.take(*tgt.shape[:-1], self.linear1.weight.shape[0]))
+            h, tgt = self.linear1(tgt, ACT_RELU, mult=pool.take(*tgt.shape[:-1], self.linear1.weight.shape[0]), fan=True)
             return self.norm3(self.linear2(h, residual=tgt, mult=pool.take(*tgt.shape)))
         tgt = self.norm1(tgt + F.dropout(self.self_attn(qk, qk, tgt), self.p, self.training))
         t2 = self.multihead_attn(tgt + qpos, mem_pos, memory, kpm)
@@ -445,7 +448,7 @@ class WindowAttention(WindowAttnBase):
         ref_k = ops.row_affine(rq, self.diff_mu, self.diff_logsigma)              # mu + exp(logsigma) * x, (rB, nrf, C), :289-292
         ra = ops.ref_scores(qkv, ref_k, rB, self.scale)                          # (rB, nWin*N, nrf, heads): pixel-major map, :295-298
         for _ in range(3):                                                        # :299-302
-            upd = ops.conv2d(ra, self.ref_attn_diffusion.weight, self.ref_attn_diffusion.bias, pad=1)
+            upd, ra = ops.conv2d(ra, self.ref_attn_diffusion.weight, self.ref_attn_diffusion.bias, pad=1, fanout=True)     # ra again, for the skip
             ra = ops.inorm_gelu_residual(ra, upd, 1e-5)
         q_new = ops.ref_mix(ra, rv, HEADS).view(B_, N, HEADS, hd)      # softmax over the ref tokens, . ref_v; second *scale: in-kernel
         wpi = regions.shape[0] if regions is not None else 1

@@ -556,7 +556,7 @@ def conv2d(x, w, bias=None, *, stride=1, pad=0, act=ACT_NONE, act_scale=1.0, res
                          getattr(w, "_gwd_bf16", None), sinks if (sinks[0] or sinks[1]) else None, mult, bool(fanout))
 
 
-def linear(x, w, bias=None, act=ACT_NONE, rows=None, residual=None, mult=None):
+def linear(x, w, bias=None, act=ACT_NONE, rows=None, residual=None, mult=None, fanout=False):
     """x (..., K) @ w(N, K)^T + bias, optional fused activation; same kernel as conv2d (1x1, one pixel per row).
     rows=(r0, r1): use only that row range of a packed parameter (the q/k/v blocks of an attention in-projection);
     the gradient then goes straight into that slice of the parameter's flat gradient instead of through a
@@ -579,9 +579,12 @@ def linear(x, w, bias=None, act=ACT_NONE, rows=None, residual=None, mult=None):
     sinks = (None if ws is None else (ws[0].view(n, 1, 1, K), ws[1]), bs)
     res = None if residual is None else residual.reshape(-1, 1, 1, n)
     mul = None if mult is None else mult.reshape(-1, 1, 1, n)
+    fan = bool(fanout) and os.environ.get("GWD_FANOUT", "1") != "0"
     y = _ConvFn.apply(x2, w.view(n, 1, 1, K), bias, res, None, None, 1, 0, act, 1.0, None,
                       None if shadow is None else shadow.view(n, 1, 1, K),
-                      sinks if (sinks[0] or sinks[1]) else None, mul)
+                      sinks if (sinks[0] or sinks[1]) else None, mul, fan)
+    if fanout:                              # (y, x again for the input's second consumer): see _ConvFn.forward
+        return (y[0].view(*lead, n), y[1].view(x.shape)) if fan else (y.view(*lead, n), x)
     return y.view(*lead, n)
 
 

@@ -86,6 +86,10 @@ CASES = [
      "fwd <128,32,4,1,4,2>, M = 1 228 800; wgrad <32,128,1,4,4,0>"),
     ("decoder_conv2_32_32_3x3_elu", (4, 480, 640), 32, 32, 3, 1, 1, None, dict(act=hip.ACT_ELU),
      "fwd <128,32,4,1,4,0>, dgrad <..,1>, wgrad <32,128,1,4,4,1> at full resolution"),
+    ("refpoint_diffusion_16_16_3x3_residual", (8, 441, 40), 16, 16, 3, 1, 1, None, dict(residual=True),
+     "the same layer's data gradient with the skip gradient added in the tile kernel's epilogue (ops._ConvFn fan-out)"),
+    ("decoder_conv2_32_32_3x3_residual_elu", (2, 480, 640), 32, 32, 3, 1, 1, None, dict(shift=True, residual=True, act=hip.ACT_ELU),
+     "tconv_fwd<32,32> with shift + residual + ELU in the epilogue"),
     ("refpoint_diffusion_16_16_3x3_bias", (8, 441, 40), 16, 16, 3, 1, 1, None, dict(shift=True),
      "the 16-head score map of the 1/32 stage (multiscale_transformerr.py:299-302), 40 columns = a ragged second tile: halo-tiled kernels "
      "tconv_fwd<16,16> (forward, data gradient) and tconv_wgrad<16,16>, half-empty channel tiles"),
