@@ -50,3 +50,264 @@ def device_collate(samples, device="cuda", dtype=torch.float32, mean=MEAN, std=S
     if have_l:
         out["seg"] = seg.view(B, 1, H, W)
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# Second slice of the input pipeline: the GEOMETRIC transforms (flip, crop, resize) on the device, bit-exact with the Pillow calls
+# the reference makes (src/datasets/transforms_depth.py:59-372 through torchvision.transforms.functional on PIL images), and the
+# matching arithmetic on the line targets.  Decoding (PNG / JSON) and the colour jitter stay on the host.
+import math
+import random
+
+import numpy as np
+
+_PRECISION_BITS = 32 - 8 - 2
+
+
+def bilinear_tables(in_size, out_size):
+    """(bounds (out,2) int32, coefficients (out,ksize) int32) of Pillow's BILINEAR resize along one axis: triangle filter whose support
+    is scaled by max(1, in/out), normalised in double precision, rounded to 22 fractional bits (Resample.c: precompute_coeffs,
+    normalize_coeffs_8bpc).  Sums run tap by tap, as Pillow's loops do - the order matters for bit-exact coefficients."""
+    scale = in_size / out_size
+    fscale = max(scale, 1.0)
+    support = 1.0 * fscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    center = (np.arange(out_size, dtype=np.float64) + 0.5) * scale
+    xmin = np.maximum((center - support + 0.5).astype(np.int64), 0)              # (int) truncation of non-negative values / clamp at 0
+    xmin = np.where(center - support + 0.5 < 0, 0, xmin)
+    xmax = np.minimum((center + support + 0.5).astype(np.int64), in_size) - xmin
+    ss = 1.0 / fscale
+    w = np.zeros((out_size, ksize), dtype=np.float64)
+    ww = np.zeros(out_size, dtype=np.float64)
+    for t in range(ksize):
+        a = np.abs((t + xmin - center + 0.5) * ss)
+        wt = np.where((a < 1.0) & (t < xmax), 1.0 - a, 0.0)
+        w[:, t] = wt
+        ww = ww + wt
+    nz = ww != 0.0
+    w[nz] = w[nz] / ww[nz, None]
+    kk = (0.5 + w * (1 << _PRECISION_BITS)).astype(np.int64)                     # weights are >= 0: (int)(0.5 + w * 2^22)
+    kk[np.arange(ksize)[None, :] >= xmax[:, None]] = 0
+    return np.stack([xmin, xmax], axis=1).astype(np.int32), kk.astype(np.int32)
+
+
+def nearest_table(in_size, out_size):
+    """Source index per output index of Pillow's NEAREST resize: the coordinate a/2 + a + a + ... accumulated in double precision, one
+    addition per pixel, truncated (Geometry.c, scale-only affine transform)."""
+    a = in_size / out_size
+    steps = np.full(out_size, a, dtype=np.float64)
+    steps[0] = a * 0.5
+    return np.clip(np.add.accumulate(steps).astype(np.int64), 0, in_size - 1).astype(np.int32)
+
+
+def _flip_map(n, flipped):
+    return (n - 1, -1) if flipped else (0, 1)
+
+
+def device_resize_rgb(img, size, hflip=False, vflip=False):
+    """Image.resize(size[::-1], BILINEAR) of a uint8 (h,w,3) device image - which may be a crop window view img[i:i+h, j:j+w] of a
+    larger one - optionally flipped first (F.hflip / F.vflip): flip, crop and resize are one read of the source."""
+    lib = hip.library()
+    h, w, C = img.shape
+    oh, ow = int(size[0]), int(size[1])
+    if img.dtype != torch.uint8 or img.stride(2) != 1 or img.stride(1) != C:
+        raise ValueError("device_resize_rgb: a uint8 (h,w,C) image or a row-window view of one expected")
+    dev = img.device
+    rs = img.stride(0)
+    need_h, need_v = ow != w, oh != h
+    xb, xs = _flip_map(w, hflip)
+    yb, ys = _flip_map(h, vflip)
+    if not need_h and not need_v:
+        out = torch.empty((h, w, C), dtype=torch.uint8, device=dev)
+        yt = torch.from_numpy(np.arange(h, dtype=np.int32)[::-1].copy() if vflip else np.arange(h, dtype=np.int32)).to(dev)
+        xt = torch.from_numpy(np.arange(w, dtype=np.int32)[::-1].copy() if hflip else np.arange(w, dtype=np.int32)).to(dev)
+        lib.gather2d(img, out, yt, xt, rs, C)
+        return out
+    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cur, cur_rs, cur_h = img, rs, h
+    cyb, cys = yb, ys
+    bv = kv = None
+    if need_v:
+        bv, kv = bilinear_tables(h, oh)
+    if need_h:
+        bh, kh = bilinear_tables(w, ow)
+        first, last = (int(bv[0, 0]), int(bv[-1, 0] + bv[-1, 1])) if need_v else (0, h)      # only the rows the vertical pass reads
+        tmp = torch.empty((last - first, ow, C), dtype=torch.uint8, device=dev)
+        # row j of tmp = (flipped) source row first + j
+        lib.resample_u8_pass(img, tmp, to_dev(bh), to_dev(kh), 1, rs, xb, xs, yb + ys * first, ys)
+        if need_v:
+            bv = bv.copy()
+            bv[:, 0] -= first
+        cur, cur_rs, cur_h, cyb, cys = tmp, ow * C, last - first, 0, 1
+        xb, xs = 0, 1
+    if need_v:
+        out = torch.empty((oh, cur.shape[1], C), dtype=torch.uint8, device=dev)
+        lib.resample_u8_pass(cur, out, to_dev(bv), to_dev(kv), 0, cur_rs, cyb, cys, xb, xs)
+        return out
+    return cur
+
+
+def device_resize_nearest(mat, size, hflip=False, vflip=False):
+    """Image.resize(size[::-1], NEAREST) of an (h,w) device map of 1-, 2- or 4-byte elements (depth in mm, labels), optionally
+    flipped first; `mat` may be a crop window view of a larger map."""
+    lib = hip.library()
+    h, w = mat.shape
+    oh, ow = int(size[0]), int(size[1])
+    if mat.stride(1) != 1:
+        raise ValueError("device_resize_nearest: an (h,w) map or a row-window view of one expected")
+    yt = nearest_table(h, oh) if oh != h else np.arange(h, dtype=np.int32)
+    xt = nearest_table(w, ow) if ow != w else np.arange(w, dtype=np.int32)
+    if vflip:
+        yt = (h - 1 - yt).astype(np.int32)
+    if hflip:
+        xt = (w - 1 - xt).astype(np.int32)
+    out = torch.empty((oh, ow), dtype=mat.dtype, device=mat.device)
+    eb = mat.element_size()
+    lib.gather2d(mat, out, torch.from_numpy(np.ascontiguousarray(yt)).to(mat.device), torch.from_numpy(np.ascontiguousarray(xt)).to(mat.device),
+                 mat.stride(0) * eb, eb)
+    return out
+
+
+# --- the same transforms on the line targets (host tensors, a few dozen rows): the reference's arithmetic, line for line ---------
+def hflip_lines(lines, w):
+    """transforms_depth.py:218-222: end points swapped, x -> w - x."""
+    return lines[:, [2, 3, 0, 1]] * torch.as_tensor([-1.0, 1.0, -1.0, 1.0]) + torch.as_tensor([float(w), 0.0, float(w), 0.0])
+
+
+def vflip_lines(lines, h):
+    """transforms_depth.py:242-250: y -> h - y; vertical lines keep their upper point first."""
+    lines = lines * torch.as_tensor([1.0, -1.0, 1.0, -1.0]) + torch.as_tensor([0.0, float(h), 0.0, float(h)])
+    vert = lines[:, 0] == lines[:, 2]
+    lines[vert] = lines[vert][:, [2, 3, 0, 1]]
+    return lines
+
+
+def resized_shape(w, h, size, max_size=None):
+    """(oh, ow) of RandomResize's aspect-preserving resize (transforms_depth.py:318-343)."""
+    if isinstance(size, (list, tuple)):
+        return int(size[1]), int(size[0])
+    if max_size is not None:
+        mn, mx = float(min(w, h)), float(max(w, h))
+        if mx / mn * size > max_size:
+            size = int(round(max_size * mn / mx))
+    if (w <= h and w == size) or (h <= w and h == size):
+        return h, w
+    if w < h:
+        return int(size * h / w), size
+    return size, int(size * w / h)
+
+
+def resize_lines(lines, w, h, ow, oh):
+    """transforms_depth.py:350-354."""
+    rw, rh = float(ow) / float(w), float(oh) / float(h)
+    return lines * torch.as_tensor([rw, rh, rw, rh])
+
+
+def crop_lines(lines, region):
+    """transforms_depth.py:59-128: shift into the crop window (i, j, h, w), drop lines wholly outside, clip the rest to the window
+    edge by edge along their slope, clamp.  Returns (lines, keep mask)."""
+    i, j, h, w = region
+    cl = lines - torch.as_tensor([j, i, j, i], dtype=lines.dtype)
+    rx = torch.logical_or(torch.logical_and(cl[:, 0] < 0, cl[:, 2] < 0), torch.logical_and(cl[:, 0] > w, cl[:, 2] > w))
+    ry = torch.logical_or(torch.logical_and(cl[:, 1] < 0, cl[:, 3] < 0), torch.logical_and(cl[:, 1] > h, cl[:, 3] > h))
+    keep = torch.logical_and(~rx, ~ry)
+    cl = cl[keep]
+    out = torch.zeros_like(cl)
+    eps = 1e-12
+    for n, line in enumerate(cl):
+        x1, y1, x2, y2 = line
+        slope = (y2 - y1) / (x2 - x1 + eps)
+        if x1 < 0:
+            x1 = 0
+            y1 = y2 + (x1 - x2) * slope
+        if y1 < 0:
+            y1 = 0
+            x1 = x2 - (y2 - y1) / slope
+        if x2 > w:
+            x2 = w
+            y2 = y1 + (x2 - x1) * slope
+        if y2 > h:
+            y2 = h
+            x2 = x1 + (y2 - y1) / slope
+        if x2 < 0:
+            x2 = 0
+            y2 = y1 + (x2 - x1) * slope
+        if y2 < 0:
+            y2 = 0
+            x2 = x1 - (y1 - y2) / slope
+        if x1 > w:
+            x1 = w
+            y1 = y2 + (x1 - x2) * slope
+        if y1 > h:
+            y1 = h
+            x1 = x2 + (y1 - y2) / slope
+        out[n, :] = torch.tensor([x1, y1, x2, y2])
+    out[:, 0::2].clamp_(min=0, max=w)
+    out[:, 1::2].clamp_(min=0, max=h)
+    return out, keep
+
+
+class DeviceAugment:
+    """The reference's training / validation transform chain (src/datasets/coco.py:74-117) over DEVICE images: random flip, random
+    resize (optionally resize -> random crop -> resize), then device_collate normalises and pads.  `params()` draws the random
+    choices (the same choices the reference makes, from this object's own generator); `apply()` is deterministic given them.
+    ColorJitter is not part of this slice."""
+    SCALES = [480, 512, 544, 576, 608, 640, 672, 680, 690, 704, 736, 768, 788, 800]
+
+    def __init__(self, train=True, max_size=1024, test_size=1024, seed=None):
+        self.train, self.max_size, self.test_size = train, max_size, test_size
+        self.rng = random.Random(seed)
+
+    def params(self, w, h):
+        r = self.rng
+        if not self.train:
+            return {"flip": None, "steps": [("resize", self.test_size, self.max_size)]}
+        flip = "h" if r.random() < 0.5 else "v"                     # RandomSelect(HFlip, VFlip); each flip itself has p = 0.5
+        if r.random() >= 0.5:
+            flip = None
+        if r.random() < 0.5:
+            return {"flip": flip, "steps": [("resize", r.choice(self.SCALES), self.max_size)]}
+        s1 = r.choice([400, 500, 600])
+        oh, ow = resized_shape(w, h, s1)
+        cw, ch = r.randint(384, min(ow, 600)), r.randint(384, min(oh, 600))
+        i, j = r.randint(0, oh - ch), r.randint(0, ow - cw)
+        return {"flip": flip, "steps": [("resize", s1, None), ("crop", (i, j, ch, cw)), ("resize", r.choice(self.SCALES), self.max_size)]}
+
+    @staticmethod
+    def apply(rgb, depth_mm, labels, lines, p):
+        """rgb uint8 (h,w,3), depth_mm int32 (h,w), labels uint8 (h,w) device tensors, lines (n,4) host fp32 in pixels.
+        Returns the transformed (rgb, depth_mm, labels, lines [still in pixels], keep mask over the input lines)."""
+        h, w = rgb.shape[:2]
+        hf, vf = p["flip"] == "h", p["flip"] == "v"
+        lines = lines.clone().float()
+        keep = torch.ones(lines.shape[0], dtype=torch.bool)
+        if hf:
+            lines = hflip_lines(lines, w)
+        if vf:
+            lines = vflip_lines(lines, h)
+        first = True
+        for step in p["steps"]:
+            if step[0] == "resize":
+                oh, ow = resized_shape(w, h, step[1], step[2])
+                f = (hf, vf) if first else (False, False)           # the flip rides in the first resize's read
+                rgb = device_resize_rgb(rgb, (oh, ow), *f)
+                depth_mm = device_resize_nearest(depth_mm, (oh, ow), *f) if depth_mm is not None else None
+                labels = device_resize_nearest(labels, (oh, ow), *f) if labels is not None else None
+                lines = resize_lines(lines, w, h, ow, oh)
+                h, w = oh, ow
+                first = False
+            else:
+                i, j, ch, cw = step[1]
+                rgb = rgb[i:i + ch, j:j + cw]                       # window views: the next resize reads them in place
+                depth_mm = depth_mm[i:i + ch, j:j + cw] if depth_mm is not None else None
+                labels = labels[i:i + ch, j:j + cw] if labels is not None else None
+                lines, k = crop_lines(lines, step[1])
+                idx = torch.nonzero(keep).flatten()
+                keep = torch.zeros_like(keep)
+                keep[idx[k]] = True
+                h, w = ch, cw
+        if first and (hf or vf):                                    # a flip with no resize behind it
+            rgb = device_resize_rgb(rgb, (h, w), hf, vf)
+            depth_mm = device_resize_nearest(depth_mm, (h, w), hf, vf) if depth_mm is not None else None
+            labels = device_resize_nearest(labels, (h, w), hf, vf) if labels is not None else None
+        return rgb.contiguous(), None if depth_mm is None else depth_mm.contiguous(), None if labels is None else labels.contiguous(), lines, keep

@@ -32,7 +32,7 @@ ENTRY_POINTS = [
     "gwd_plane_loss_forward", "gwd_plane_loss_backward", "gwd_collate",
     "gwd_anchor_depth_forward", "gwd_anchor_depth_backward", "gwd_mha_flash_forward", "gwd_mha_flash_backward",
     "gwd_ref_scores_forward", "gwd_ref_scores_backward", "gwd_ref_mix_forward", "gwd_ref_mix_backward", "gwd_unpad_add_batch", "gwd_stem_pack", "gwd_stem_forward", "gwd_pos_sine", "gwd_silog_finalize", "gwd_psp_pool_forward", "gwd_psp_pool_backward",
-    "gwd_match_cost", "gwd_set_losses_forward", "gwd_set_losses_backward",
+    "gwd_match_cost", "gwd_set_losses_forward", "gwd_set_losses_backward", "gwd_resample_u8_pass", "gwd_gather2d",
 ]
 
 
@@ -168,6 +168,8 @@ class HipLibrary:
         L.gwd_layernorm_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, i32, vp]
         L.gwd_unpad_add_batch.argtypes = [ctypes.POINTER(UnpadJob), i32, vp]
         L.gwd_silog_finalize.argtypes = [vp, f32, f32, vp, vp]
+        L.gwd_resample_u8_pass.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i32, i32, i32, i32, vp]
+        L.gwd_gather2d.argtypes = [vp, vp, vp, vp, i32, i32, i64, i32, vp]
         L.gwd_match_cost.argtypes = [vp] * 5 + [i32] * 6 + [f32, f32, vp]
         L.gwd_set_losses_forward.argtypes = [vp] * 9 + [f32] + [vp] * 4 + [i32] * 6 + [vp]
         L.gwd_set_losses_backward.argtypes = [vp] * 8 + [f32] + [vp] * 6 + [i32] * 6 + [vp]
@@ -593,6 +595,25 @@ class HipLibrary:
         self._check(self.lib.gwd_certain_sample(_ptr(small), _ptr(large), _ptr(coords), B, hs, ws, H, W, _ptr(edges),
                                                 edges.numel() - 1, sample_num, self._stream(small, large, coords)),
                     "gwd_certain_sample")
+
+    def resample_u8_pass(self, src, dst, bounds, kk, axis, row_stride, base0, step0, base1, step1):
+        """One pass of Pillow's BILINEAR resize over uint8 pixels (gwd_resample_u8_pass); src may be a window / flipped view given by
+        the index maps, dst dense: (other, n_out, C) for axis 1, (n_out, other, C) for axis 0."""
+        n_out, ksize = kk.shape
+        other, C = (dst.shape[0], dst.shape[2]) if axis == 1 else (dst.shape[1], dst.shape[2])
+        if src.dtype != torch.uint8 or dst.dtype != torch.uint8 or bounds.dtype != torch.int32 or kk.dtype != torch.int32 or not dst.is_contiguous():
+            raise ValueError("resample_u8_pass: uint8 images and int32 tables expected")
+        if dst.shape[1 if axis == 1 else 0] != n_out or tuple(bounds.shape) != (n_out, 2):
+            raise ValueError("resample_u8_pass: table / output shapes do not match")
+        self._check(self.lib.gwd_resample_u8_pass(_ptr_pitched(src), _ptr(dst), _ptr(bounds), _ptr(kk), ksize, axis, n_out, other, C, row_stride,
+                                                  base0, step0, base1, step1, self._stream(src, dst, bounds, kk)), "gwd_resample_u8_pass")
+
+    def gather2d(self, src, dst, ytab, xtab, row_stride_bytes, elem_bytes):
+        oh, ow = ytab.numel(), xtab.numel()
+        if ytab.dtype != torch.int32 or xtab.dtype != torch.int32 or not dst.is_contiguous() or dst.numel() * dst.element_size() != oh * ow * elem_bytes:
+            raise ValueError("gather2d: int32 tables and a dense (oh, ow) output expected")
+        self._check(self.lib.gwd_gather2d(_ptr_pitched(src), _ptr(dst), _ptr(ytab), _ptr(xtab), oh, ow, row_stride_bytes, elem_bytes,
+                                          self._stream(src, dst, ytab, xtab)), "gwd_gather2d")
 
     def match_cost(self, logits, lines, tgt_lines, tgt_labels, cost, w_line, w_class):
         """cost (L,B,Q,cap) of matcher.py:52-70 from logits (L,B,Q,K), lines (L,B,Q,D), padded targets (cap,D) / (cap,) int64."""

@@ -459,6 +459,23 @@ int gwd_mha_flash_backward(const void *q, const void *k, const void *v, const vo
  *            pointer may be NULL when the matching output is NULL); read on the host, passed in the kernel arguments;
  *   images [n][H][W][3] (dtype, pixel-major), mask [n][H][W] uint8 (1 = padding), depth [n][H][W] fp32 metres,
  *   seg [n][H][W] int64 {0,1}; every element is written (padding = 0); any output may be NULL.                      */
+/* The geometric transforms of the input pipeline on decoded images (src/datasets/transforms_depth.py:59-372: hflip / vflip, crop,
+ * resize), bit-exact with the Pillow calls the reference makes through torchvision; tables are built by the caller on the host
+ * (gw_depth_amd/data.py shows how; oracle/pil_resize_ref.py is the numpy restatement the tests pin against Pillow).
+ * gwd_resample_u8_pass: ONE separable pass of Image.resize(BILINEAR) over uint8 pixels with C interleaved channels:
+ *   axis 1 (horizontal): dst [other][n_out][C],  dst[j][o][c] = clip8((2^21 + sum_t src[row(j)][col(first_o + t)][c] * kk[o][t]) >> 22)
+ *   axis 0 (vertical):   dst [n_out][other][C],  dst[o][j][c] = ... src[row(first_o + t)][col(j)][c] ...
+ *   bounds (n_out,2) int32 = (first source index, tap count), kk (n_out,ksize) int32 fixed-point coefficients (22 fractional bits);
+ *   index maps along the resampled axis i -> base0 + step0 * i and along the other axis j -> base1 + step1 * j (step = +-1): a flip
+ *   and / or a crop window of the source folded into the read; src_row_stride in elements.
+ * gwd_gather2d: dst[y][x] = src[ytab[y]][xtab[x]] for elements of 1-4 bytes (NEAREST resize / flip / crop of depth and label maps;
+ *   flips and crops of RGB), src_row_stride in BYTES.                                                                             */
+int gwd_resample_u8_pass(const uint8_t *src, uint8_t *dst, const int32_t *bounds, const int32_t *kk, int32_t ksize, int32_t axis,
+                         int32_t n_out, int32_t other, int32_t C, int64_t src_row_stride, int32_t base0, int32_t step0, int32_t base1,
+                         int32_t step1, void *stream);
+int gwd_gather2d(const void *src, void *dst, const int32_t *ytab, const int32_t *xtab, int32_t oh, int32_t ow,
+                 int64_t src_row_stride_bytes, int32_t elem_bytes, void *stream);
+
 #define GWD_COLLATE_BATCH 16
 typedef struct {
     const void *rgb, *depth_mm, *labels;

@@ -310,6 +310,32 @@ class FakeDevice:
         mean.copy_(mu)
         rstd.copy_(rs)
 
+    def resample_u8_pass(self, src, dst, bounds, kk, axis, row_stride, base0, step0, base1, step1):
+        n_out, ksize = kk.shape
+        C = dst.shape[2]
+        other = dst.shape[0] if axis == 1 else dst.shape[1]
+        flat = src.as_strided((src.untyped_storage().nbytes() - src.storage_offset(),), (1,)).to(torch.int64)
+        o = torch.arange(n_out)[:, None, None, None]
+        j = torch.arange(other)[None, :, None, None]
+        c = torch.arange(C)[None, None, :, None]
+        t = torch.arange(ksize)[None, None, None, :]
+        a = base0 + step0 * (bounds[:, 0].long()[:, None, None, None] + t)
+        jo = base1 + step1 * j
+        off = (jo * row_stride + a * C + c) if axis == 1 else (a * row_stride + jo * C + c)
+        valid = t < bounds[:, 1].long()[:, None, None, None]
+        vals = flat[torch.where(valid, off, torch.zeros_like(off))] * valid
+        acc = (vals * kk.long()[:, None, None, :]).sum(-1) + (1 << 21)
+        res = (acc >> 22).clamp(0, 255).to(torch.uint8)                 # (n_out, other, C)
+        dst.copy_(res.permute(1, 0, 2) if axis == 1 else res)
+
+    def gather2d(self, src, dst, ytab, xtab, row_stride_bytes, elem_bytes):
+        eb = src.element_size()
+        rs = row_stride_bytes // eb
+        per = elem_bytes // eb                                          # elements per gathered item (3 for RGB bytes)
+        flat = src.as_strided((src.untyped_storage().nbytes() // eb - src.storage_offset(),), (1,))
+        off = ytab.long()[:, None, None] * rs + xtab.long()[None, :, None] * per + torch.arange(per)[None, None, :]
+        dst.view(-1).copy_(flat[off].reshape(-1))
+
     def match_cost(self, logits, lines, tgt_lines, tgt_labels, cost, w_line, w_class):
         prob = logits.softmax(-1)
         l1 = (lines[..., None, :] - tgt_lines).abs().sum(-1)

@@ -1,0 +1,171 @@
+"""Geometric input transforms on the device (second slice): flip / crop / resize of RGB, depth and label maps,
+bit-exact with Pillow (the library the reference calls through torchvision, src/datasets/transforms_depth.py:59-372), and the matching
+arithmetic on the line targets.  tests/golden/pil_resize.npz: inputs and outputs produced by Pillow (oracle/make_golden_pil_resize.py).
+Everything here is integer / index work: the bar is bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gw_depth_amd import data, hip
+from oracle import pil_resize_ref as ref
+from tests.fake_device import FakeDevice
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pil_resize.npz")
+N_CASES = 7
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(GOLDEN))
+
+
+def test_oracle_resizes_match_the_pillow_golden_vectors(gold):
+    for n in range(N_CASES):
+        oh, ow = (int(v) for v in gold[f"size{n}"])
+        np.testing.assert_array_equal(ref.resize_bilinear_u8(gold[f"rgb{n}"], oh, ow), gold[f"rgb_out{n}"])
+        np.testing.assert_array_equal(ref.resize_nearest(gold[f"dep{n}"], oh, ow), gold[f"dep_out{n}"])
+        np.testing.assert_array_equal(ref.resize_nearest(gold[f"lab{n}"], oh, ow), gold[f"lab_out{n}"])
+        flipped = gold[f"rgb{n}"][:, ::-1] if n % 2 == 0 else gold[f"rgb{n}"][::-1]
+        np.testing.assert_array_equal(ref.resize_bilinear_u8(np.ascontiguousarray(flipped), oh, ow), gold[f"rgb_flip_out{n}"])
+
+
+def test_oracle_matches_the_installed_pillow_on_dataset_like_sizes():
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(3)
+    for (h, w, oh, ow) in [(270, 480, 200, 355), (135, 240, 300, 533), (240, 135, 426, 240)]:
+        rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        np.testing.assert_array_equal(ref.resize_bilinear_u8(rgb, oh, ow), np.asarray(Image.fromarray(rgb).resize((ow, oh), Image.BILINEAR)))
+        dep = rng.integers(0, 12000, (h, w)).astype(np.int32)
+        np.testing.assert_array_equal(ref.resize_nearest(dep, oh, ow), np.asarray(Image.fromarray(dep, mode="I").resize((ow, oh), Image.NEAREST)))
+
+
+def test_product_tables_equal_the_oracle_tables():
+    rng = np.random.default_rng(5)
+    for _ in range(150):
+        a, b = int(rng.integers(2, 1500)), int(rng.integers(2, 1500))
+        b1, k1 = data.bilinear_tables(a, b)
+        b2, k2 = ref.bilinear_tables(a, b)
+        np.testing.assert_array_equal(b1, b2)
+        np.testing.assert_array_equal(k1, k2)
+        np.testing.assert_array_equal(data.nearest_table(a, b), ref.nearest_table(a, b))
+
+
+def _chain_reference(rgb, dep, lab, p):
+    """The same chain through the oracle, step by step (each step a new image, as the reference's Compose does)."""
+    if p["flip"] == "h":
+        rgb, dep, lab = rgb[:, ::-1], dep[:, ::-1], lab[:, ::-1]
+    if p["flip"] == "v":
+        rgb, dep, lab = rgb[::-1], dep[::-1], lab[::-1]
+    rgb, dep, lab = np.ascontiguousarray(rgb), np.ascontiguousarray(dep), np.ascontiguousarray(lab)
+    for step in p["steps"]:
+        h, w = rgb.shape[:2]
+        if step[0] == "resize":
+            oh, ow = data.resized_shape(w, h, step[1], step[2])
+            rgb, dep, lab = ref.resize_bilinear_u8(rgb, oh, ow), ref.resize_nearest(dep, oh, ow), ref.resize_nearest(lab, oh, ow)
+        else:
+            i, j, ch, cw = step[1]
+            rgb, dep, lab = (np.ascontiguousarray(a[i:i + ch, j:j + cw]) for a in (rgb, dep, lab))
+    return rgb, dep, lab
+
+
+PARAMS = [
+    {"flip": None, "steps": [("resize", 96, 1024)]},
+    {"flip": "h", "steps": [("resize", 120, 160)]},
+    {"flip": "v", "steps": [("resize", 80, None), ("crop", (5, 9, 50, 61)), ("resize", 100, 1024)]},
+    {"flip": "h", "steps": [("resize", 70, None), ("crop", (0, 0, 40, 40)), ("resize", 64, 1024)]},
+    {"flip": "v", "steps": []},
+]
+
+
+def _run_chain(p, device):
+    rng = np.random.default_rng(11)
+    h, w = 72, 128
+    rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    dep = rng.integers(0, 12000, (h, w)).astype(np.int32)
+    lab = rng.integers(0, 3, (h, w)).astype(np.uint8)
+    lines = torch.tensor([[10.0, 20.0, 100.0, 60.0], [5.0, 5.0, 5.0, 70.0], [0.0, 71.0, 127.0, 0.0], [120.0, 10.0, 126.0, 12.0]])
+    out = data.DeviceAugment.apply(torch.from_numpy(rgb).to(device), torch.from_numpy(dep).to(device), torch.from_numpy(lab).to(device), lines, p)
+    want = _chain_reference(rgb, dep, lab, p)
+    for got, w_ in zip(out[:3], want):
+        np.testing.assert_array_equal(got.cpu().numpy(), w_)
+    return out
+
+
+@pytest.mark.parametrize("p", PARAMS, ids=[str(i) for i in range(len(PARAMS))])
+def test_device_augment_host_logic_on_the_cpu_stand_in(p):
+    hip.set_library(FakeDevice())
+    try:
+        _run_chain(p, "cpu")
+    finally:
+        hip.set_library(None)
+
+
+def test_line_target_transforms():
+    lines = torch.tensor([[10.0, 20.0, 100.0, 60.0], [5.0, 5.0, 5.0, 70.0]])
+    hf = data.hflip_lines(lines, 128)
+    assert torch.equal(hf, torch.tensor([[28.0, 60.0, 118.0, 20.0], [123.0, 70.0, 123.0, 5.0]]))          # swapped end points, x -> w - x
+    assert torch.equal(data.hflip_lines(hf, 128), lines)
+    vf = data.vflip_lines(lines.clone(), 72)
+    assert torch.equal(vf, torch.tensor([[10.0, 52.0, 100.0, 12.0], [5.0, 2.0, 5.0, 67.0]]))               # vertical line: upper point first again
+    assert torch.equal(data.resize_lines(lines, 128, 72, 256, 144), lines * 2)
+    # crop (i=10, j=20, h=40, w=60): line 0 enters at x=0 on its slope and leaves through the bottom edge; line 1 lies left of the window
+    cl, keep = data.crop_lines(lines, (10, 20, 40, 60))
+    assert keep.tolist() == [True, False]
+    slope = 40.0 / 90.0
+    x1, y1 = 0.0, 50.0 + (0.0 - 80.0) * slope            # shifted line: (-10, 10) -> (80, 50)
+    # ... x2 = 60 first gives y2 = 41.1 > h = 40, so the line is cut again at the bottom edge: y2 = 40, x2 = x1 + (40 - y1) / slope
+    assert torch.allclose(cl, torch.tensor([[x1, y1, (40.0 - y1) / slope, 40.0]]), atol=1e-4)
+    assert data.resized_shape(1280, 720, 480, 1024) == (480, 853) and data.resized_shape(720, 1280, 800, 1024) == (1024, 576)
+    assert data.resized_shape(640, 480, 480, 1024) == (480, 640) and data.resized_shape(100, 50, (30, 20)) == (20, 30)
+
+
+def test_params_follow_the_reference_recipe():
+    aug = data.DeviceAugment(train=True, seed=0)
+    kinds = set()
+    for _ in range(200):
+        p = aug.params(1280, 720)
+        assert p["flip"] in (None, "h", "v")
+        kinds.add(tuple(s[0] for s in p["steps"]))
+        for s in p["steps"]:
+            if s[0] == "resize":
+                assert s[1] in data.DeviceAugment.SCALES + [400, 500, 600]
+            else:
+                i, j, ch, cw = s[1]
+                assert 384 <= ch <= 600 and 384 <= cw <= 600 and i >= 0 and j >= 0
+    assert kinds == {("resize",), ("resize", "crop", "resize")}
+    assert data.DeviceAugment(train=False).params(1280, 720) == {"flip": None, "steps": [("resize", 1024, 1024)]}
+
+
+# ------------------------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", PARAMS, ids=[str(i) for i in range(len(PARAMS))])
+def test_device_augment_kernels_bit_exact(p):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    hip.set_library(None)
+    _run_chain(p, "cuda")
+
+
+@pytest.mark.gpu
+def test_device_resizes_match_golden_and_pillow_at_dataset_size(gold):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    hip.set_library(None)
+    for n in range(N_CASES):
+        oh, ow = (int(v) for v in gold[f"size{n}"])
+        rgb = torch.from_numpy(gold[f"rgb{n}"]).cuda()
+        np.testing.assert_array_equal(data.device_resize_rgb(rgb, (oh, ow)).cpu().numpy(), gold[f"rgb_out{n}"])
+        np.testing.assert_array_equal(data.device_resize_rgb(rgb, (oh, ow), hflip=n % 2 == 0, vflip=n % 2 == 1).cpu().numpy(), gold[f"rgb_flip_out{n}"])
+        np.testing.assert_array_equal(data.device_resize_nearest(torch.from_numpy(gold[f"dep{n}"]).cuda(), (oh, ow)).cpu().numpy(), gold[f"dep_out{n}"])
+        np.testing.assert_array_equal(data.device_resize_nearest(torch.from_numpy(gold[f"lab{n}"]).cuda(), (oh, ow)).cpu().numpy(), gold[f"lab_out{n}"])
+    # full-size frame (the dataset's 720 x 1280) through the oracle; idempotence of the double flip as a size-independent property
+    rng = np.random.default_rng(8)
+    rgb = rng.integers(0, 256, (720, 1280, 3), dtype=np.uint8)
+    t = torch.from_numpy(rgb).cuda()
+    oh, ow = data.resized_shape(1280, 720, 480, 1024)
+    got = data.device_resize_rgb(t, (oh, ow)).cpu().numpy()
+    np.testing.assert_array_equal(got, ref.resize_bilinear_u8(rgb, oh, ow))
+    twice = data.device_resize_rgb(data.device_resize_rgb(t, (720, 1280), hflip=True), (720, 1280), hflip=True)
+    assert torch.equal(twice, t)
