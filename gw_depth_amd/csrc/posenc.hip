@@ -9,7 +9,7 @@
 namespace {
 
 // one workgroup per image: thread t < w scans column t (y counts), thread w + i scans row i (x counts); also writes the level mask
-__global__ __launch_bounds__(256) void pos_counts_kernel(const uint8_t *__restrict__ full, uint8_t *__restrict__ lvl, int16_t *__restrict__ counts,
+__global__ __launch_bounds__(1024) void pos_counts_kernel(const uint8_t *__restrict__ full, uint8_t *__restrict__ lvl, int16_t *__restrict__ counts,
                                                          int H, int W, int h, int w) {
     __shared__ uint8_t sm[32768];                       // the level mask of one image when it fits (every level of the 480 x 640 step)
     const int b = blockIdx.x;
@@ -78,7 +78,7 @@ extern "C" int gwd_pos_sine(const uint8_t *mask_full, uint8_t *mask_level, int16
     hipStream_t s = (hipStream_t)stream;
     if (mask_full) {                                   // first call for a level: mask + counts
         if (!mask_level) return -1;
-        pos_counts_kernel<<<B, 256, 0, s>>>(mask_full, mask_level, counts, H, W, h, w);
+        pos_counts_kernel<<<B, 1024, 0, s>>>(mask_full, mask_level, counts, H, W, h, w);       // one workgroup per image: 16 waves hide the gather latency
         GWD_CHECK_LAUNCH();
     }
     if (out) {                                         // an embedding of F + F channels from the level's counts

@@ -323,6 +323,17 @@ int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s) {
     }
     const int per_cu = lds > 53 * 1024 ? 2 : 3;
     long grid = 256L * per_cu;
+    // every workgroup ends with CG x 9 x CX fp32 atomics onto the SAME few thousand addresses: with 768 workgroups that flush
+    // (768-way contention per address) outweighs the tile loop for the small weights; cap the workgroup count by the weight size
+    static int cap_env = -2;
+    if (cap_env == -2) {
+        const char *e = getenv("GWD_TCONV_WGRAD_GRID");
+        cap_env = e ? atoi(e) : -1;
+    }
+    // measured (tools/convbench.py, GWD_TCONV_WGRAD_GRID sweep): 32 x 32 at 480 x 640: 154 us with 768 workgroups, 116 with 512;
+    // 64 x 32 at 240 x 320: 125 -> 86 us with 256
+    const long cap = cap_env > 0 ? cap_env : (CX * CG <= 1024 ? 512 : 256);
+    if (grid > cap) grid = cap;
     if (grid > ntiles) grid = ntiles;
     tconv_wgrad_kernel<CX, CG, UP><<<(unsigned)grid, 192, lds, s>>>(*d, dw, ty, tx, (int)ntiles);
     return 1;
@@ -372,7 +383,7 @@ int gwd_tile_conv_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s) {
     const int cx = d->Cin, cg = d->Cout;
 #define TW_(CX_, CG_)                                                                               \
     if (cx == CX_ && cg == CG_) return up ? launch_wgrad<CX_, CG_, true>(d, dw, s) : launch_wgrad<CX_, CG_, false>(d, dw, s);
-    TW_(32, 32) TW_(64, 32) TW_(16, 16)
+    TW_(32, 32) TW_(64, 32)        // (16, 16) stays on the generic kernel: 19 us there, 21-35 us here (its 2 304 weights are all atomics)
 #undef TW_
     return 0;
 }
