@@ -71,7 +71,80 @@ __global__ void point_sample_bwd_kernel(const float *__restrict__ gout, const fl
     }
 }
 
+// The same gradient as a GATHER: a thread owns one pixel x 16 bytes of channels of image b and walks the S points (their taps and
+// weights staged once per workgroup in LDS), adding the points that touch its pixel; every element of gmap is written exactly once -
+// no pre-zeroing pass, no read-modify-write chain of S x 4 dependent updates per thread (31 us per call on the 21 x 21 x 512 maps of
+// the 1/32 stage, where the scatter form has only B x C = 4 096 threads).
+template <typename T>
+__global__ __launch_bounds__(256) void point_sample_bwd_gather_kernel(const float *__restrict__ gout, const float *__restrict__ coords,
+                                                                      T *__restrict__ gmap, int H, int W, int C, int S, int mode) {
+    constexpr int VEC = 16 / (int)sizeof(T), SMAX = 256;
+    __shared__ int px[SMAX], py[SMAX];
+    __shared__ float wgt[SMAX][4];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int s = tid; s < S; s += 256) {
+        const int64_t bs = (int64_t)b * S + s;
+        const float ix = unnormalize(coords[bs * 2], W), iy = unnormalize(coords[bs * 2 + 1], H);
+        if (mode == 1) {
+            px[s] = (int)nearbyintf(ix);
+            py[s] = (int)nearbyintf(iy);
+            wgt[s][0] = 1.f;
+            wgt[s][1] = wgt[s][2] = wgt[s][3] = 0.f;
+        } else {
+            const int x0 = (int)floorf(ix), y0 = (int)floorf(iy);
+            const float wx1 = ix - (float)x0, wx0 = (float)(x0 + 1) - ix, wy1 = iy - (float)y0, wy0 = (float)(y0 + 1) - iy;
+            px[s] = x0;
+            py[s] = y0;
+            wgt[s][0] = wx0 * wy0;
+            wgt[s][1] = wx1 * wy0;
+            wgt[s][2] = wx0 * wy1;
+            wgt[s][3] = wx1 * wy1;
+        }
+    }
+    __syncthreads();
+    const int CV = C / VEC;
+    const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+    if (i >= (int64_t)H * W * CV) return;
+    const int cv = (int)(i % CV);
+    const int pix = (int)(i / CV), y = pix / W, x = pix - y * W;
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    const int span = mode == 1 ? 0 : 1;
+    for (int s = 0; s < S; ++s) {
+        const int dx = x - px[s], dy = y - py[s];
+        if ((unsigned)dx > (unsigned)span || (unsigned)dy > (unsigned)span) continue;
+        const float w = wgt[s][dy * 2 + dx];
+        const float *g = gout + ((int64_t)b * S + s) * C + cv * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; e += 4) {
+            const float4 v = *(const float4 *)(g + e);
+            acc[e] += v.x * w; acc[e + 1] += v.y * w; acc[e + 2] += v.z * w; acc[e + 3] += v.w * w;
+        }
+    }
+    alignas(16) T o[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] = from_f32<T>(acc[e]);
+    *(uint4 *)(gmap + ((int64_t)b * H * W + pix) * C + cv * VEC) = *(const uint4 *)o;
+}
+
 }  // namespace
+
+extern "C" int gwd_point_sample_backward_gather(const float *gout, const float *coords, void *gmap, int32_t B, int32_t H, int32_t W,
+                                                int32_t C, int32_t S, int32_t mode, int32_t dtype, void *stream) {
+    if (!gout || !coords || !gmap || B <= 0 || H <= 0 || W <= 0 || C <= 0 || S <= 0 || (mode != 0 && mode != 1)) return -1;
+    const int vec = dtype == GWD_BF16 ? 8 : (dtype == GWD_F32 ? 4 : 0);
+    if (!vec) return -2;
+    if (C % vec || S > 256 || B > 65535) return -4;            // caller: zero gmap, gwd_point_sample_backward
+    const int64_t per = (int64_t)H * W * (C / vec);
+    if (per >= (1LL << 31)) return -7;
+    dim3 grid((unsigned)((per + 255) / 256), (unsigned)B);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GWD_BF16) point_sample_bwd_gather_kernel<__bf16><<<grid, 256, 0, st>>>(gout, coords, (__bf16 *)gmap, H, W, C, S, mode);
+    else point_sample_bwd_gather_kernel<float><<<grid, 256, 0, st>>>(gout, coords, (float *)gmap, H, W, C, S, mode);
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int gwd_point_sample_forward(const void *map, const float *coords, float *out, int32_t B, int32_t H, int32_t W,
                                         int32_t C, int32_t S, int32_t mode, int32_t dtype, void *stream) {

@@ -32,7 +32,7 @@ ENTRY_POINTS = [
     "gwd_plane_loss_forward", "gwd_plane_loss_backward", "gwd_collate",
     "gwd_anchor_depth_forward", "gwd_anchor_depth_backward", "gwd_mha_flash_forward", "gwd_mha_flash_backward",
     "gwd_ref_scores_forward", "gwd_ref_scores_backward", "gwd_ref_mix_forward", "gwd_ref_mix_backward", "gwd_unpad_add_batch", "gwd_stem_pack", "gwd_stem_forward", "gwd_pos_sine", "gwd_silog_finalize", "gwd_psp_pool_forward", "gwd_psp_pool_backward",
-    "gwd_match_cost", "gwd_set_losses_forward", "gwd_set_losses_backward", "gwd_resample_u8_pass", "gwd_gather2d",
+    "gwd_match_cost", "gwd_set_losses_forward", "gwd_set_losses_backward", "gwd_resample_u8_pass", "gwd_gather2d", "gwd_point_sample_backward_gather",
 ]
 
 
@@ -210,6 +210,7 @@ class HipLibrary:
         L.gwd_act_backward_colsum.argtypes = [vp, vp, vp, vp, i64, i32, i32, ctypes.c_float, vp, i32, vp]
         L.gwd_point_sample_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_point_sample_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+        L.gwd_point_sample_backward_gather.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_weight_prep_batch.argtypes = [vp, i32, i32, vp]
         L.gwd_window_map.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_sqnorm.argtypes = [vp, vp, i64, vp]
@@ -661,6 +662,15 @@ class HipLibrary:
     def point_sample_forward(self, fmap, coords, out, B, H, W, C, S, mode):
         self._check(self.lib.gwd_point_sample_forward(_ptr(fmap), _ptr(coords), _ptr(out), B, H, W, C, S, mode, dtype_code(fmap),
                                                       self._stream(fmap, out)), "gwd_point_sample_forward")
+
+    def point_sample_backward_gather(self, gout, coords, gmap, B, H, W, C, S, mode):
+        """Writes every element of gmap (no pre-zeroing); False when the shape is not supported (zero gmap, point_sample_backward)."""
+        rc = self.lib.gwd_point_sample_backward_gather(_ptr(gout), _ptr(coords), _ptr(gmap), B, H, W, C, S, mode, dtype_code(gmap),
+                                                       self._stream(gout, gmap))
+        if rc == -4:
+            return False
+        self._check(rc, "gwd_point_sample_backward_gather")
+        return True
 
     def point_sample_backward(self, gout, coords, gmap, B, H, W, C, S, mode):
         self._check(self.lib.gwd_point_sample_backward(_ptr(gout), _ptr(coords), _ptr(gmap), B, H, W, C, S, mode, dtype_code(gmap),

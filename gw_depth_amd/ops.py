@@ -1387,8 +1387,11 @@ class _PointSampleFn(torch.autograd.Function):
     def backward(ctx, gout):
         (coords,) = ctx.saved_tensors
         B, H, W, C, S, mode, dtype = ctx.cfg
-        gmap = torch.zeros((B, H, W, C), dtype=dtype, device=gout.device)
-        _lib().point_sample_backward(gout.float().contiguous(), coords, gmap, B, H, W, C, S, mode)
+        gmap = torch.empty((B, H, W, C), dtype=dtype, device=gout.device)
+        g = gout.float().contiguous()
+        if not _lib().point_sample_backward_gather(g, coords, gmap, B, H, W, C, S, mode):      # gather: every element written once
+            gmap.zero_()
+            _lib().point_sample_backward(g, coords, gmap, B, H, W, C, S, mode)
         return gmap, None, None
 
 

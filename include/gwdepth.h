@@ -261,6 +261,10 @@ int gwd_point_sample_forward(const void *map, const float *coords, float *out, i
                              int32_t S, int32_t mode, int32_t dtype, void *stream);
 int gwd_point_sample_backward(const float *gout, const float *coords, void *gmap, int32_t B, int32_t H, int32_t W, int32_t C,
                               int32_t S, int32_t mode, int32_t dtype, void *stream);
+/* The same gradient, every element of gmap WRITTEN (no pre-zeroing): a gather over the S <= 256 points per pixel.  Returns -4 when C is
+ * not a multiple of 16 bytes or S > 256 (use the pair above).                                                     */
+int gwd_point_sample_backward_gather(const float *gout, const float *coords, void *gmap, int32_t B, int32_t H, int32_t W, int32_t C,
+                                     int32_t S, int32_t mode, int32_t dtype, void *stream);
 
 /* gwd_weight_prep for many weights in one launch (bf16 outputs).  `jobs` is a DEVICE array; job i owns the blocks
  * [block0_i, block0_{i+1}) of the launch, one 32(n) x 32(c) tile of one tap each: blocks_i = taps*ceil(N/32)*ceil(C/32),

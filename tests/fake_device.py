@@ -668,6 +668,11 @@ class FakeDevice:
                           mode="nearest" if mode == 1 else "bilinear", align_corners=False)
         out.copy_(r.reshape(B, C, S).permute(0, 2, 1).reshape(out.shape))
 
+    def point_sample_backward_gather(self, gout, coords, gmap, B, H, W, C, S, mode):
+        gmap.zero_()
+        self.point_sample_backward(gout, coords, gmap, B, H, W, C, S, mode)
+        return True
+
     def point_sample_backward(self, gout, coords, gmap, B, H, W, C, S, mode):
         with torch.enable_grad():
             x = torch.zeros(B, C, H, W, requires_grad=True)
