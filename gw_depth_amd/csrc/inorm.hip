@@ -89,39 +89,52 @@ __global__ __launch_bounds__(NT) void inorm_stats_kernel(const T *__restrict__ u
     }
 }
 
-// merge the S slice statistics of image b for the VN channels starting at c0 -> mean, rstd
+// merge the S slice statistics of image b for the VN channels starting at c0 -> mean, rstd (in every thread of the channel group).
+// The threads of a group share the slices (one global load each, then an LDS tree) - a per-thread walk over the S = 32 slices was 32
+// DEPENDENT L2 round trips in front of one iteration of real work: 29 us per launch for a 4.5 MB tensor.
+//   mean = sum_s n_s mean_s / L,   M2 = sum_s (M2_s + n_s (mean_s - mean)^2)
 template <int VN>
-__device__ __forceinline__ void merge_stats(const float *__restrict__ part, int b, int c0, int64_t L, int C, int S, float eps,
+__device__ __forceinline__ void merge_stats(const float *__restrict__ part, float *lds, int b, int c0, int64_t L, int C, int S, float eps, int CG,
                                             float (&mean)[VN], float (&rstd)[VN]) {
-    float cnt = 0.f, m2[VN];
+    const int sl0 = threadIdx.x / CG, nsl = NT / CG;
+    float acc[VN];
 #pragma unroll
-    for (int i = 0; i < VN; ++i) { mean[i] = 0.f; m2[i] = 0.f; }
-    for (int s = 0; s < S; ++s) {
+    for (int i = 0; i < VN; ++i) acc[i] = 0.f;
+    for (int s = sl0; s < S; s += nsl) {
         int64_t lo, hi;
         slice_bounds(L, S, s, lo, hi);
         const float nb = (float)(hi - lo);
-        if (nb <= 0.f) continue;
         const float *p = part + (((int64_t)b * S + s) * C + c0) * 2;
-        const float tot = cnt + nb;
+#pragma unroll
+        for (int i = 0; i < VN; ++i) acc[i] += nb * p[2 * i];
+    }
+    group_reduce<VN>(acc, lds, CG);
+#pragma unroll
+    for (int i = 0; i < VN; ++i) { mean[i] = acc[i] / (float)L; acc[i] = 0.f; }
+    for (int s = sl0; s < S; s += nsl) {
+        int64_t lo, hi;
+        slice_bounds(L, S, s, lo, hi);
+        const float nb = (float)(hi - lo);
+        const float *p = part + (((int64_t)b * S + s) * C + c0) * 2;
 #pragma unroll
         for (int i = 0; i < VN; ++i) {
             const float d = p[2 * i] - mean[i];
-            mean[i] += d * (nb / tot);
-            m2[i] += p[2 * i + 1] + d * d * (cnt * nb / tot);
+            acc[i] += p[2 * i + 1] + nb * d * d;
         }
-        cnt = tot;
     }
+    group_reduce<VN>(acc, lds, CG);
 #pragma unroll
-    for (int i = 0; i < VN; ++i) rstd[i] = rsqrtf(m2[i] / cnt + eps);
+    for (int i = 0; i < VN; ++i) rstd[i] = rsqrtf(acc[i] / (float)L + eps);
 }
 
 template <typename T>
 __global__ __launch_bounds__(NT) void inorm_gelu_fwd_kernel(const T *__restrict__ a, const T *__restrict__ u, const float *__restrict__ part,
                                                              T *__restrict__ y, float *__restrict__ stat, int64_t L, int C, int S, float eps) {
     constexpr int VN = Vec16<T>::N;
+    __shared__ float lds[NT * VN];
     const int CG = C / VN, g = threadIdx.x % CG, b = blockIdx.y;
     float mean[VN], rstd[VN];
-    merge_stats<VN>(part, b, g * VN, L, C, S, eps, mean, rstd);
+    merge_stats<VN>(part, lds, b, g * VN, L, C, S, eps, CG, mean, rstd);
     if (blockIdx.x == 0 && threadIdx.x < CG) {
 #pragma unroll
         for (int i = 0; i < VN; ++i) { stat[((int64_t)b * C + g * VN + i) * 2] = mean[i]; stat[((int64_t)b * C + g * VN + i) * 2 + 1] = rstd[i]; }
@@ -177,6 +190,7 @@ template <typename T>
 __global__ __launch_bounds__(NT) void inorm_gelu_bwd_kernel(const T *__restrict__ gy, const T *__restrict__ u, const float *__restrict__ stat,
                                                              const float *__restrict__ part, T *__restrict__ du, int64_t L, int C, int S) {
     constexpr int VN = Vec16<T>::N;
+    __shared__ float lds[NT * VN];
     const int CG = C / VN, g = threadIdx.x % CG, b = blockIdx.y;
     float mean[VN], rstd[VN], m1[VN], m2[VN];
 #pragma unroll
@@ -185,11 +199,13 @@ __global__ __launch_bounds__(NT) void inorm_gelu_bwd_kernel(const T *__restrict_
         rstd[i] = stat[((int64_t)b * C + g * VN + i) * 2 + 1];
         m1[i] = m2[i] = 0.f;
     }
-    for (int s = 0; s < S; ++s) {
+    for (int s = threadIdx.x / CG; s < S; s += NT / CG) {      // the group's threads share the slices: one load each, then an LDS tree
         const float *p = part + (((int64_t)b * S + s) * C + g * VN) * 2;
 #pragma unroll
         for (int i = 0; i < VN; ++i) { m1[i] += p[2 * i]; m2[i] += p[2 * i + 1]; }
     }
+    group_reduce<VN>(m1, lds, CG);
+    group_reduce<VN>(m2, lds, CG);
     const float inv = 1.0f / (float)L;
 #pragma unroll
     for (int i = 0; i < VN; ++i) { m1[i] *= inv; m2[i] *= inv; }
