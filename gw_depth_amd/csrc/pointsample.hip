@@ -75,10 +75,10 @@ __global__ void point_sample_bwd_kernel(const float *__restrict__ gout, const fl
 // weights staged once per workgroup in LDS), adding the points that touch its pixel; every element of gmap is written exactly once -
 // no pre-zeroing pass, no read-modify-write chain of S x 4 dependent updates per thread (31 us per call on the 21 x 21 x 512 maps of
 // the 1/32 stage, where the scatter form has only B x C = 4 096 threads).
-template <typename T>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void point_sample_bwd_gather_kernel(const float *__restrict__ gout, const float *__restrict__ coords,
                                                                       T *__restrict__ gmap, int H, int W, int C, int S, int mode) {
-    constexpr int VEC = 16 / (int)sizeof(T), SMAX = 256;
+    constexpr int SMAX = 256;                    // VEC = 16 bytes of channels per thread, or 1 channel (any C: the 1-channel depth maps)
     __shared__ int px[SMAX], py[SMAX];
     __shared__ float wgt[SMAX][4];
     const int b = blockIdx.y, tid = threadIdx.x;
@@ -116,16 +116,25 @@ __global__ __launch_bounds__(256) void point_sample_bwd_gather_kernel(const floa
         if ((unsigned)dx > (unsigned)span || (unsigned)dy > (unsigned)span) continue;
         const float w = wgt[s][dy * 2 + dx];
         const float *g = gout + ((int64_t)b * S + s) * C + cv * VEC;
+        if constexpr (VEC == 1) {
+            acc[0] += g[0] * w;
+        } else {
 #pragma unroll
-        for (int e = 0; e < VEC; e += 4) {
-            const float4 v = *(const float4 *)(g + e);
-            acc[e] += v.x * w; acc[e + 1] += v.y * w; acc[e + 2] += v.z * w; acc[e + 3] += v.w * w;
+            for (int e = 0; e < VEC; e += 4) {
+                const float4 v = *(const float4 *)(g + e);
+                acc[e] += v.x * w; acc[e + 1] += v.y * w; acc[e + 2] += v.z * w; acc[e + 3] += v.w * w;
+            }
         }
     }
-    alignas(16) T o[VEC];
+    T *dst = gmap + ((int64_t)b * H * W + pix) * C + cv * VEC;
+    if constexpr (VEC == 1) {
+        dst[0] = from_f32<T>(acc[0]);
+    } else {
+        alignas(16) T o[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) o[e] = from_f32<T>(acc[e]);
-    *(uint4 *)(gmap + ((int64_t)b * H * W + pix) * C + cv * VEC) = *(const uint4 *)o;
+        for (int e = 0; e < VEC; ++e) o[e] = from_f32<T>(acc[e]);
+        *(uint4 *)dst = *(const uint4 *)o;
+    }
 }
 
 }  // namespace
@@ -133,15 +142,21 @@ __global__ __launch_bounds__(256) void point_sample_bwd_gather_kernel(const floa
 extern "C" int gwd_point_sample_backward_gather(const float *gout, const float *coords, void *gmap, int32_t B, int32_t H, int32_t W,
                                                 int32_t C, int32_t S, int32_t mode, int32_t dtype, void *stream) {
     if (!gout || !coords || !gmap || B <= 0 || H <= 0 || W <= 0 || C <= 0 || S <= 0 || (mode != 0 && mode != 1)) return -1;
-    const int vec = dtype == GWD_BF16 ? 8 : (dtype == GWD_F32 ? 4 : 0);
+    int vec = dtype == GWD_BF16 ? 8 : (dtype == GWD_F32 ? 4 : 0);
     if (!vec) return -2;
-    if (C % vec || S > 256 || B > 65535) return -4;            // caller: zero gmap, gwd_point_sample_backward
+    if (S > 256 || B > 65535) return -4;                       // caller: zero gmap, gwd_point_sample_backward
+    if (C % vec || ((uintptr_t)gmap % 16)) vec = 1;
     const int64_t per = (int64_t)H * W * (C / vec);
     if (per >= (1LL << 31)) return -7;
     dim3 grid((unsigned)((per + 255) / 256), (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == GWD_BF16) point_sample_bwd_gather_kernel<__bf16><<<grid, 256, 0, st>>>(gout, coords, (__bf16 *)gmap, H, W, C, S, mode);
-    else point_sample_bwd_gather_kernel<float><<<grid, 256, 0, st>>>(gout, coords, (float *)gmap, H, W, C, S, mode);
+    if (dtype == GWD_BF16) {
+        if (vec == 1) point_sample_bwd_gather_kernel<__bf16, 1><<<grid, 256, 0, st>>>(gout, coords, (__bf16 *)gmap, H, W, C, S, mode);
+        else point_sample_bwd_gather_kernel<__bf16, 8><<<grid, 256, 0, st>>>(gout, coords, (__bf16 *)gmap, H, W, C, S, mode);
+    } else {
+        if (vec == 1) point_sample_bwd_gather_kernel<float, 1><<<grid, 256, 0, st>>>(gout, coords, (float *)gmap, H, W, C, S, mode);
+        else point_sample_bwd_gather_kernel<float, 4><<<grid, 256, 0, st>>>(gout, coords, (float *)gmap, H, W, C, S, mode);
+    }
     GWD_CHECK_LAUNCH();
     return 0;
 }

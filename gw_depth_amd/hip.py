@@ -211,7 +211,7 @@ class HipLibrary:
         L.gwd_point_sample_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_point_sample_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_point_sample_backward_gather.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
-        L.gwd_weight_prep_batch.argtypes = [vp, i32, i32, vp]
+        L.gwd_weight_prep_batch.argtypes = [vp, i32, i32, vp, vp]
         L.gwd_window_map.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_sqnorm.argtypes = [vp, vp, i64, vp]
         L.gwd_adamw_step.argtypes = [vp, vp, vp, vp, vp, vp, i64] + [f32] * 9 + [vp]
@@ -676,9 +676,10 @@ class HipLibrary:
         self._check(self.lib.gwd_point_sample_backward(_ptr(gout), _ptr(coords), _ptr(gmap), B, H, W, C, S, mode, dtype_code(gmap),
                                                        self._stream(gout, gmap)), "gwd_point_sample_backward")
 
-    def weight_prep_batch(self, table, n_jobs, total_blocks):
-        """table: device uint8 tensor holding n_jobs packed gwd_prep_job records (see PrepJob)."""
-        self._check(self.lib.gwd_weight_prep_batch(_ptr(table), n_jobs, total_blocks, self._stream(table)), "gwd_weight_prep_batch")
+    def weight_prep_batch(self, table, n_jobs, total_blocks, block_job=None):
+        """table: device uint8 tensor holding n_jobs packed gwd_prep_job records (see PrepJob); block_job: device int32 (total_blocks,)
+        job index per block (optional, saves every block a binary search)."""
+        self._check(self.lib.gwd_weight_prep_batch(_ptr(table), n_jobs, total_blocks, _ptr(block_job), self._stream(table)), "gwd_weight_prep_batch")
 
     def window_map(self, src, dst, B, H, W, C, shift, gather, residual=None):
         self._check(self.lib.gwd_window_map(_ptr(src), _ptr(dst), _ptr(residual), B, H, W, C, shift, int(gather), dtype_code(src),

@@ -83,6 +83,7 @@ class WeightCache:
         if self.dirty and self.jobs:
             recs = (hip.PrepJob * len(self.jobs))()
             b0 = 0
+            owners = []
             for i, job in enumerate(self.jobs.values()):
                 w = job["w"]
                 N, C = w.shape[0], w.shape[-1]
@@ -92,15 +93,18 @@ class WeightCache:
                 r.w_dgrad = 0 if job["t"] is None else job["t"].data_ptr()
                 r.N, r.taps, r.C, r.block0 = N, w.numel() // (N * C), C, b0
                 r.Np, r.Cg, r.Cgp = job["geom"] if job.get("geom") is not None else (0, 0, 0)
-                b0 += (w.numel() // (N * C)) * ((N + 31) // 32) * ((C + 31) // 32)
+                nblk = (w.numel() // (N * C)) * ((N + 31) // 32) * ((C + 31) // 32)
+                owners.append(torch.full((nblk,), i, dtype=torch.int32))
+                b0 += nblk
             raw = torch.frombuffer(bytearray(bytes(recs)), dtype=torch.uint8)
             dev = next(iter(self.jobs.values()))["w"].device
-            self._retired.append(self.table)      # a captured HIP graph may still launch with the old table
+            self._retired.append((self.table, getattr(self, "block_job", None)))      # a captured HIP graph may still launch with the old tables
             self.table = raw.to(dev)
+            self.block_job = torch.cat(owners).to(dev)
             self.n_jobs, self.blocks = len(self.jobs), b0
             self.dirty = False
         if self.table is not None:
-            _lib().weight_prep_batch(self.table, self.n_jobs, self.blocks)
+            _lib().weight_prep_batch(self.table, self.n_jobs, self.blocks, getattr(self, "block_job", None))
         self.active = True
         global _ACTIVE_WEIGHTS
         _ACTIVE_WEIGHTS = self

@@ -261,8 +261,8 @@ int gwd_point_sample_forward(const void *map, const float *coords, float *out, i
                              int32_t S, int32_t mode, int32_t dtype, void *stream);
 int gwd_point_sample_backward(const float *gout, const float *coords, void *gmap, int32_t B, int32_t H, int32_t W, int32_t C,
                               int32_t S, int32_t mode, int32_t dtype, void *stream);
-/* The same gradient, every element of gmap WRITTEN (no pre-zeroing): a gather over the S <= 256 points per pixel.  Returns -4 when C is
- * not a multiple of 16 bytes or S > 256 (use the pair above).                                                     */
+/* The same gradient, every element of gmap WRITTEN (no pre-zeroing): a gather over the S <= 256 points per pixel.  Returns -4 when
+ * S > 256 (use the pair above).                                                     */
 int gwd_point_sample_backward_gather(const float *gout, const float *coords, void *gmap, int32_t B, int32_t H, int32_t W, int32_t C,
                                      int32_t S, int32_t mode, int32_t dtype, void *stream);
 
@@ -281,7 +281,9 @@ typedef struct gwd_prep_job {
     int32_t reserved;        /* input channels are G = C / Cg groups of Cg, each padded to Cgp; the caller zeroes the copies     */
                              /* once, the launch writes the N x taps x C real entries only.  Np = 0: dense copies as above.      */
 } gwd_prep_job;
-int gwd_weight_prep_batch(const gwd_prep_job *jobs, int32_t n_jobs, int32_t total_blocks, void *stream);
+/* block_job (may be NULL): DEVICE array, job index of every block of the launch (total_blocks int32) - without it each block finds
+ * its job by a binary search over the device table (~9 dependent loads in front of one 32 x 32 tile).                       */
+int gwd_weight_prep_batch(const gwd_prep_job *jobs, int32_t n_jobs, int32_t total_blocks, const int32_t *block_job, void *stream);
 
 /* The set criterion of the line branch around the device LSAP (gwd_lsap), on PADDED targets (cap columns: column t belongs to image
  * bidx[t], valid[t] = 0 marks padding; the LSAP gives padding columns the dummy query Q).  All tensors fp32 unless noted; K = classes

@@ -660,7 +660,7 @@ class FakeDevice:
         gn = gy.reshape(B, L, C).float() * (cdf + n * pdf)
         du.copy_((st[..., 1] * (gn - gn.mean(dim=1, keepdim=True) - n * (gn * n).mean(dim=1, keepdim=True))).reshape(du.shape))
 
-    def weight_prep_batch(self, table, n_jobs, total_blocks):
+    def weight_prep_batch(self, table, n_jobs, total_blocks, block_job=None):
         raise NotImplementedError("the CPU stand-in never activates the batched weight cache")
 
     def point_sample_forward(self, fmap, coords, out, B, H, W, C, S, mode):
