@@ -472,6 +472,42 @@ __global__ void psp_pool_bwd_kernel(const T *__restrict__ gpass, const T *__rest
     }
 }
 
+// dst (B,H,W,C) = [residual +] src (B,Ho,Wo,C) placed on the pixels (s*i, s*j), zeros elsewhere: the data gradient of a 1x1 convolution
+// with stride s is a plain GEMM over the OUTPUT pixels followed by this placement (3/4 of the input pixels of a stride-2 layer get
+// no gradient at all; the transposed-gather implicit GEMM computed them as zero-page products).
+template <typename T>
+__global__ void stride_place_kernel(const T *__restrict__ src, const T *__restrict__ residual, T *__restrict__ dst, int B, int H, int W,
+                                    int Ho, int Wo, int C, int s) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int CV = C / VEC;
+    const int64_t total = (int64_t)B * H * W * CV;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        int64_t r = i / CV;
+        const int x = (int)(r % W);
+        r /= W;
+        const int y = (int)(r % H);
+        const int b = (int)(r / H);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        const int oy = y / s, ox = x / s;
+        const bool live = (y % s == 0) && (x % s == 0) && oy < Ho && ox < Wo;
+        if (live) v = *(const uint4 *)(src + (((size_t)b * Ho + oy) * Wo + ox) * C + cv * VEC);
+        if (residual) {
+            const uint4 rr = *(const uint4 *)(residual + i * VEC);
+            if (live) {
+                const T *a = (const T *)&v, *c = (const T *)&rr;
+                alignas(16) T o[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o[e] = from_f32<T>(to_f32(a[e]) + to_f32(c[e]));
+                v = *(const uint4 *)o;
+            } else {
+                v = rr;
+            }
+        }
+        *(uint4 *)(dst + i * VEC) = v;
+    }
+}
+
 inline int flat_grid(int64_t total) {
     int64_t b = (total + 255) / 256;
     return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
@@ -620,6 +656,21 @@ extern "C" int gwd_psp_pool_backward(const void *gpass, const void *g16, const v
         psp_pool_bwd_kernel<__bf16><<<flat_grid(total), 256, 0, (hipStream_t)stream>>>((const __bf16 *)gpass, (const __bf16 *)g16, (const __bf16 *)g8, (const __bf16 *)g4, (const __bf16 *)g2, (__bf16 *)gx, B, H, W, C, ldg);
     else
         psp_pool_bwd_kernel<float><<<flat_grid(total), 256, 0, (hipStream_t)stream>>>((const float *)gpass, (const float *)g16, (const float *)g8, (const float *)g4, (const float *)g2, (float *)gx, B, H, W, C, ldg);
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gwd_stride_place(const void *src, const void *residual, void *dst, int32_t B, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                                int32_t C, int32_t stride, int32_t dtype, void *stream) {
+    if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || stride <= 0) return -1;
+    const int vec = dtype == GWD_BF16 ? 8 : (dtype == GWD_F32 ? 4 : 0);
+    if (!vec) return -2;
+    if (C % vec) return -4;
+    const int64_t total = (int64_t)B * H * W * (C / vec);
+    if (dtype == GWD_BF16)
+        stride_place_kernel<__bf16><<<flat_grid(total), 256, 0, (hipStream_t)stream>>>((const __bf16 *)src, (const __bf16 *)residual, (__bf16 *)dst, B, H, W, Ho, Wo, C, stride);
+    else
+        stride_place_kernel<float><<<flat_grid(total), 256, 0, (hipStream_t)stream>>>((const float *)src, (const float *)residual, (float *)dst, B, H, W, Ho, Wo, C, stride);
     GWD_CHECK_LAUNCH();
     return 0;
 }

@@ -32,7 +32,7 @@ ENTRY_POINTS = [
     "gwd_plane_loss_forward", "gwd_plane_loss_backward", "gwd_collate",
     "gwd_anchor_depth_forward", "gwd_anchor_depth_backward", "gwd_mha_flash_forward", "gwd_mha_flash_backward",
     "gwd_ref_scores_forward", "gwd_ref_scores_backward", "gwd_ref_mix_forward", "gwd_ref_mix_backward", "gwd_unpad_add_batch", "gwd_stem_pack", "gwd_stem_forward", "gwd_pos_sine", "gwd_silog_finalize", "gwd_psp_pool_forward", "gwd_psp_pool_backward",
-    "gwd_match_cost", "gwd_set_losses_forward", "gwd_set_losses_backward", "gwd_resample_u8_pass", "gwd_gather2d", "gwd_point_sample_backward_gather",
+    "gwd_match_cost", "gwd_set_losses_forward", "gwd_set_losses_backward", "gwd_resample_u8_pass", "gwd_gather2d", "gwd_point_sample_backward_gather", "gwd_stride_place",
 ]
 
 
@@ -173,6 +173,7 @@ class HipLibrary:
         L.gwd_match_cost.argtypes = [vp] * 5 + [i32] * 6 + [f32, f32, vp]
         L.gwd_set_losses_forward.argtypes = [vp] * 9 + [f32] + [vp] * 4 + [i32] * 6 + [vp]
         L.gwd_set_losses_backward.argtypes = [vp] * 8 + [f32] + [vp] * 6 + [i32] * 6 + [vp]
+        L.gwd_stride_place.argtypes = [vp, vp, vp] + [i32] * 8 + [vp]
         L.gwd_psp_pool_forward.argtypes = [vp] * 5 + [i32] * 5 + [vp]
         L.gwd_psp_pool_backward.argtypes = [vp] * 6 + [i32] * 6 + [vp]
         L.gwd_pos_sine.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -506,6 +507,16 @@ class HipLibrary:
         if rc == -4:
             return False
         self._check(rc, "gwd_resample_backward_sep")
+        return True
+
+    def stride_place(self, src, residual, dst, stride):
+        """dst (B,H,W,C) = [residual +] src (B,Ho,Wo,C) on the pixels (stride*i, stride*j), zeros elsewhere; False when C is not vector-sized."""
+        B, H, W, C = dst.shape
+        Ho, Wo = src.shape[1], src.shape[2]
+        rc = self.lib.gwd_stride_place(_ptr(src), _ptr(residual), _ptr(dst), B, H, W, Ho, Wo, C, stride, dtype_code(dst), self._stream(src, dst))
+        if rc == -4:
+            return False
+        self._check(rc, "gwd_stride_place")
         return True
 
     def psp_pool_forward(self, x, p16, p8, p4, p2):

@@ -375,6 +375,12 @@ int gwd_resample_backward_sep(const void *gy, float *tmp, void *gx, int32_t B, i
                               int32_t C, int32_t mode, int32_t ldg, int32_t dtype, void *stream);
 
 /* k x k / stride k average pooling (nn.AvgPool2d(k, stride=k), points_sample.py:61-75), floor mode.  */
+/* dst (B,H,W,C) = [residual +] src (B,Ho,Wo,C) placed on the pixels (stride*i, stride*j), zero elsewhere: with a plain GEMM over
+ * the output pixels this is the data gradient of a 1x1 convolution with stride > 1 (the ResNet downsample convs,
+ * src/models/backbone.py:90-92), a quarter of the transposed-gather work.  C a multiple of 16 bytes, else -4.        */
+int gwd_stride_place(const void *src, const void *residual, void *dst, int32_t B, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t C,
+                     int32_t stride, int32_t dtype, void *stream);
+
 /* The four average pools of the PSP module (F.avg_pool2d with k = 16, 8, 4, 2; src/models/points/points_sample.py:107-113) from
  * ONE pass over x (B,H,W,C): p_k (B,H/k,W/k,C).  Backward in one pass as well: gx = g_pass + sum_k g_k[y/k][x/k] / k^2, where g_pass
  * (may be NULL; pixel pitch ldg, 0 = C) is the gradient that reaches the map directly - on this path the first channel slice of the

@@ -512,6 +512,13 @@ class FakeDevice:
             (g,) = torch.autograd.grad(o, x0, gy.reshape(B, Ho, Wo, C).permute(0, 3, 1, 2).float())
         gx.copy_(g.permute(0, 2, 3, 1).reshape(gx.shape))
 
+    def stride_place(self, src, residual, dst, stride):
+        out = torch.zeros(dst.shape) if residual is None else residual.float().clone()
+        Ho, Wo = src.shape[1], src.shape[2]
+        out[:, 0:Ho * stride:stride, 0:Wo * stride:stride] += src.float()
+        dst.copy_(out)
+        return True
+
     def psp_pool_forward(self, x, p16, p8, p4, p2):
         B, H, W, C = x.shape
         for k, out in ((16, p16), (8, p8), (4, p4), (2, p2)):
