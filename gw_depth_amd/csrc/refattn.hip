@@ -132,17 +132,30 @@ __global__ void ref_mix_fwd_kernel(const T *__restrict__ ra, const T *__restrict
     const T *src = ra + bt * RH;
     for (int e = threadIdx.x; e < RH; e += blockDim.x) sm[e] = to_f32(src[e]);
     __syncthreads();
-    for (int h = threadIdx.x; h < H; h += blockDim.x) {       // H <= 64: one lane per head, R terms each
+    {   // softmax over r for every head with ALL threads: thread (h, part) owns the references part, part + parts, ...
+        float *red = sm + RH;                                    // [parts][H]
+        const int parts = blockDim.x / H, hh = threadIdx.x % H, pp = threadIdx.x / H;
         float m = -INFINITY;
-        for (int r = 0; r < R; ++r) m = fmaxf(m, sm[r * H + h]);
+        if (pp < parts)
+            for (int r = pp; r < R; r += parts) m = fmaxf(m, sm[r * H + hh]);
+        if (pp < parts) red[pp * H + hh] = m;
+        __syncthreads();
+        for (int q = 0; q < parts; ++q) m = fmaxf(m, red[q * H + hh]);
+        __syncthreads();
         float l = 0.f;
-        for (int r = 0; r < R; ++r) {
-            const float p = __expf(sm[r * H + h] - m);
-            sm[r * H + h] = p;
-            l += p;
-        }
+        if (pp < parts)
+            for (int r = pp; r < R; r += parts) {
+                const float p = __expf(sm[r * H + hh] - m);
+                sm[r * H + hh] = p;
+                l += p;
+            }
+        if (pp < parts) red[pp * H + hh] = l;
+        __syncthreads();
+        l = 0.f;
+        for (int q = 0; q < parts; ++q) l += red[q * H + hh];
         const float inv = 1.0f / l;
-        for (int r = 0; r < R; ++r) sm[r * H + h] *= inv;
+        if (pp < parts)
+            for (int r = pp; r < R; r += parts) sm[r * H + hh] *= inv;
     }
     __syncthreads();
     if (att_out)
@@ -163,26 +176,57 @@ __global__ void ref_mix_bwd_kernel(const T *__restrict__ att, const T *__restric
     extern __shared__ float sm[];          // g row [C] | datt [R][H] | dot [H]
     const long bt = blockIdx.x;
     const int C = H * hd, RH = R * H;
-    float *gs = sm, *da = sm + C, *dot = da + RH;
-    for (int e = threadIdx.x; e < C; e += blockDim.x) gs[e] = to_f32(g[bt * C + e]);
+    const int GP = hd + 1;                                        // padded head pitch: lanes of one wave read gs at stride hd (16 heads, same bank)
+    float *gs = sm, *da = sm + H * GP, *dot = da + RH;
+    for (int e = threadIdx.x; e < C; e += blockDim.x) gs[(e / hd) * GP + e % hd] = to_f32(g[bt * C + e]);
     __syncthreads();
     const T *vb = refv + (bt / Tn) * R * C;
+    constexpr int VE = 16 / (int)sizeof(T);
+    const bool vec = (hd % VE) == 0 && ((uintptr_t)vb % 16) == 0;          // 16-byte pieces of a head's row (was: hd scalar loads)
     for (int e = threadIdx.x; e < RH; e += blockDim.x) {
         const int r = e / H, h = e % H;
         const T *vp = vb + (long)r * C + h * hd;
         float acc = 0.f;
-        for (int d = 0; d < hd; ++d) acc += gs[h * hd + d] * to_f32(vp[d]);
+        if (vec) {
+            for (int d = 0; d < hd; d += VE) {
+                const uint4 raw = *(const uint4 *)(vp + d);
+                const T *pv = (const T *)&raw;
+#pragma unroll
+                for (int k = 0; k < VE; ++k) acc += gs[h * GP + d + k] * to_f32(pv[k]);
+            }
+        } else {
+            for (int d = 0; d < hd; ++d) acc += gs[h * GP + d] * to_f32(vp[d]);
+        }
         da[e] = acc;
     }
     __syncthreads();
-    for (int h = threadIdx.x; h < H; h += blockDim.x) {
-        float s = 0.f;
-        for (int r = 0; r < R; ++r) s += to_f32(att[bt * RH + r * H + h]) * da[r * H + h];
-        dot[h] = s;
+    // dot[h] = sum_r att * datt: every thread takes a few r of one head, the partial sums meet in LDS (was: H threads walking all R
+    // references with dependent global loads while the other 240 waited)
+    float *part = dot + H;                                       // [blockDim / H][H]
+    const int parts = blockDim.x / H, hh = threadIdx.x % H, pp = threadIdx.x / H;
+    float av[4];                                                 // this thread's att values (R <= 128, parts >= 4 x ... see launch)
+    float s = 0.f;
+    int n = 0;
+    if (pp < parts)
+        for (int r = pp; r < R; r += parts, ++n) {
+            const float a = to_f32(att[bt * RH + r * H + hh]);
+            if (n < 4) av[n] = a;
+            s += a * da[r * H + hh];
+        }
+    if (pp < parts) part[pp * H + hh] = s;
+    __syncthreads();
+    if (threadIdx.x < H) {
+        float t = 0.f;
+        for (int q = 0; q < parts; ++q) t += part[q * H + threadIdx.x];
+        dot[threadIdx.x] = t;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < RH; e += blockDim.x)
-        dra[bt * RH + e] = from_f32<T>(to_f32(att[bt * RH + e]) * (da[e] - dot[e % H]));
+    n = 0;
+    if (pp < parts)
+        for (int r = pp; r < R; r += parts, ++n) {
+            const float a = n < 4 ? av[n] : to_f32(att[bt * RH + r * H + hh]);
+            dra[bt * RH + r * H + hh] = from_f32<T>(a * (da[r * H + hh] - dot[hh]));
+        }
 }
 
 bool shape_ok(int B, int nwin, int R, int H, int hd) { return B > 0 && nwin > 0 && R > 0 && R <= 128 && H > 0 && H <= 64 && hd > 0 && hd <= 64; }
@@ -262,7 +306,7 @@ extern "C" int gwd_ref_mix_forward(const void *ra, const void *ref_v, void *q_ne
     if (!ra || !ref_v || !q_new || T <= 0 || !shape_ok(B, 1, R, H, hd)) return -1;
     const unsigned grid = (unsigned)((long)B * T);
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = (size_t)R * H * sizeof(float);
+    const size_t lds = ((size_t)R * H + (size_t)(256 / H) * H) * sizeof(float);
     if (dtype == GWD_BF16) ref_mix_fwd_kernel<__bf16><<<grid, 256, lds, s>>>((const __bf16 *)ra, (const __bf16 *)ref_v, (__bf16 *)q_new, (__bf16 *)att, R, H, hd, T);
     else if (dtype == GWD_F32) ref_mix_fwd_kernel<float><<<grid, 256, lds, s>>>((const float *)ra, (const float *)ref_v, (float *)q_new, (float *)att, R, H, hd, T);
     else return -2;
@@ -277,7 +321,7 @@ extern "C" int gwd_ref_mix_backward(const void *att, const void *ref_v, const vo
     if (!att || !ref_v || !g || !d_ra || !d_ref_v || T <= 0 || T % 49 || !shape_ok(B, 1, R, H, hd)) return -1;
     if ((uintptr_t)g % 16) return -5;
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = ((size_t)H * hd + (size_t)R * H + H) * sizeof(float);
+    const size_t lds = ((size_t)H * (hd + 1) + (size_t)R * H + H + (size_t)(256 / H) * H) * sizeof(float);
     const unsigned rgrid = (unsigned)(((long)B * R * H + 3) / 4);
     const long C = (long)H * hd;
     const QOp go{g, 49 * C, C, hd};                    // g of q_new viewed as the (B*nwin, 49, H, hd) operand
