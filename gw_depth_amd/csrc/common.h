@@ -104,3 +104,14 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// Workgroup ids go round-robin over the 8 XCDs (id % 8), each with its own L2.  When `per` consecutive workgroups share one
+// window's rows of a packed operand (the head groups of a window attention), this renumbering keeps them on ONE XCD: the rows
+// are fetched into one L2 instead of up to 8, and the partial lines the heads write merge there before they go to memory.
+// Groups of 8 * per ids: physical j * 8 + g  ->  virtual g * per + j; a ragged last group keeps its ids.
+__device__ __forceinline__ long xcd_grouped_block(long b, long nb, int per) {
+    const long grp = 8L * per, base = (b / grp) * grp;
+    if (base + grp > nb) return b;
+    const long r = b - base;
+    return base + (r % 8) * per + r / 8;
+}

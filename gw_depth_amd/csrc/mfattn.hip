@@ -510,6 +510,7 @@ int launch(bool backward, const Args &a, const float *bias, float *dbias, const 
     if (gx * heads < 2048) gx = (2048 + heads - 1) / heads;       // ... but never fewer waves than fill the chip twice
     if (gx > n_windows) gx = n_windows;
     if (gx > 256) gx = 256;
+    if (gx >= 8) gx &= ~7L;                    // gridDim.x a multiple of 8: the head groups (blockIdx.y) of a window share its XCD / L2
     if (!backward) {
         constexpr int WAVES = 4;
         if (heads % WAVES) return 1;
@@ -665,7 +666,8 @@ __global__ __launch_bounds__(64 * WAVES) void tok_fwd_kernel(TOp q, TOp k, TOp v
     for (int e = lane * 8; e < PER; e += 512) *(uint4 *)(qi + e) = make_uint4(0, 0, 0, 0);
     lds_settle();
     const int tokc = lane < NT ? lane : NT - 1;
-    for (long pb = (long)blockIdx.x * WAVES + wave; pb < n_problems; pb += (long)gridDim.x * WAVES) {
+    const long vblock = (heads % WAVES) ? (long)blockIdx.x : xcd_grouped_block(blockIdx.x, gridDim.x, heads / WAVES);   // a window's head groups on one XCD
+    for (long pb = vblock * WAVES + wave; pb < n_problems; pb += (long)gridDim.x * WAVES) {
         const long w = pb / heads;
         const int head = (int)(pb - w * heads);
         put_row_4(qi, (const __bf16 *)q.p + w * q.ws + (long)tokc * q.ts + (long)head * q.hs, lane);
@@ -725,7 +727,8 @@ __global__ __launch_bounds__(64 * WAVES) void tok_bwd_kernel(TOp q, TOp k, TOp v
     for (int e = lane * 8; e < PER; e += 512) *(uint4 *)(qi + e) = make_uint4(0, 0, 0, 0);
     lds_settle();
     const int tokc = lane < NT ? lane : NT - 1;
-    for (long pb = (long)blockIdx.x * WAVES + wave; pb < n_problems; pb += (long)gridDim.x * WAVES) {
+    const long vblock = (heads % WAVES) ? (long)blockIdx.x : xcd_grouped_block(blockIdx.x, gridDim.x, heads / WAVES);   // a window's head groups on one XCD
+    for (long pb = vblock * WAVES + wave; pb < n_problems; pb += (long)gridDim.x * WAVES) {
         const long w = pb / heads;
         const int head = (int)(pb - w * heads);
         put_row_4(qi, (const __bf16 *)q.p + w * q.ws + (long)tokc * q.ts + (long)head * q.hs, lane);
@@ -785,7 +788,14 @@ int gwd_mfattn_token(bool backward, const gwd_strided *const *ops, long n_proble
     // measured per launch (53 k problems at E = 12, 13.8 k at 16, 3.8 k at 24): forward 107 / 39 / 23 us on the lane-per-token kernels ->
     // 90 / 20 / ~12 here; backward 224 / 77 / 43 -> 269 / 52 / 20: at E = 12 the 48 wave reductions of the VALU form are cheaper than this
     // kernel's 8-24-byte-per-lane row traffic, so that one case stays there
-    if (backward && e == 12) return 1;
+    // (with a window's head groups on one XCD - xcd_grouped_block - the E = 12 backward is the faster one here as well: same-box
+    //  A/B -0.1 ... -0.25 ms per step; GWD_TOK_BWD12=0 = the lane-per-token kernel for that case)
+    static int bwd12 = -1;
+    if (bwd12 < 0) {
+        const char *ev = getenv("GWD_TOK_BWD12");
+        bwd12 = (ev && ev[0] == '0') ? 0 : 1;
+    }
+    if (backward && e == 12 && !bwd12) return 1;
     switch (e) {
         case 12: return tok::run<12>(backward, ops, n_problems, heads, scale, s);
         case 16: return tok::run<16>(backward, ops, n_problems, heads, scale, s);

@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256) void tokattn_fwd_kernel(Op q, Op k, Op v, Op o
     const int lane = threadIdx.x & 63;
     const bool live = lane < NT;
     const int n = live ? lane : 0;
-    for (long pb = (long)blockIdx.x * 4 + (threadIdx.x >> 6); pb < n_problems; pb += (long)gridDim.x * 4) {
+    const long vblock = (heads % 4) ? (long)blockIdx.x : xcd_grouped_block(blockIdx.x, gridDim.x, heads / 4);      // a window's head groups on one XCD
+    for (long pb = vblock * 4 + (threadIdx.x >> 6); pb < n_problems; pb += (long)gridDim.x * 4) {
         const long w = pb / heads;
         const int h = (int)(pb - w * heads);
         float qr[R], kr[E], vr[E], a[R][E];
@@ -122,7 +123,8 @@ __global__ __launch_bounds__(256) void tokattn_bwd_kernel(Op q, Op k, Op v, Op g
     const int lane = threadIdx.x & 63;
     const bool live = lane < NT;
     const int n = live ? lane : 0;
-    for (long pb = (long)blockIdx.x * 4 + (threadIdx.x >> 6); pb < n_problems; pb += (long)gridDim.x * 4) {
+    const long vblock = (heads % 4) ? (long)blockIdx.x : xcd_grouped_block(blockIdx.x, gridDim.x, heads / 4);      // a window's head groups on one XCD
+    for (long pb = vblock * 4 + (threadIdx.x >> 6); pb < n_problems; pb += (long)gridDim.x * 4) {
         const long w = pb / heads;
         const int h = (int)(pb - w * heads);
         float qr[R], kr[E], vr[E], a[R][E], dor[R];
