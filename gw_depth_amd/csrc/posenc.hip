@@ -51,10 +51,12 @@ __global__ __launch_bounds__(1024) void pos_counts_kernel(const uint8_t *__restr
 __global__ __launch_bounds__(256) void pos_emit_kernel(const int16_t *__restrict__ counts, const float *__restrict__ dim_t, float *__restrict__ out,
                                                        int64_t total, int h, int w, int F, int normalize) {
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % (2 * F));
-        const int64_t p = idx / (2 * F);                       // (b, i, j)
-        const int j = (int)(p % w), i = (int)((p / w) % h);
-        const int64_t b = p / ((int64_t)w * h);
+        // 32-bit index arithmetic (the host checks total < 2^31): four 64-bit divisions per element were most of this kernel
+        const unsigned u = (unsigned)idx, F2 = 2u * (unsigned)F;
+        const int c = (int)(u % F2);
+        const unsigned p = u / F2;                             // (b, i, j)
+        const int j = (int)(p % (unsigned)w), i = (int)((p / (unsigned)w) % (unsigned)h);
+        const int64_t b = p / ((unsigned)w * (unsigned)h);
         const int16_t *cb = counts + b * h * w * 2;
         const bool isx = c >= F;
         float v = (float)cb[((size_t)i * w + j) * 2 + (isx ? 1 : 0)];
@@ -84,6 +86,7 @@ extern "C" int gwd_pos_sine(const uint8_t *mask_full, uint8_t *mask_level, int16
     if (out) {                                         // an embedding of F + F channels from the level's counts
         if (!dim_t || F <= 0) return -1;
         const int64_t total = (int64_t)B * h * w * 2 * F;
+        if (total >= (1LL << 31)) return -7;
         int64_t nb = (total + 255) / 256;
         pos_emit_kernel<<<(int)(nb > 4096 ? 4096 : nb), 256, 0, s>>>(counts, dim_t, out, total, h, w, F, normalize);
         GWD_CHECK_LAUNCH();
