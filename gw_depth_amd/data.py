@@ -5,7 +5,7 @@ src/datasets/coco.py:76-79), converts depth / segmentation there (src/datasets/g
 masks in collate_fn_aux (src/util/misc.py:273-313) and ships 24 bytes per pixel of fp32 / int64 to the GPU.  Here the host
 ships what the decoder produced - uint8 RGB, 16-bit depth in millimetres, uint8 labels: 5 bytes per pixel (8 with depth
 widened to int32) - and ONE kernel (gwd_collate) writes the normalised pixel-major image batch, the padding mask, metric depth
-and {0,1} labels.  Geometric / photometric augmentation (PIL resize, polygon clipping, colour jitter) stays where it is.
+and {0,1} labels.  The geometric and photometric augmentation in front of it follows below (DeviceAugment).
 """
 import torch
 
@@ -249,9 +249,9 @@ def crop_lines(lines, region):
 
 class DeviceAugment:
     """The reference's training / validation transform chain (src/datasets/coco.py:74-117) over DEVICE images: random flip, random
-    resize (optionally resize -> random crop -> resize), then device_collate normalises and pads.  `params()` draws the random
-    choices (the same choices the reference makes, from this object's own generator); `apply()` is deterministic given them.
-    ColorJitter is not part of this slice."""
+    resize (optionally resize -> random crop -> resize), colour jitter, then device_collate normalises and pads.  `params()` draws
+    the random choices (the same choices the reference makes, from this object's own generator); `apply()` is deterministic
+    given them."""
     SCALES = [480, 512, 544, 576, 608, 640, 672, 680, 690, 704, 736, 768, 788, 800]
 
     def __init__(self, train=True, max_size=1024, test_size=1024, seed=None):
@@ -266,12 +266,14 @@ class DeviceAugment:
         if r.random() >= 0.5:
             flip = None
         if r.random() < 0.5:
-            return {"flip": flip, "steps": [("resize", r.choice(self.SCALES), self.max_size)]}
-        s1 = r.choice([400, 500, 600])
-        oh, ow = resized_shape(w, h, s1)
-        cw, ch = r.randint(384, min(ow, 600)), r.randint(384, min(oh, 600))
-        i, j = r.randint(0, oh - ch), r.randint(0, ow - cw)
-        return {"flip": flip, "steps": [("resize", s1, None), ("crop", (i, j, ch, cw)), ("resize", r.choice(self.SCALES), self.max_size)]}
+            steps = [("resize", r.choice(self.SCALES), self.max_size)]
+        else:
+            s1 = r.choice([400, 500, 600])
+            oh, ow = resized_shape(w, h, s1)
+            cw, ch = r.randint(384, min(ow, 600)), r.randint(384, min(oh, 600))
+            i, j = r.randint(0, oh - ch), r.randint(0, ow - cw)
+            steps = [("resize", s1, None), ("crop", (i, j, ch, cw)), ("resize", r.choice(self.SCALES), self.max_size)]
+        return {"flip": flip, "steps": steps, "jitter": jitter_params(r)}          # T.ColorJitter() with its defaults (coco.py:107)
 
     @staticmethod
     def apply(rgb, depth_mm, labels, lines, p):
@@ -310,4 +312,38 @@ class DeviceAugment:
             rgb = device_resize_rgb(rgb, (h, w), hf, vf)
             depth_mm = device_resize_nearest(depth_mm, (h, w), hf, vf) if depth_mm is not None else None
             labels = device_resize_nearest(labels, (h, w), hf, vf) if labels is not None else None
+        if p.get("jitter"):
+            rgb = device_color_jitter(rgb, p["jitter"])
         return rgb.contiguous(), None if depth_mm is None else depth_mm.contiguous(), None if labels is None else labels.contiguous(), lines, keep
+
+
+# --- third slice: the photometric jitter (transforms_depth.py:551-600) ------------------------------------------------------------
+def hue_shift(hue_factor):
+    """uint8 shift of the H channel for adjust_hue(hue_factor): np.uint8(hue_factor * 255) as a C cast wraps it."""
+    return int(hue_factor * 255) & 255
+
+
+def device_color_jitter(rgb, ops):
+    """rgb uint8 (h,w,3) device image; ops: sequence of ('brightness' | 'contrast' | 'saturation' | 'hue', factor) applied in order,
+    each bit-exact with torchvision.transforms.functional.adjust_* on the PIL image (Pillow ImageEnhance / HSV conversion)."""
+    lib = hip.library()
+    cur = rgb.contiguous()
+    scratch = None
+    for name, f in ops:
+        out = torch.empty_like(cur)
+        if name == "contrast" and scratch is None:
+            scratch = torch.zeros(1, dtype=torch.int64, device=cur.device)
+        lib.color_adjust(cur, out, name, float(hue_shift(f)) if name == "hue" else float(f), scratch if name == "contrast" else None)
+        cur = out
+    return cur
+
+
+def jitter_params(rng, brightness=0.4, contrast=0.4, saturation=0.4, hue=0.4):
+    """The random choices of ColorJitter.__call__ (a random order of the four adjustments, one uniform factor each) from a
+    random.Random; the reference draws them from torch's generator (randperm(4), uniform_)."""
+    order = list(range(4))
+    rng.shuffle(order)
+    names = ["brightness", "contrast", "saturation", "hue"]
+    lo_hi = [(max(0.0, 1 - brightness), 1 + brightness), (max(0.0, 1 - contrast), 1 + contrast), (max(0.0, 1 - saturation), 1 + saturation),
+             (-hue, hue)]
+    return [(names[i], rng.uniform(*lo_hi[i])) for i in order]

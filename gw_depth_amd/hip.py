@@ -32,7 +32,7 @@ ENTRY_POINTS = [
     "gwd_plane_loss_forward", "gwd_plane_loss_backward", "gwd_collate",
     "gwd_anchor_depth_forward", "gwd_anchor_depth_backward", "gwd_mha_flash_forward", "gwd_mha_flash_backward",
     "gwd_ref_scores_forward", "gwd_ref_scores_backward", "gwd_ref_mix_forward", "gwd_ref_mix_backward", "gwd_unpad_add_batch", "gwd_stem_pack", "gwd_stem_forward", "gwd_pos_sine", "gwd_silog_finalize", "gwd_psp_pool_forward", "gwd_psp_pool_backward",
-    "gwd_match_cost", "gwd_set_losses_forward", "gwd_set_losses_backward", "gwd_resample_u8_pass", "gwd_gather2d", "gwd_point_sample_backward_gather", "gwd_stride_place",
+    "gwd_match_cost", "gwd_set_losses_forward", "gwd_set_losses_backward", "gwd_resample_u8_pass", "gwd_gather2d", "gwd_point_sample_backward_gather", "gwd_stride_place", "gwd_color_adjust",
 ]
 
 
@@ -173,6 +173,7 @@ class HipLibrary:
         L.gwd_match_cost.argtypes = [vp] * 5 + [i32] * 6 + [f32, f32, vp]
         L.gwd_set_losses_forward.argtypes = [vp] * 9 + [f32] + [vp] * 4 + [i32] * 6 + [vp]
         L.gwd_set_losses_backward.argtypes = [vp] * 8 + [f32] + [vp] * 6 + [i32] * 6 + [vp]
+        L.gwd_color_adjust.argtypes = [vp, vp, vp, i64, i32, f32, vp]
         L.gwd_stride_place.argtypes = [vp, vp, vp] + [i32] * 8 + [vp]
         L.gwd_psp_pool_forward.argtypes = [vp] * 5 + [i32] * 5 + [vp]
         L.gwd_psp_pool_backward.argtypes = [vp] * 6 + [i32] * 6 + [vp]
@@ -607,6 +608,15 @@ class HipLibrary:
         self._check(self.lib.gwd_certain_sample(_ptr(small), _ptr(large), _ptr(coords), B, hs, ws, H, W, _ptr(edges),
                                                 edges.numel() - 1, sample_num, self._stream(small, large, coords)),
                     "gwd_certain_sample")
+
+    COLOR_MODES = {"brightness": 0, "contrast": 1, "saturation": 2, "hue": 3}
+
+    def color_adjust(self, rgb, out, mode, factor, scratch=None):
+        """One ColorJitter adjustment on a uint8 (h,w,3) device image (gwd_color_adjust); scratch: 1-element int64 tensor for 'contrast'."""
+        if rgb.dtype != torch.uint8 or out.dtype != torch.uint8 or rgb.shape != out.shape or rgb.shape[-1] != 3:
+            raise ValueError("color_adjust: uint8 (h,w,3) images expected")
+        self._check(self.lib.gwd_color_adjust(_ptr(rgb), _ptr(out), _ptr(scratch), rgb.numel() // 3, self.COLOR_MODES[mode], float(factor),
+                                              self._stream(rgb, out)), "gwd_color_adjust")
 
     def resample_u8_pass(self, src, dst, bounds, kk, axis, row_stride, base0, step0, base1, step1):
         """One pass of Pillow's BILINEAR resize over uint8 pixels (gwd_resample_u8_pass); src may be a window / flipped view given by

@@ -488,6 +488,13 @@ int gwd_resample_u8_pass(const uint8_t *src, uint8_t *dst, const int32_t *bounds
 int gwd_gather2d(const void *src, void *dst, const int32_t *ytab, const int32_t *xtab, int32_t oh, int32_t ow,
                  int64_t src_row_stride_bytes, int32_t elem_bytes, void *stream);
 
+/* One adjustment of the reference's ColorJitter (src/datasets/transforms_depth.py:551-600) on a uint8 RGB image of npix pixels,
+ * bit-exact with torchvision's PIL path: mode 0 brightness, 1 contrast, 2 saturation (Pillow ImageEnhance: Image.blend with a black /
+ * mean-luma / luma degenerate image, factor >= 0), 3 hue (RGB -> HSV, H + shift with uint8 wrap-around, HSV -> RGB; here `factor` is
+ * the SHIFT 0..255 = uint8(hue_factor * 255) as the caller's host arithmetic casts it: int(hue_factor * 255) & 255).  scratch: 8 bytes of device memory (the contrast mean's luma sum; may be NULL for the other modes).  Data-pipeline
+ * entry point: not meant for HIP-graph capture (mode 1 clears its scratch with a memset node).                                     */
+int gwd_color_adjust(const uint8_t *rgb, uint8_t *out, uint64_t *scratch, int64_t npix, int32_t mode, float factor, void *stream);
+
 #define GWD_COLLATE_BATCH 16
 typedef struct {
     const void *rgb, *depth_mm, *labels;

@@ -336,6 +336,17 @@ class FakeDevice:
         off = ytab.long()[:, None, None] * rs + xtab.long()[None, :, None] * per + torch.arange(per)[None, None, :]
         dst.view(-1).copy_(flat[off].reshape(-1))
 
+    def color_adjust(self, rgb, out, mode, factor, scratch=None):
+        from oracle import pil_color_ref as C                       # the CPU stand-in is test infrastructure: it may use the oracle
+        a = rgb.cpu().numpy()
+        if mode == "hue":
+            hsv = C.rgb_to_hsv(a)
+            hsv[..., 0] = ((hsv[..., 0].astype("int32") + int(factor)) & 255).astype("uint8")
+            r = C.hsv_to_rgb(hsv)
+        else:
+            r = {"brightness": C.adjust_brightness, "contrast": C.adjust_contrast, "saturation": C.adjust_saturation}[mode](a, factor)
+        out.copy_(torch.from_numpy(r))
+
     def match_cost(self, logits, lines, tgt_lines, tgt_labels, cost, w_line, w_class):
         prob = logits.softmax(-1)
         l1 = (lines[..., None, :] - tgt_lines).abs().sum(-1)

@@ -135,6 +135,7 @@ def test_params_follow_the_reference_recipe():
                 i, j, ch, cw = s[1]
                 assert 384 <= ch <= 600 and 384 <= cw <= 600 and i >= 0 and j >= 0
     assert kinds == {("resize",), ("resize", "crop", "resize")}
+    assert sorted(n for n, _ in p["jitter"]) == ["brightness", "contrast", "hue", "saturation"]
     assert data.DeviceAugment(train=False).params(1280, 720) == {"flip": None, "steps": [("resize", 1024, 1024)]}
 
 
@@ -169,3 +170,74 @@ def test_device_resizes_match_golden_and_pillow_at_dataset_size(gold):
     np.testing.assert_array_equal(got, ref.resize_bilinear_u8(rgb, oh, ow))
     twice = data.device_resize_rgb(data.device_resize_rgb(t, (720, 1280), hflip=True), (720, 1280), hflip=True)
     assert torch.equal(twice, t)
+
+
+# ------------------------------------------------------------------------------------------------------------ colour jitter
+COLOR_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pil_color.npz")
+
+
+@pytest.fixture(scope="module")
+def cgold():
+    return dict(np.load(COLOR_GOLDEN))
+
+
+def _color_cases(cgold):
+    for f in cgold["factors"]:
+        for name in ("brightness", "contrast", "saturation"):
+            yield name, float(f), cgold["%s_%.2f" % (name, f)]
+    for f in cgold["hue_factors"]:
+        yield "hue", float(f), cgold["hue_%.2f" % f]
+
+
+def test_colour_oracle_matches_the_pillow_golden_vectors(cgold):
+    from oracle import pil_color_ref as C
+    fn = {"brightness": C.adjust_brightness, "contrast": C.adjust_contrast, "saturation": C.adjust_saturation, "hue": C.adjust_hue}
+    np.testing.assert_array_equal(C.rgb_to_hsv(cgold["rgb"]), cgold["hsv"])
+    for name, f, want in _color_cases(cgold):
+        np.testing.assert_array_equal(fn[name](cgold["rgb"], f), want, err_msg="%s %.2f" % (name, f))
+
+
+def test_colour_oracle_matches_the_installed_pillow():
+    Image = pytest.importorskip("PIL.Image")
+    from PIL import ImageEnhance
+    from oracle import pil_color_ref as C
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (90, 120, 3), dtype=np.uint8)
+    im = Image.fromarray(img)
+    for f in (0.61, 0.99, 1.0, 1.39):
+        np.testing.assert_array_equal(C.adjust_brightness(img, f), np.asarray(ImageEnhance.Brightness(im).enhance(f)))
+        np.testing.assert_array_equal(C.adjust_contrast(img, f), np.asarray(ImageEnhance.Contrast(im).enhance(f)))
+        np.testing.assert_array_equal(C.adjust_saturation(img, f), np.asarray(ImageEnhance.Color(im).enhance(f)))
+    hsv = np.asarray(im.convert("HSV"))
+    np.testing.assert_array_equal(C.rgb_to_hsv(img), hsv)
+    np.testing.assert_array_equal(C.hsv_to_rgb(hsv), np.asarray(Image.fromarray(hsv, "HSV").convert("RGB")))
+
+
+def test_jitter_params_and_hue_shift():
+    import random
+    ops = data.jitter_params(random.Random(3))
+    assert sorted(n for n, _ in ops) == ["brightness", "contrast", "hue", "saturation"]
+    for n, f in ops:
+        assert (-0.4 <= f <= 0.4) if n == "hue" else (0.6 <= f <= 1.4)
+    assert data.hue_shift(0.1) == 25 and data.hue_shift(-0.3) == 180 and data.hue_shift(0.0) == 0 and data.hue_shift(-0.001) == 0
+
+
+@pytest.mark.gpu
+def test_device_colour_jitter_bit_exact(cgold):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import pil_color_ref as C
+    hip.set_library(None)
+    rgb = torch.from_numpy(cgold["rgb"]).cuda()
+    for name, f, want in _color_cases(cgold):
+        got = data.device_color_jitter(rgb, [(name, f)])
+        np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg="%s %.2f" % (name, f))
+    # a full jitter chain on a frame-sized image against the oracle, step by step
+    rng = np.random.default_rng(6)
+    img = rng.integers(0, 256, (480, 853, 3), dtype=np.uint8)
+    ops = [("contrast", 1.23), ("hue", -0.31), ("brightness", 0.77), ("saturation", 1.38)]
+    want = img
+    fn = {"brightness": C.adjust_brightness, "contrast": C.adjust_contrast, "saturation": C.adjust_saturation, "hue": C.adjust_hue}
+    for name, f in ops:
+        want = fn[name](want, f)
+    np.testing.assert_array_equal(data.device_color_jitter(torch.from_numpy(img).cuda(), ops).cpu().numpy(), want)
