@@ -171,6 +171,7 @@ class WgradQueue:
     def __init__(self):
         self.jobs, self.active = [], False
         self._pool, self._used, self._want, self._dev = None, 0, 0, None
+        self._retired = []
 
     def scratch(self, shape, device):
         """Zeroed fp32 scratch for a weight gradient formed in a padded shape.  Inside a backward pass the pieces come from ONE
@@ -228,6 +229,8 @@ class WgradQueue:
             self.jobs, self.active = [], False
             if self._want and self._dev is not None and (self._pool is None or self._pool.numel() < self._want) \
                     and not torch.cuda.is_current_stream_capturing():
+                if self._pool is not None:
+                    self._retired.append(self._pool)          # a captured HIP graph may still zero / write the old buffer: never freed
                 self._pool = torch.empty(self._want, dtype=torch.float32, device=self._dev)     # for the next pass
         return False
 
@@ -303,6 +306,7 @@ def pos_sine(mask, num_pos_feats, normalize, temperature=10000.0):
 
 
 _STEM_PACKED = {}
+_STEM_RETIRED = []
 
 
 def stem(x, w, scale, shift):
@@ -315,6 +319,8 @@ def stem(x, w, scale, shift):
     if ent is None or ent[0] != key:
         packed = torch.empty(hip.STEM_PACKED_ELEMS, dtype=torch.bfloat16, device=w.device)
         lib.stem_pack(w.detach(), scale.detach().float().contiguous(), packed)
+        if ent is not None:
+            _STEM_RETIRED.append(ent[1])                      # a captured graph may still read the previous copy
         ent = _STEM_PACKED[w.data_ptr()] = (key, packed)
     B, H, W, _ = x.shape
     y = torch.empty((B, hip.stem_out(H), hip.stem_out(W), 64), dtype=x.dtype, device=x.device)
