@@ -27,9 +27,9 @@ __device__ __forceinline__ f32x16 mma(const bf16x8 &a, const bf16x8 &b, const f3
 }
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
-template <int CIN, int TH> struct Halo {
+template <int CIN, int TH, int RPW = 2> struct Halo {
     static constexpr int HH = TH + 2, HPIX = HH * HW;       // halo rows / pixels
-    static constexpr int NT = 32 * TH;                      // threads: one wave per two output rows
+    static constexpr int NT = 64 * TH / RPW;                // threads: one wave per RPW output rows
     static constexpr int PS = CIN + 8;                      // pixel stride in elements (80 / 144 bytes: spreads the banks)
     static constexpr int CHUNKS = HPIX * (CIN / 8);         // 16-byte pieces of one halo
     static constexpr int NCH = (CHUNKS + NT - 1) / NT;      // per thread
@@ -59,9 +59,11 @@ __device__ __forceinline__ void halo_put(__bf16 *halo, int chunk, const u32x4 &v
 // ------------------------------------------------------------------------------------------------ forward / data gradient
 // x: [B][Hs][Ws][CIN] (Hs = Hv / 2 when UP), w: [COUT][3][3][CIN] bf16 (already scaled / transposed by gwd_weight_prep),
 // y: [B][Hv][Wv][COUT].  FLIP: the data-gradient gather (source = pixel + 1 - tap).
-template <int CIN, int COUT, int TH, bool UP, bool FLIP>
-__global__ __launch_bounds__(32 * TH) void tconv_fwd_kernel(const gwd_conv_desc d, int tiles_y, int tiles_x, int ntiles) {
-    using H = Halo<CIN, TH>;
+template <int CIN, int COUT, int TH, bool UP, bool FLIP, int RPW = 2>
+__global__ __launch_bounds__(64 * TH / RPW) void tconv_fwd_kernel(const gwd_conv_desc d, int tiles_y, int tiles_x, int ntiles) {
+    // RPW = output rows per wave: 2 halves the weight-fragment reads per MFMA; 1 doubles the waves of a workgroup - for the layers whose
+    // LDS footprint (weights + halo) allows ONE workgroup per CU, that is the difference between one and two waves per SIMD
+    using H = Halo<CIN, TH, RPW>;
     constexpr int NT = H::NT;
     constexpr int NTL = (COUT + 31) / 32, COUTP = 32 * NTL;  // output-channel tiles; rows COUT..COUTP-1 of the weight image are zero
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
@@ -111,9 +113,9 @@ __global__ __launch_bounds__(32 * TH) void tconv_fwd_kernel(const gwd_conv_desc 
 #pragma unroll
             for (int i = 0; i < H::NCH; ++i) pre[i] = halo_fetch<CIN, TH, UP>(x, tid + NT * i, nb, ny, nx, Hs, Ws, Hv, Wv);
         }
-        f32x16 acc[2][NTL];
+        f32x16 acc[RPW][NTL];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < RPW; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
@@ -124,22 +126,22 @@ __global__ __launch_bounds__(32 * TH) void tconv_fwd_kernel(const gwd_conv_desc 
             const int dy = FLIP ? 2 - kh : kh, dx = FLIP ? 2 - kw : kw;      // halo offset of the tap (0..2)
 #pragma unroll
             for (int s = 0; s < CIN / 16; ++s) {
-                bf16x8 bf[2];
+                bf16x8 bf[RPW];
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-                    bf[mt] = *(const bf16x8 *)(halo + ((2 * wave + mt + dy) * HW + r + dx) * H::PS + 16 * s + 8 * h);
+                for (int mt = 0; mt < RPW; ++mt)
+                    bf[mt] = *(const bf16x8 *)(halo + ((RPW * wave + mt + dy) * HW + r + dx) * H::PS + 16 * s + 8 * h);
 #pragma unroll
                 for (int nt = 0; nt < NTL; ++nt) {
                     const bf16x8 af = *(const bf16x8 *)(wl + (tap * COUTP + 32 * nt + r) * H::PS + 16 * s + 8 * h);
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = mma(af, bf[mt], acc[mt][nt]);
+                    for (int mt = 0; mt < RPW; ++mt) acc[mt][nt] = mma(af, bf[mt], acc[mt][nt]);
                 }
             }
         }
         // epilogue: lane = pixel, registers 4g..4g+3 = channels 32 nt + 8 g + 4 h + 0..3
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int oy = oy0 + 2 * wave + mt, ox = ox0 + r;
+        for (int mt = 0; mt < RPW; ++mt) {
+            const int oy = oy0 + RPW * wave + mt, ox = ox0 + r;
             if (oy < Hv && ox < Wv) {
                 __bf16 *dst = y + (((size_t)b * Hv + oy) * Wv + ox) * COUT;
                 const __bf16 *rsd = d.residual ? (const __bf16 *)d.residual + (((size_t)b * Hv + oy) * Wv + ox) * COUT : nullptr;
@@ -190,6 +192,23 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
     const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
     long grid = 256L * per_cu;
     if (grid > ntiles) grid = ntiles;
+    static int rpw1 = -1;                                       // GWD_TCONV_RPW1: bit mask of the layers that run one row per wave (A/B)
+    if (rpw1 < 0) {                                             //   1: 64 -> 64, 2: 64 -> 32, 4: 32 -> 64, 8: 32 -> 32
+        const char *e = getenv("GWD_TCONV_RPW1");
+        rpw1 = e ? atoi(e) : 1;
+    }
+    constexpr int bit = (CIN == 64 && COUT == 64) ? 1 : (CIN == 64 && COUT == 32) ? 2 : (CIN == 32 && COUT == 64) ? 4 : (CIN == 32 && COUT == 32) ? 8 : 0;
+    if constexpr (bit != 0) {
+        if (rpw1 & bit) {
+            static bool attr1 = false;
+            if (!attr1) {
+                (void)hipFuncSetAttribute((const void *)tconv_fwd_kernel<CIN, COUT, TH, UP, FLIP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr1 = true;
+            }
+            tconv_fwd_kernel<CIN, COUT, TH, UP, FLIP, 1><<<(unsigned)grid, 64 * TH, lds, s>>>(*d, ty, tx, (int)ntiles);
+            return 1;
+        }
+    }
     tconv_fwd_kernel<CIN, COUT, TH, UP, FLIP><<<(unsigned)grid, 32 * TH, lds, s>>>(*d, ty, tx, (int)ntiles);
     return 1;
 }
