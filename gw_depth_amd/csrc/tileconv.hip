@@ -227,12 +227,12 @@ __device__ __forceinline__ bf16x8 gather16(const __bf16 *img, int rs, int pix0, 
     return u.v;
 }
 
-template <int CX, int CG, bool UP>
-__global__ __launch_bounds__(192) void tconv_wgrad_kernel(const gwd_conv_desc d, float *__restrict__ dw, int tiles_y, int tiles_x, int ntiles) {
-    constexpr int TH = 8, HPIX = (TH + 2) * HW;
+template <int CX, int CG, bool UP, int TPW = 3>
+__global__ __launch_bounds__(64 * 9 / TPW) void tconv_wgrad_kernel(const gwd_conv_desc d, float *__restrict__ dw, int tiles_y, int tiles_x, int ntiles) {
+    constexpr int TH = 8, HPIX = (TH + 2) * HW, NTW = 64 * 9 / TPW;     // TPW taps per wave: 3 waves x 3 taps, or 9 waves x 1 tap
     using H = Halo<CX, TH>;
     constexpr int GS = CG + 8;                              // gy image pixel stride
-    constexpr int GCH = TH * TW * (CG / 8), NG = (GCH + 191) / 192, NX = (H::CHUNKS + 191) / 192;
+    constexpr int GCH = TH * TW * (CG / 8), NG = (GCH + NTW - 1) / NTW, NX = (H::CHUNKS + NTW - 1) / NTW;
     constexpr int TX = (CX + 31) / 32, TG = (CG + 31) / 32;   // 16 channels: the column gathers of a 32-wide tile run on into the next
                                                              // pixel's bytes - those rows / columns of the product are never flushed
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
@@ -240,9 +240,9 @@ __global__ __launch_bounds__(192) void tconv_wgrad_kernel(const gwd_conv_desc d,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const __bf16 *x = (const __bf16 *)d.x, *gy = (const __bf16 *)d.y;      // gwd_conv_wgrad: the desc's y slot carries the output gradient
     const int Hv = d.Ho, Wv = d.Wo, Hs = d.Hi, Ws = d.Wi;
-    f32x16 acc[3][TG][TX];
+    f32x16 acc[TPW][TG][TX];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < TPW; ++a)
 #pragma unroll
         for (int b = 0; b < TG; ++b)
 #pragma unroll
@@ -270,17 +270,17 @@ __global__ __launch_bounds__(192) void tconv_wgrad_kernel(const gwd_conv_desc d,
         int b, oy0, ox0;
         where(tile, b, oy0, ox0);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) px[i] = halo_fetch<CX, 8, UP>(x, tid + 192 * i, b, oy0, ox0, Hs, Ws, Hv, Wv);
+        for (int i = 0; i < NX; ++i) px[i] = halo_fetch<CX, 8, UP>(x, tid + NTW * i, b, oy0, ox0, Hs, Ws, Hv, Wv);
 #pragma unroll
-        for (int i = 0; i < NG; ++i) pg[i] = gy_fetch(tid + 192 * i, b, oy0, ox0);
+        for (int i = 0; i < NG; ++i) pg[i] = gy_fetch(tid + NTW * i, b, oy0, ox0);
     }
     for (; tile < ntiles; tile += gridDim.x) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < NX; ++i) halo_put<CX, 8>(halo, tid + 192 * i, px[i]);
+        for (int i = 0; i < NX; ++i) halo_put<CX, 8>(halo, tid + NTW * i, px[i]);
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
-            const int chunk = tid + 192 * i;
+            const int chunk = tid + NTW * i;
             if (chunk < GCH) *(u32x4 *)(gimg + (chunk / (CG / 8)) * GS + (chunk % (CG / 8)) * 8) = pg[i];
         }
         __syncthreads();
@@ -288,9 +288,9 @@ __global__ __launch_bounds__(192) void tconv_wgrad_kernel(const gwd_conv_desc d,
             int nb, ny, nx;
             where(tile + gridDim.x, nb, ny, nx);
 #pragma unroll
-            for (int i = 0; i < NX; ++i) px[i] = halo_fetch<CX, 8, UP>(x, tid + 192 * i, nb, ny, nx, Hs, Ws, Hv, Wv);
+            for (int i = 0; i < NX; ++i) px[i] = halo_fetch<CX, 8, UP>(x, tid + NTW * i, nb, ny, nx, Hs, Ws, Hv, Wv);
 #pragma unroll
-            for (int i = 0; i < NG; ++i) pg[i] = gy_fetch(tid + 192 * i, nb, ny, nx);
+            for (int i = 0; i < NG; ++i) pg[i] = gy_fetch(tid + NTW * i, nb, ny, nx);
         }
 #pragma unroll 2
         for (int ks = 0; ks < 16; ++ks) {                   // 16 consecutive pixels of tile row ks / 2
@@ -299,8 +299,8 @@ __global__ __launch_bounds__(192) void tconv_wgrad_kernel(const gwd_conv_desc d,
 #pragma unroll
             for (int b = 0; b < TG; ++b) af[b] = gather16(gimg, GS, row * TW + x0, 32 * b, lane);
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const int tap = 3 * wave + a, kh = tap / 3, kw = tap - 3 * kh;
+            for (int a = 0; a < TPW; ++a) {
+                const int tap = TPW * wave + a, kh = tap / 3, kw = tap - 3 * kh;
 #pragma unroll
                 for (int c = 0; c < TX; ++c) {
                     const bf16x8 bf = gather16(halo, H::PS, (row + kh) * HW + x0 + kw, 32 * c, lane);
@@ -313,8 +313,8 @@ __global__ __launch_bounds__(192) void tconv_wgrad_kernel(const gwd_conv_desc d,
     // flush: D[cg][cx] of tap -> dw[cg][tap][cx] (fp32 atomics, lanes = consecutive cx)
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const int tap = 3 * wave + a;
+    for (int a = 0; a < TPW; ++a) {
+        const int tap = TPW * wave + a;
 #pragma unroll
         for (int b = 0; b < TG; ++b)
 #pragma unroll
@@ -354,6 +354,22 @@ int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s) {
     const long cap = cap_env > 0 ? cap_env : (CX * CG <= 1024 ? 512 : 256);
     if (grid > cap) grid = cap;
     if (grid > ntiles) grid = ntiles;
+    // nine waves with one filter tap each instead of three with three: 64 x 32 at 240 x 320 85 -> 52 us (more waves per CU for the
+    // same LDS), 32 x 32 at 480 x 640 120 -> 126 us - so only the 64-channel input runs that way (GWD_TCONV_WGRAD_TPW1=0 / 1 forces)
+    static int tpw1 = -1;
+    if (tpw1 < 0) {
+        const char *e = getenv("GWD_TCONV_WGRAD_TPW1");
+        tpw1 = e ? (e[0] == '1' ? 1 : 0) : 2;
+    }
+    if (tpw1 == 1 || (tpw1 == 2 && CX == 64)) {
+        static bool attr1 = false;
+        if (!attr1) {
+            (void)hipFuncSetAttribute((const void *)tconv_wgrad_kernel<CX, CG, UP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr1 = true;
+        }
+        tconv_wgrad_kernel<CX, CG, UP, 1><<<(unsigned)grid, 576, lds, s>>>(*d, dw, ty, tx, (int)ntiles);
+        return 1;
+    }
     tconv_wgrad_kernel<CX, CG, UP><<<(unsigned)grid, 192, lds, s>>>(*d, dw, ty, tx, (int)ntiles);
     return 1;
 }
