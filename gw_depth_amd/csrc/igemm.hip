@@ -1302,6 +1302,14 @@ static int wgrad_target_blocks(int resident) {
     }
     return v > 0 ? v : resident;     // default: exactly one full round of resident workgroups (no tail round)
 }
+static int wgrad_per_cu_128() {              // resident 128 x 128 weight-gradient workgroups per CU the split count aims at (A/B: GWD_WGRAD_PER_CU128)
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GWD_WGRAD_PER_CU128");
+        v = e ? atoi(e) : 2;
+    }
+    return v;
+}
 static int wgrad_variant() {
     static int v = -1;
     if (v < 0) {
@@ -1369,7 +1377,8 @@ int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s, WgradCollecto
         const int tiles = ((N + BN_ - 1) / BN_) * ((K + BK_ - 1) / BK_);                                     \
         const int lds = ST_ * 32 * (BN_ + BK_) * 2;                                                          \
         int per_cu = (160 * 1024) / lds;                  /* LDS-limited; the >= 128-wide tiles hold ~200 VGPRs */      \
-        if (BN_ * BK_ >= 128 * 128 && per_cu > 2) per_cu = 2;  /* -> 2 waves per SIMD = 2 workgroups per CU */          \
+        if (BN_ * BK_ > 128 * 128 && per_cu > 2) per_cu = 2;   /* -> 2 waves per SIMD = 2 workgroups per CU */          \
+        if (BN_ * BK_ == 128 * 128 && per_cu > wgrad_per_cu_128()) per_cu = wgrad_per_cu_128();  /* 138 registers: 3 fit */      \
         /* plain GEMMs: a step costs ~0.45 us, one split's flush tiles * BN * BK * 4 bytes at ~1.3 TB/s */                \
         const double bal = (fast == 2 && wgrad_variant() != 9) ? 0.45e-6 * 1.3e12 / ((double)tiles * BN_ * BK_ * 4) : 0.0;  \
         wgrad_split(M, tiles, 32, splits, m_per_block, 256 * (per_cu > 4 ? 4 : per_cu), bal);                \
