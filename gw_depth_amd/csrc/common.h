@@ -40,6 +40,12 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
+// gwd_conv_desc.gate: backward of an activation from its OUTPUT rv (what act_bwd_kernel computes with act_scale = 1)
+__device__ __forceinline__ float gate_grad(float g, float rv, int act) {
+    if (act == GWD_ACT_RELU) return rv > 0.f ? g : 0.f;
+    return g * (rv > 0.f ? 1.0f : rv + 1.0f);             // GWD_ACT_ELU (check_desc admits nothing else)
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -265,6 +265,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const gwd_conv_desc d) {
     T *z = (T *)d.z;
     const T *res = (const T *)d.residual;
     const T *mul = MULT ? (const T *)d.mult : nullptr;
+    const T *gate = MULT ? nullptr : (const T *)d.gate;        // never together with a multiplier (check_desc)
     if constexpr (sizeof(T) == 2) {
         if ((N & 7) == 0) {
             // each wave transposes one 32x32 accumulator tile at a time through a private LDS patch, then every
@@ -320,8 +321,16 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const gwd_conv_desc d) {
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) out[e] = (__bf16)(apply_act(v[e], d.act) * d.act_scale * (float)mv[e] + (float)rv[e]);
                             } else {
+                                float gm[8];                 // desc.gate: backward of the producer's activation, from its output
 #pragma unroll
-                                for (int e = 0; e < 8; ++e) out[e] = (__bf16)(apply_act(v[e], d.act) * d.act_scale);
+                                for (int e = 0; e < 8; ++e) gm[e] = d.act_scale;
+                                if (gate) {
+                                    const bf16x8 gv = *(const bf16x8 *)(gate + o);
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) gm[e] = gate_grad(d.act_scale, (float)gv[e], d.gate_act);
+                                }
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) out[e] = (__bf16)(apply_act(v[e], d.act) * gm[e]);
                             }
                             *(bf16x8 *)(y + o) = out;
                         }
@@ -349,6 +358,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const gwd_conv_desc d) {
                 if (z) z[o] = from_f32<T>(v);
                 v = apply_act(v, d.act) * d.act_scale;
                 if (mul) v = v * to_f32(mul[o]) + (res ? to_f32(res[o]) : 0.f);
+                if (gate) v = gate_grad(v, to_f32(gate[o]), d.gate_act);
                 y[o] = from_f32<T>(v);
             }
         }
@@ -571,6 +581,7 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
     T *z = (T *)d.z;
     const T *res = (const T *)d.residual;
     const T *mul = MULT ? (const T *)d.mult : nullptr;       // compile-time: the multiplier path costs the plain kernels registers
+    const T *gate = MULT ? nullptr : (const T *)d.gate;      // never together with a multiplier (check_desc)
     float *stage = (float *)smem + wave * (32 * 36);
     const int vr = lane >> 2, vc = (lane & 3) * 8;
 #pragma unroll
@@ -621,8 +632,16 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
 #pragma unroll
                         for (int e = 0; e < 8; ++e) out[e] = (__bf16)(apply_act(v[e], d.act) * d.act_scale * (float)mv[e] + (float)rv[e]);
                     } else {
+                        float gm[8];                         // desc.gate: backward of the producer's activation, from its output
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) out[e] = (__bf16)(apply_act(v[e], d.act) * d.act_scale);
+                        for (int e = 0; e < 8; ++e) gm[e] = d.act_scale;
+                        if (gate) {
+                            const bf16x8 gv = *(const bf16x8 *)(gate + o);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) gm[e] = gate_grad(d.act_scale, (float)gv[e], d.gate_act);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) out[e] = (__bf16)(apply_act(v[e], d.act) * gm[e]);
                     }
                     *(bf16x8 *)(y + o) = out;
                 }
@@ -1153,6 +1172,7 @@ int check_desc(const gwd_conv_desc *d) {
     if (d->gather == GWD_GATHER_UPSAMPLED && (d->stride != 1 || d->Hv <= 0 || d->Wv <= 0)) return -6;
     if ((int64_t)d->B * d->Ho * d->Wo >= (1LL << 31) || (int64_t)d->KH * d->KW * d->Cin >= (1LL << 31)) return -7;
     if ((int64_t)d->B * d->Hi * d->Wi * d->Cin >= (1LL << 40)) return -7;
+    if (d->gate && ((d->gate_act != GWD_ACT_RELU && d->gate_act != GWD_ACT_ELU) || d->mult)) return -4;
     return 0;
 }
 

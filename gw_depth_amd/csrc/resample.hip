@@ -97,7 +97,8 @@ template <> struct RsRaw<8> { typedef uint2 type; };
 // legacy-nearest source is (sy, sx) - at most ceil(Ho/Hs)+1 candidates per axis, tested with the forward's own rule.
 // (gradient of the virtually up-sampled convolution inputs of the decoder: 314 MB per call at full resolution)
 template <typename T, int VB>
-__global__ void resample_nearest_bwd_vec_kernel(const T *__restrict__ gy, T *__restrict__ gx, int B, int Hs, int Ws, int Ho, int Wo, int C) {
+__global__ void resample_nearest_bwd_vec_kernel(const T *__restrict__ gy, T *__restrict__ gx, int B, int Hs, int Ws, int Ho, int Wo, int C,
+                                                const T *__restrict__ gate, int gate_act) {
     constexpr int VEC = VB / (int)sizeof(T);
     typedef typename RsRaw<VB>::type Raw;
     const int CV = C / VEC;
@@ -125,6 +126,12 @@ __global__ void resample_nearest_bwd_vec_kernel(const T *__restrict__ gy, T *__r
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) acc[e] += to_f32(p[e]);
             }
+        }
+        if (gate) {                                      // the source map is an activation output whose backward runs here (conv2d defer)
+            const Raw rg = *(const Raw *)(gate + (size_t)i * VEC);
+            const T *pg = (const T *)&rg;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = gate_grad(acc[e], to_f32(pg[e]), gate_act);
         }
         alignas(16) T out[VEC];
 #pragma unroll
@@ -549,18 +556,20 @@ extern "C" int gwd_resample_forward(const void *x, void *y, int32_t B, int32_t H
 }
 
 extern "C" int gwd_resample_backward(const void *gy, void *gx, int32_t B, int32_t Hs, int32_t Ws, int32_t Ho, int32_t Wo,
-                                     int32_t C, int32_t mode, int32_t dtype, void *stream) {
+                                     int32_t C, int32_t mode, const void *gate, int32_t gate_act, int32_t dtype, void *stream) {
     if (!gy || !gx || B <= 0 || Hs <= 0 || Ws <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || mode < 0 || mode > 1) return -1;
+    if (gate && (gate_act != GWD_ACT_RELU && gate_act != GWD_ACT_ELU)) return -1;
+    if (gate && !(mode == MODE_NEAREST && C % 4 == 0)) return -4;           // the vector kernels of the nearest mode only
     const int64_t total = (int64_t)B * Hs * Ws * C;
     if (mode == MODE_NEAREST && dtype == GWD_BF16 && C % 4 == 0) {
         hipStream_t s = (hipStream_t)stream;
-        if (C % 8 == 0) resample_nearest_bwd_vec_kernel<__bf16, 16><<<flat_grid(total / 8), 256, 0, s>>>((const __bf16 *)gy, (__bf16 *)gx, B, Hs, Ws, Ho, Wo, C);
-        else resample_nearest_bwd_vec_kernel<__bf16, 8><<<flat_grid(total / 4), 256, 0, s>>>((const __bf16 *)gy, (__bf16 *)gx, B, Hs, Ws, Ho, Wo, C);
+        if (C % 8 == 0) resample_nearest_bwd_vec_kernel<__bf16, 16><<<flat_grid(total / 8), 256, 0, s>>>((const __bf16 *)gy, (__bf16 *)gx, B, Hs, Ws, Ho, Wo, C, (const __bf16 *)gate, gate_act);
+        else resample_nearest_bwd_vec_kernel<__bf16, 8><<<flat_grid(total / 4), 256, 0, s>>>((const __bf16 *)gy, (__bf16 *)gx, B, Hs, Ws, Ho, Wo, C, (const __bf16 *)gate, gate_act);
         GWD_CHECK_LAUNCH();
         return 0;
     }
     if (mode == MODE_NEAREST && dtype == GWD_F32 && C % 4 == 0) {
-        resample_nearest_bwd_vec_kernel<float, 16><<<flat_grid(total / 4), 256, 0, (hipStream_t)stream>>>((const float *)gy, (float *)gx, B, Hs, Ws, Ho, Wo, C);
+        resample_nearest_bwd_vec_kernel<float, 16><<<flat_grid(total / 4), 256, 0, (hipStream_t)stream>>>((const float *)gy, (float *)gx, B, Hs, Ws, Ho, Wo, C, (const float *)gate, gate_act);
         GWD_CHECK_LAUNCH();
         return 0;
     }

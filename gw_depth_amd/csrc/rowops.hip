@@ -420,7 +420,7 @@ __global__ __launch_bounds__(NWV * 64) void layernorm_bwd_vec_kernel(const T *__
                 const bool ok = okv && (!PAD || (sub + c * LPR) * VEC + e < C);
                 xh[c][e] = ok ? (to_f32(px[e]) - mu) * rs : 0.f;
                 float gg = ok ? to_f32(pg[e]) : 0.f;
-                if (gelu) gg *= gelu_grad_f(xh[c][e] * g[c][e] + b[c][e]);
+                if (gelu & 1) gg *= gelu_grad_f(xh[c][e] * g[c][e] + b[c][e]);
                 ag[c][e] += gg * xh[c][e];
                 ab[c][e] += gg;
                 gw[c][e] = gg * g[c][e];
@@ -443,6 +443,10 @@ __global__ __launch_bounds__(NWV * 64) void layernorm_bwd_vec_kernel(const T *__
             for (int e = 0; e < VEC; ++e) {
                 float o = rs * (gw[c][e] - s1 - xh[c][e] * s2);
                 if (gskip) o += to_f32(pk[e]);
+                if (gelu & 2) {                          // x is the output of an ELU whose backward runs here (GWD_LN_ELU_INPUT): elu'
+                    const float xo = xh[c][e] / rs + mu; // is continuous, so the rounding of the reconstructed x does not matter
+                    o *= xo > 0.f ? 1.0f : xo + 1.0f;
+                }
                 if (PAD && (sub + c * LPR) * VEC + e >= C) o = 0.f;
                 outv[e] = from_f32<T>(o);
             }
@@ -715,6 +719,7 @@ int launch_ln_bwd_vec(const T *gy, const T *x, const float *ga, const float *be,
 
 extern "C" int gwd_layernorm_forward(const void *x, const float *gamma, const float *beta, const void *residual, void *y, float *mean,
                                      float *rstd, int64_t rows, int32_t C, int32_t ld, int32_t gelu, int32_t dtype, void *stream) {
+    gelu &= 1;
     if (!x || !y || !mean || !rstd || rows < 0 || C <= 0 || C > 64 * MAX_PER_LANE) return -1;
     if ((gamma == nullptr) != (beta == nullptr)) return -1;
     if (ld == 0) ld = C;
@@ -768,7 +773,7 @@ extern "C" int gwd_layernorm_backward(const void *gy, const void *x, const float
         else if (dtype == GWD_F32 && C % 2 == 0) rc = launch_ln_bwd_vec<float, 8>((const float *)gy, (const float *)x, gamma, beta, mean, rstd, (float *)gx, dgamma, dbeta, rows, C, gelu, ld, (const float *)gskip, s);
         if (rc == 0) { GWD_CHECK_LAUNCH(); return 0; }
     }
-    if (gskip) return -4;                    // the generic kernel has no skip input: the caller adds it
+    if (gskip || (gelu & 2)) return -4;      // the generic kernel has neither a skip input nor the ELU gate: the caller does both
     int grid = row_grid(rows, 4);
     if (grid > 1024) grid = 1024;
     DISPATCH_T(dtype,

@@ -125,11 +125,18 @@ __global__ __launch_bounds__(256) void thin_dgrad_kernel(const gwd_conv_desc d) 
     const int oh = h0 + ty, ow = w0 + tx;
     if (oh < H && ow < W) {
         __bf16 *gx = (__bf16 *)d.y + (((size_t)b * H + oh) * W + ow) * C;
+        const __bf16 *gte = d.gate ? (const __bf16 *)d.gate + (((size_t)b * H + oh) * W + ow) * C : nullptr;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             bf16x8 o;
+            if (gte) {                                    // backward of the activation that produced this layer's input (desc.gate)
+                const bf16x8 gg = *(const bf16x8 *)(gte + v * 8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[v * 8 + e];
+                for (int e = 0; e < 8; ++e) o[e] = (__bf16)gate_grad(acc[v * 8 + e], (float)gg[e], d.gate_act);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[v * 8 + e];
+            }
             *(bf16x8 *)(gx + v * 8) = o;
         }
     }
@@ -189,7 +196,8 @@ bool thin_common(const gwd_conv_desc *d) {
 int gwd_thin_conv_forward(const gwd_conv_desc *d, hipStream_t s) {
     if (!thin_common(d) || d->mult) return 0;
     const unsigned tiles = (unsigned)(d->B * ((d->Hi + TILE - 1) / TILE) * ((d->Wi + TILE - 1) / TILE));
-    if (d->gather == GWD_GATHER_CONV && d->Cin == C && (d->Cout == 1 || d->Cout == 2) && !d->residual) {
+    if (d->gate && ((uintptr_t)d->gate % 16)) return 0;
+    if (d->gather == GWD_GATHER_CONV && d->Cin == C && (d->Cout == 1 || d->Cout == 2) && !d->residual && !d->gate) {
         if (d->Cout == 1) thin_fwd_kernel<1><<<tiles, 256, 0, s>>>(*d);
         else thin_fwd_kernel<2><<<tiles, 256, 0, s>>>(*d);
         return 1;

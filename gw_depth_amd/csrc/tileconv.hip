@@ -145,6 +145,7 @@ __global__ __launch_bounds__(64 * TH / RPW) void tconv_fwd_kernel(const gwd_conv
             if (oy < Hv && ox < Wv) {
                 __bf16 *dst = y + (((size_t)b * Hv + oy) * Wv + ox) * COUT;
                 const __bf16 *rsd = d.residual ? (const __bf16 *)d.residual + (((size_t)b * Hv + oy) * Wv + ox) * COUT : nullptr;
+                const __bf16 *gte = d.gate ? (const __bf16 *)d.gate + (((size_t)b * Hv + oy) * Wv + ox) * COUT : nullptr;
 #pragma unroll
                 for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
@@ -153,9 +154,17 @@ __global__ __launch_bounds__(64 * TH / RPW) void tconv_fwd_kernel(const gwd_conv
                         union { uint2 u; __bf16 e[4]; } v, rr;
                         rr.u = uint2{0u, 0u};
                         if (rsd) rr.u = *(const uint2 *)(rsd + 32 * nt + 8 * g + 4 * h);         // added before the activation, as the implicit GEMM does
+                        float f[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            v.e[j] = (__bf16)(apply_act(acc[mt][nt][4 * g + j] + sh[nt][4 * g + j] + (float)rr.e[j], d.act) * d.act_scale);
+                        for (int j = 0; j < 4; ++j) f[j] = apply_act(acc[mt][nt][4 * g + j] + sh[nt][4 * g + j] + (float)rr.e[j], d.act) * d.act_scale;
+                        if (gte) {                                             // backward of the producer's activation (desc.gate), last
+                            union { uint2 u; __bf16 e[4]; } gg;
+                            gg.u = *(const uint2 *)(gte + 32 * nt + 8 * g + 4 * h);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) f[j] = gate_grad(f[j], (float)gg.e[j], d.gate_act);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v.e[j] = (__bf16)f[j];
                         *(uint2 *)(dst + 32 * nt + 8 * g + 4 * h) = v.u;
                     }
             }
@@ -387,6 +396,7 @@ int gwd_tile_conv_forward(const gwd_conv_desc *d, hipStream_t s) {
     if (!enabled() || d->dtype != GWD_BF16 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1) return 0;
     if (d->scale || d->z || d->mult || !d->w) return 0;
     if (d->residual && ((uintptr_t)d->residual % 8)) return 0;
+    if (d->gate && ((uintptr_t)d->gate % 8)) return 0;
     if ((long)d->B * d->Ho * d->Wo < 131072 || (long)d->B * d->Ho * d->Wo >= (1L << 31)) return 0;
     if (((uintptr_t)d->x | (uintptr_t)d->w | (uintptr_t)d->y) % 16) return 0;
     const bool up = d->gather == GWD_GATHER_UPSAMPLED, flip = d->gather == GWD_GATHER_TRANSPOSED;

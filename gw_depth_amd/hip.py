@@ -43,10 +43,10 @@ class HipUnavailable(RuntimeError):
 class ConvDesc(ctypes.Structure):
     _fields_ = [("x", ctypes.c_void_p), ("w", ctypes.c_void_p), ("y", ctypes.c_void_p), ("z", ctypes.c_void_p),
                 ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("residual", ctypes.c_void_p),
-                ("zero_page", ctypes.c_void_p), ("mult", ctypes.c_void_p)] + \
+                ("zero_page", ctypes.c_void_p), ("mult", ctypes.c_void_p), ("gate", ctypes.c_void_p)] + \
                [(n, ctypes.c_int32) for n in ("B", "Hi", "Wi", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad",
                                               "gather", "Hv", "Wv", "act")] + \
-               [("act_scale", ctypes.c_float), ("dtype", ctypes.c_int32)]
+               [("act_scale", ctypes.c_float), ("dtype", ctypes.c_int32), ("gate_act", ctypes.c_int32)]
 
 
 class PrepJob(ctypes.Structure):
@@ -187,7 +187,7 @@ class HipLibrary:
         L.gwd_seg_ce_sum.argtypes = [vp, vp, vp, i64, i32, vp]
         L.gwd_seg_ce_backward.argtypes = [vp, vp, vp, f32, vp, i64, i32, vp]
         L.gwd_resample_forward.argtypes = [vp, vp] + [i32] * 9 + [vp]
-        L.gwd_resample_backward.argtypes = [vp, vp] + [i32] * 8 + [vp]
+        L.gwd_resample_backward.argtypes = [vp, vp] + [i32] * 7 + [vp, i32, i32, vp]
         L.gwd_avgpool_forward.argtypes = [vp, vp] + [i32] * 6 + [vp]
         L.gwd_avgpool_backward.argtypes = [vp, vp] + [i32] * 6 + [vp]
         sp = ctypes.POINTER(Strided)
@@ -246,20 +246,22 @@ class HipLibrary:
     # ------------------------------------------------------------------ entry points
     @staticmethod
     def _desc(x, w, y, dims, z=None, scale=None, shift=None, residual=None, stride=1, pad=0,
-              gather=GATHER_CONV, virt=(0, 0), act=ACT_NONE, act_scale=1.0, mult=None):
+              gather=GATHER_CONV, virt=(0, 0), act=ACT_NONE, act_scale=1.0, mult=None, gate=None, gate_act=ACT_NONE):
         B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW = dims
         d = ConvDesc()
         d.x, d.w, d.y, d.z = _ptr(x), _ptr(w), _ptr(y), _ptr(z)
         d.scale, d.shift, d.residual = _ptr(scale), _ptr(shift), _ptr(residual)
         d.zero_page = _zero_page(x.device)
         d.mult = _ptr(mult)
+        d.gate, d.gate_act = _ptr(gate), (gate_act if gate is not None else ACT_NONE)
         d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW = B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW
         d.stride, d.pad, d.gather, d.Hv, d.Wv = stride, pad, gather, virt[0], virt[1]
         d.act, d.act_scale, d.dtype = act, act_scale, dtype_code(x)
         return d
 
     def conv_forward(self, x, w, y, dims, **kw):
-        """dims = (B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW); kw: z scale shift residual stride pad gather virt act act_scale."""
+        """dims = (B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW); kw: z scale shift residual stride pad gather virt act act_scale mult
+        gate gate_act (the epilogue's last step: backward of the activation whose output is `gate`)."""
         d = self._desc(x, w, y, dims, **kw)
         self._check(self.lib.gwd_conv_forward(ctypes.byref(d), self._stream(x, w, y)), "gwd_conv_forward")
 
@@ -320,14 +322,16 @@ class HipLibrary:
                                                    rows, C, ld, int(gelu), dtype_code(x), self._stream(x, y)),
                     "gwd_layernorm_forward")
 
-    def layernorm_backward(self, gy, x, gamma, beta, mean, rstd, gx, dgamma, dbeta, rows, C, gelu, ld=0, gskip=None):
-        """gskip: a second gradient of x, added to gx in the kernel; returns False when it could not be (no vector kernel for the
-        shape: the call has then run WITHOUT it and the caller adds it)."""
+    def layernorm_backward(self, gy, x, gamma, beta, mean, rstd, gx, dgamma, dbeta, rows, C, gelu, ld=0, gskip=None, elu_input=False):
+        """gskip: a second gradient of x, added to gx in the kernel; elu_input: x is an ELU output whose backward is applied to gx
+        as well (GWD_LN_ELU_INPUT).  Returns False when that could not be done (no vector kernel for the shape: the call has then
+        run WITHOUT both and the caller does them)."""
+        flags = int(bool(gelu)) | (2 if elu_input else 0)
         rc = self.lib.gwd_layernorm_backward(_ptr(gy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(gx), _ptr(dgamma),
-                                             _ptr(dbeta), rows, C, ld, int(gelu), _ptr(gskip), dtype_code(x), self._stream(gy, x, gx))
-        if rc == -4 and gskip is not None:
+                                             _ptr(dbeta), rows, C, ld, flags, _ptr(gskip), dtype_code(x), self._stream(gy, x, gx))
+        if rc == -4 and (gskip is not None or elu_input):
             self._check(self.lib.gwd_layernorm_backward(_ptr(gy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(gx), _ptr(dgamma),
-                                                        _ptr(dbeta), rows, C, ld, int(gelu), None, dtype_code(x), self._stream(gy, x, gx)),
+                                                        _ptr(dbeta), rows, C, ld, int(bool(gelu)), None, dtype_code(x), self._stream(gy, x, gx)),
                         "gwd_layernorm_backward")
             return False
         self._check(rc, "gwd_layernorm_backward")
@@ -497,9 +501,17 @@ class HipLibrary:
         self._check(self.lib.gwd_resample_forward(_ptr(x), _ptr_pitched(y), B, Hs, Ws, Ho, Wo, C, mode, self._pixel_pitch(y, Ho, Wo, C), dtype_code(x),
                                                   self._stream(x, y)), "gwd_resample_forward")
 
-    def resample_backward(self, gy, gx, B, Hs, Ws, Ho, Wo, C, mode):
-        self._check(self.lib.gwd_resample_backward(_ptr(gy), _ptr(gx), B, Hs, Ws, Ho, Wo, C, mode, dtype_code(gy),
-                                                   self._stream(gy, gx)), "gwd_resample_backward")
+    def resample_backward(self, gy, gx, B, Hs, Ws, Ho, Wo, C, mode, gate=None, gate_act=ACT_NONE):
+        """gate / gate_act: gx *= act'(.) of the activation whose output is `gate` (B,Hs,Ws,C); False when the shape cannot (the call
+        has then run WITHOUT the gate)."""
+        rc = self.lib.gwd_resample_backward(_ptr(gy), _ptr(gx), B, Hs, Ws, Ho, Wo, C, mode, _ptr(gate), gate_act if gate is not None else 0,
+                                            dtype_code(gy), self._stream(gy, gx))
+        if rc == -4 and gate is not None:
+            self._check(self.lib.gwd_resample_backward(_ptr(gy), _ptr(gx), B, Hs, Ws, Ho, Wo, C, mode, None, 0, dtype_code(gy),
+                                                       self._stream(gy, gx)), "gwd_resample_backward")
+            return False
+        self._check(rc, "gwd_resample_backward")
+        return True
 
     def resample_backward_sep(self, gy, tmp, gx, B, Hs, Ws, Ho, Wo, C, mode):
         """Separable backward through the fp32 scratch `tmp` (B,Ho,Ws,C); False when C is not vector-sized."""

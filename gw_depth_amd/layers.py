@@ -52,9 +52,9 @@ class LayerNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(c))
         self.bias = nn.Parameter(torch.zeros(c))
 
-    def forward(self, x, gelu=False, residual=None, fan=False):
+    def forward(self, x, gelu=False, residual=None, fan=False, in_gate=0):
         """fan: (y, x') with x' = x for the input's second consumer (the skip of a pre-norm block), see ops.layer_norm."""
-        return ops.layer_norm(x, self.weight, self.bias, gelu, residual=residual, fanout=fan)
+        return ops.layer_norm(x, self.weight, self.bias, gelu, residual=residual, fanout=fan, in_gate=in_gate)
 
 
 class FrozenBN(nn.Module):

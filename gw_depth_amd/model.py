@@ -94,17 +94,23 @@ class Bottleneck(nn.Module):
         self.stride = stride
         self.downsample = Seq(_0=Conv(inplanes, planes * 4, 1), _1=FrozenBN(planes * 4)) if down else None
 
-    def forward(self, x):
+    def forward(self, x, gated_in=False, defer_out=False):
+        """gated_in: x is the previous block's output and that block left its ReLU backward to us (defer_out there); inside the block
+        conv1 -> conv2 -> conv3 hand theirs on the same way (ops.conv2d: defer / in_gate), so a block's three activation-backward
+        passes run in the data-gradient epilogues of the layers behind them."""
+        g = ACT_RELU if ops.act_gate_enabled() else ACT_NONE
+        d = g != ACT_NONE
         s, b = self.bn1.folded()
-        out, x = ops.conv2d(x, self.conv1.weight, row_scale=s, shift=b, act=ACT_RELU, fanout=True)     # x again, for the skip path
+        out, x = ops.conv2d(x, self.conv1.weight, row_scale=s, shift=b, act=ACT_RELU, fanout=True,     # x again, for the skip path
+                            in_gate=ACT_RELU if gated_in else ACT_NONE, defer=d)
         s, b = self.bn2.folded()
-        out = ops.conv2d(out, self.conv2.weight, stride=self.stride, pad=1, row_scale=s, shift=b, act=ACT_RELU)
+        out = ops.conv2d(out, self.conv2.weight, stride=self.stride, pad=1, row_scale=s, shift=b, act=ACT_RELU, in_gate=g, defer=d)
         idt = x
         if self.downsample is not None:
             s, b = self.downsample[1].folded()
             idt = ops.conv2d(x, self.downsample[0].weight, stride=self.stride, row_scale=s, shift=b)
         s, b = self.bn3.folded()
-        return ops.conv2d(out, self.conv3.weight, row_scale=s, shift=b, residual=idt, act=ACT_RELU)
+        return ops.conv2d(out, self.conv3.weight, row_scale=s, shift=b, residual=idt, act=ACT_RELU, in_gate=g, defer=defer_out)
 
 
 class ResNetBody(nn.Module):
@@ -132,8 +138,13 @@ class ResNetBody(nn.Module):
             x = ops.conv2d(x, self.conv1.weight, stride=2, pad=3, row_scale=s, shift=b, act=ACT_RELU)
             x = to_pixel_major(F.max_pool2d(to_nchw(x), 3, 2, 1))
         feats = []
+        # a block whose output feeds only the next block of its layer defers its last ReLU backward to that block's first conv
+        # (which, with the fan-out, is the single consumer of the map); the last block's output also leaves as a feature level
+        chain = ops.act_gate_enabled() and os.environ.get("GWD_FANOUT", "1") != "0"
         for li in range(1, 5):
-            x = getattr(self, f"layer{li}")(x)
+            blocks = getattr(self, f"layer{li}")
+            for bi, blk in enumerate(blocks):
+                x = blk(x, gated_in=chain and bi > 0, defer_out=chain and bi + 1 < len(blocks))
             feats.append(x)
         return feats
 
@@ -832,9 +843,9 @@ class UpConv(nn.Module):
         super().__init__()
         self.conv = Conv(cin, cout, 3)
 
-    def forward(self, x, size):
+    def forward(self, x, size, defer=False, in_gate=ACT_NONE):
         """nearest upsample fused into the conv's gather, ELU in its epilogue (dense_upsample.py:82-90)."""
-        return ops.conv2d(x, self.conv.weight, pad=1, act=ACT_ELU, upsample_to=size)
+        return ops.conv2d(x, self.conv.weight, pad=1, act=ACT_ELU, upsample_to=size, defer=defer, in_gate=in_gate)
 
 
 class DensePrediction(nn.Module):
@@ -883,11 +894,14 @@ class DensePrediction(nn.Module):
         B, H, W, _ = fuse_in.shape
         f = fuse(cast("decoder_fuse", fuse_in))
         f = cast("decoder_up1", f)
-        u1 = getattr(self, f"norm_{tag}")(getattr(self, f"upconv1_{tag}")(f, (2 * H, 2 * W)))
-        c1 = ops.conv2d(u1, getattr(self, f"conv1_{tag}")[0].weight, pad=1, act=ACT_ELU)
+        # the ELU backward of all four convolutions runs inside the backward of the layer behind each: the LayerNorm (upconv1), the
+        # footprint sum of the up-sampling conv (conv1), the data-gradient epilogue of conv2 (upconv2) and of the depth / seg head (conv2)
+        g = ACT_ELU if ops.act_gate_enabled() else ACT_NONE
+        u1 = getattr(self, f"norm_{tag}")(getattr(self, f"upconv1_{tag}")(f, (2 * H, 2 * W), defer=g != ACT_NONE), in_gate=g)
+        c1 = ops.conv2d(u1, getattr(self, f"conv1_{tag}")[0].weight, pad=1, act=ACT_ELU, defer=g != ACT_NONE)
         c1 = cast("decoder_up2", c1)
-        u2 = getattr(self, f"upconv2_{tag}")(c1, size)
-        return cast("decoder_head", ops.conv2d(u2, getattr(self, f"conv2_{tag}")[0].weight, pad=1, act=ACT_ELU))
+        u2 = getattr(self, f"upconv2_{tag}")(c1, size, defer=g != ACT_NONE, in_gate=g)
+        return cast("decoder_head", ops.conv2d(u2, getattr(self, f"conv2_{tag}")[0].weight, pad=1, act=ACT_ELU, in_gate=g, defer=g != ACT_NONE))
 
     def forward(self, feat, depth3, dtok, stok, size, cast=None):
         cast = cast or (lambda stage, t: t)
@@ -898,9 +912,10 @@ class DensePrediction(nn.Module):
         if pad and feat.is_cuda:
             parts.append(self.zero_channels(feat, pad))
         d = self.branch(torch.cat(parts, dim=-1), "depth", self.fuse_padded, size, cast)
-        depth = ops.conv2d(d, self.get_depth[0].weight, pad=1, act=ACT_SIGMOID, act_scale=float(self.max_depth))
+        g = ACT_ELU if ops.act_gate_enabled() else ACT_NONE
+        depth = ops.conv2d(d, self.get_depth[0].weight, pad=1, act=ACT_SIGMOID, act_scale=float(self.max_depth), in_gate=g)
         s = self.branch(torch.cat([feat, stok], dim=-1), "seg", self.seg_token_fuse, size, cast)
-        seg = ops.conv2d(s, self.get_seg.weight, pad=1)
+        seg = ops.conv2d(s, self.get_seg.weight, pad=1, in_gate=g)
         return depth.float().view(B, 1, size[0], size[1]), seg.permute(0, 3, 1, 2)
 
 

@@ -424,9 +424,18 @@ class _ConvFn(torch.autograd.Function):
     dropout multiplier) y = act_scale * act(conv + shift) * mult + residual: the skip is added after the dropout."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual, row_scale, shift_const, stride, pad, act, act_scale, virt, shadow, sinks, mult=None, fanout=False):
+    def forward(ctx, x, w, bias, residual, row_scale, shift_const, stride, pad, act, act_scale, virt, shadow, sinks, mult=None, fanout=False,
+                in_gate=ACT_NONE, defer=False):
         lib = _lib()
         ctx.fan = bool(fanout)
+        # in_gate / defer: the activation backward of a ReLU / ELU layer moves into the data-gradient epilogue of its ONLY consumer
+        # (gwd_conv_desc.gate = the consumer's saved input): the producer (defer) passes the incoming gradient on unchanged, the
+        # consumer (in_gate = the producer's activation) returns the gradient w.r.t. the producer's PRE-activation value
+        ctx.in_gate, ctx.defer = int(in_gate), bool(defer)
+        if defer and (act not in (ACT_RELU, ACT_ELU) or act_scale != 1.0 or mult is not None):
+            raise ValueError("conv2d: defer needs ReLU / ELU with act_scale 1 and no dropout multiplier")
+        if in_gate not in (ACT_NONE, ACT_RELU, ACT_ELU):
+            raise ValueError("conv2d: in_gate is ReLU or ELU")
         B, Hi, Wi, Cin = x.shape
         Cout, KH, KW, Cw = w.shape
         if Cw != Cin:
@@ -487,6 +496,8 @@ class _ConvFn(torch.autograd.Function):
                     b_sink[1]()
             else:
                 dv = None
+        if ctx.defer:
+            dv = gy                                    # the consumer's data-gradient epilogue has applied act'(.) already
         if dv is None:
             if mult is not None:
                 gy = gy * mult
@@ -504,17 +515,25 @@ class _ConvFn(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             wt = _weight_transposed(w, row_scale, x.dtype)
+            gate = dict(gate=x, gate_act=ctx.in_gate) if ctx.in_gate != ACT_NONE else {}
             if gather == GATHER_UPSAMPLED:
                 gxv = torch.empty((B, vv[0], vv[1], Cin), dtype=x.dtype, device=x.device)
                 lib.conv_forward(dv, wt, gxv, (B, Ho, Wo, Cout, vv[0], vv[1], Cin, KH, KW), stride=1, pad=pad,
                                  gather=GATHER_TRANSPOSED)
-                gx = _nearest_upsample_backward(gxv, Hi, Wi)
-                if g_in is not None:
-                    gx = gx + g_in
+                if gate and g_in is None:              # the gate rides on the footprint sum
+                    gx = _nearest_upsample_backward(gxv, Hi, Wi, gate=x, gate_act=ctx.in_gate)
+                else:
+                    gx = _nearest_upsample_backward(gxv, Hi, Wi)
+                    if g_in is not None:
+                        gx = gx + g_in
+                    if gate:                           # behind the skip gradient: a pass of its own
+                        gated = torch.empty_like(gx)
+                        lib.act_backward(gx, x, gated, None, B * Hi * Wi, Cin, ctx.in_gate, 1.0)
+                        gx = gated
             else:
                 gx = torch.empty_like(x)
                 done = False
-                if KH == 1 and KW == 1 and stride > 1 and pad == 0 and os.environ.get("GWD_STRIDE_PLACE", "1") != "0":
+                if KH == 1 and KW == 1 and stride > 1 and pad == 0 and not gate and os.environ.get("GWD_STRIDE_PLACE", "1") != "0":
                     # 1x1 / stride s: only the pixels (s i, s j) get a gradient - a plain GEMM over the OUTPUT pixels, then placement
                     # (+ the skip gradient) in one pass; the transposed gather spent 3/4 of its work on zero-page products
                     q = torch.empty((B, Ho, Wo, Cin), dtype=x.dtype, device=x.device)
@@ -522,7 +541,7 @@ class _ConvFn(torch.autograd.Function):
                     done = lib.stride_place(q, g_in, gx, stride)
                 if not done:
                     lib.conv_forward(dv, wt, gx, (B, Ho, Wo, Cout, Hi, Wi, Cin, KH, KW), stride=stride, pad=pad,
-                                     gather=GATHER_TRANSPOSED, residual=g_in)
+                                     gather=GATHER_TRANSPOSED, residual=g_in, **gate)
         elif g_in is not None:
             gx = g_in
         if ctx.needs_input_grad[1]:
@@ -540,15 +559,21 @@ class _ConvFn(torch.autograd.Function):
                 gb = torch.zeros(Cout, dtype=torch.float32, device=gy.device)
                 lib.colsum(dv, gb, rows, Cout)
         gres = (g_skip if mult is not None else dv) if (has_res and ctx.needs_input_grad[3]) else None
-        return gx, gw, gb, gres, None, None, None, None, None, None, None, None, None, None, None
+        return gx, gw, gb, gres, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
-def _nearest_upsample_backward(gv, Hi, Wi):
+def _nearest_upsample_backward(gv, Hi, Wi, gate=None, gate_act=ACT_NONE):
     """Sum the gradient of a nearest-upsampled view back onto its source pixels: one gather pass of gwd_resample_backward
-    (each source pixel sums its own footprint; was a strided aten::sum at 1.5 TB/s)."""
+    (each source pixel sums its own footprint; was a strided aten::sum at 1.5 TB/s).  gate: the source map when it is the output of
+    an activation whose backward is applied to the sums in the same pass (conv2d defer / in_gate)."""
     B, Hv, Wv, C = gv.shape
     gx = torch.empty((B, Hi, Wi, C), dtype=gv.dtype, device=gv.device)
-    _lib().resample_backward(gv.contiguous(), gx, B, Hi, Wi, Hv, Wv, C, hip.RESAMPLE_NEAREST)
+    lib = _lib()
+    done = lib.resample_backward(gv.contiguous(), gx, B, Hi, Wi, Hv, Wv, C, hip.RESAMPLE_NEAREST, gate=gate, gate_act=gate_act)
+    if gate is not None and done is False:
+        gated = torch.empty_like(gx)
+        lib.act_backward(gx, gate, gated, None, B * Hi * Wi, C, gate_act, 1.0)
+        gx = gated
     return gx
 
 
@@ -561,17 +586,25 @@ def _sink(p, shape=None):
 
 
 def conv2d(x, w, bias=None, *, stride=1, pad=0, act=ACT_NONE, act_scale=1.0, residual=None, row_scale=None,
-           shift=None, upsample_to=None, mult=None, fanout=False):
+           shift=None, upsample_to=None, mult=None, fanout=False, in_gate=ACT_NONE, defer=False):
     """x (B,H,W,Cin); w (Cout,KH,KW,Cin) fp32 master; bias fp32 parameter or None.
     row_scale / shift: constant per-Cout tensors of a folded FrozenBatchNorm.
     upsample_to=(Hv,Wv): convolve a nearest-upsampled view of x without materialising it.
-    fanout: return (y, x'), x' = x for the OTHER consumer of the input (use x' instead of x there): see _ConvFn.forward."""
+    fanout: return (y, x'), x' = x for the OTHER consumer of the input (use x' instead of x there): see _ConvFn.forward.
+    defer / in_gate: a ReLU / ELU layer whose output has exactly ONE consumer (this function again, or the fan-out chain that starts
+    with it) is called with defer=True and that consumer with in_gate=<the producer's activation>: the activation's backward then
+    runs in the consumer's data-gradient epilogue instead of as a pass of its own (act_gate_enabled(): both or neither)."""
     sinks = (_sink(w), _sink(bias) if bias is not None else None)
     if fanout and os.environ.get("GWD_FANOUT", "1") == "0":         # A/B: autograd's own accumulation of the two gradients
         return _ConvFn.apply(x, w, bias, residual, row_scale, shift, stride, pad, act, float(act_scale), upsample_to,
-                             getattr(w, "_gwd_bf16", None), sinks if (sinks[0] or sinks[1]) else None, mult, False), x
+                             getattr(w, "_gwd_bf16", None), sinks if (sinks[0] or sinks[1]) else None, mult, False, in_gate, defer), x
     return _ConvFn.apply(x, w, bias, residual, row_scale, shift, stride, pad, act, float(act_scale), upsample_to,
-                         getattr(w, "_gwd_bf16", None), sinks if (sinks[0] or sinks[1]) else None, mult, bool(fanout))
+                         getattr(w, "_gwd_bf16", None), sinks if (sinks[0] or sinks[1]) else None, mult, bool(fanout), in_gate, defer)
+
+
+def act_gate_enabled():
+    """A/B switch (GWD_ACT_GATE=0: every activation layer runs its own backward pass)."""
+    return os.environ.get("GWD_ACT_GATE", "1") != "0"
 
 
 def linear(x, w, bias=None, act=ACT_NONE, rows=None, residual=None, mult=None, fanout=False):
@@ -608,10 +641,13 @@ def linear(x, w, bias=None, act=ACT_NONE, rows=None, residual=None, mult=None, f
 
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, gelu, sinks, residual, fanout=False):
+    def forward(ctx, x, gamma, beta, gelu, sinks, residual, fanout=False, in_gate=ACT_NONE):
         lib = _lib()
         ctx.sinks = sinks
         ctx.fan = bool(fanout)
+        if in_gate not in (ACT_NONE, ACT_ELU):
+            raise ValueError("layer_norm: in_gate is ELU (the gate is rebuilt from the normalised value: continuous derivatives only)")
+        ctx.in_gate = int(in_gate)                  # x is the output of a conv2d(..., act=ELU, defer=True): its backward runs in ours
         ctx.has_res = residual is not None
         x = x.contiguous()
         ld = x.shape[-1]
@@ -647,19 +683,25 @@ class _LayerNormFn(torch.autograd.Function):
         elif g is not None:
             dg = torch.zeros(C, dtype=torch.float32, device=x.device)
             db = torch.zeros(C, dtype=torch.float32, device=x.device)
-        fused = lib.layernorm_backward(gy, x, g, b, mean, rstd, gx, dg, db, rows, C, ctx.gelu, ld=0 if ld == C else ld, gskip=g_in)
-        if g_in is not None and fused is False:            # no vector kernel for this width: the skip gradient is added here
-            gx = gx + g_in
+        fused = lib.layernorm_backward(gy, x, g, b, mean, rstd, gx, dg, db, rows, C, ctx.gelu, ld=0 if ld == C else ld, gskip=g_in,
+                                       elu_input=ctx.in_gate == ACT_ELU)
+        if fused is False:                                 # no vector kernel for this width: the skip gradient / the gate as passes
+            if g_in is not None:
+                gx = gx + g_in
+            if ctx.in_gate != ACT_NONE:
+                gated = torch.empty_like(gx)
+                lib.act_backward(gx, x, gated, None, rows, ld, ctx.in_gate, 1.0)
+                gx = gated
         gres = gy if ctx.has_res else None                # y = LN(x) + residual: the skip gets the incoming gradient as is
         if direct:
             for h in (h1, h2):
                 if h is not None:
                     h()
-            return gx, None, None, None, None, gres, None
-        return gx, dg, db, None, None, gres, None
+            return gx, None, None, None, None, gres, None, None
+        return gx, dg, db, None, None, gres, None, None
 
 
-def layer_norm(x, gamma, beta, gelu=False, residual=None, fanout=False):
+def layer_norm(x, gamma, beta, gelu=False, residual=None, fanout=False, in_gate=ACT_NONE):
     """LayerNorm over the last dim (eps 1e-5) with optional fused exact GELU; residual (same shape) is added afterwards.
     fanout: return (y, x') with x' = x for the OTHER consumer of the input (the skip of a pre-norm block): x's two gradients then
     meet inside the LayerNorm backward kernel instead of an accumulation pass."""
@@ -668,8 +710,8 @@ def layer_norm(x, gamma, beta, gelu=False, residual=None, fanout=False):
         sg, sb = _sink(gamma), _sink(beta)
         sinks = (sg, sb) if (sg is not None and sb is not None) else None
     if fanout and os.environ.get("GWD_LN_FANOUT", "1") == "0":
-        return _LayerNormFn.apply(x, gamma, beta, bool(gelu), sinks, residual, False), x
-    return _LayerNormFn.apply(x, gamma, beta, bool(gelu), sinks, residual, bool(fanout))
+        return _LayerNormFn.apply(x, gamma, beta, bool(gelu), sinks, residual, False, in_gate), x
+    return _LayerNormFn.apply(x, gamma, beta, bool(gelu), sinks, residual, bool(fanout), in_gate)
 
 
 class _SoftmaxFn(torch.autograd.Function):

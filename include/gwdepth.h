@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GWD_VERSION 6
+#define GWD_VERSION 7
 
 enum { GWD_F32 = 0, GWD_BF16 = 1 };
 enum { GWD_ACT_NONE = 0, GWD_ACT_RELU = 1, GWD_ACT_GELU = 2, GWD_ACT_ELU = 3, GWD_ACT_SIGMOID = 4 };
@@ -48,12 +48,18 @@ typedef struct {
                           /* after the multiply instead of before the activation:                    */
                           /*   y = act_scale * act(conv + shift) * mult + residual                   */
                           /* (x + dropout(sublayer(x)) of src/models/transformer.py:149-162,212-233)  */
+    const void *gate;     /* optional [B][Ho][Wo][Cout], with gate_act: the LAST step of the epilogue multiplies the   */
+                          /* result by act'(.) of an activation whose OUTPUT is `gate` (ReLU: gate > 0, ELU with       */
+                          /* alpha 1: gate > 0 ? 1 : gate + 1).  For a data-gradient launch this is the backward of    */
+                          /* the activation that produced the layer's input (gate = that input, which the layer keeps  */
+                          /* for its weight gradient anyway): the producer then skips its own activation-backward pass */
     int32_t B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
     int32_t gather;       /* GWD_GATHER_*                                                       */
     int32_t Hv, Wv;       /* virtual input size for GWD_GATHER_UPSAMPLED                        */
     int32_t act;          /* GWD_ACT_*                                                          */
     float act_scale;      /* y = act_scale * act(v)  (max_depth * sigmoid)                      */
-    int32_t dtype;        /* GWD_F32 / GWD_BF16 for x, w, y, z, residual                        */
+    int32_t dtype;        /* GWD_F32 / GWD_BF16 for x, w, y, z, residual, mult, gate            */
+    int32_t gate_act;     /* GWD_ACT_RELU or GWD_ACT_ELU when gate != NULL, else ignored         */
 } gwd_conv_desc;
 
 int gwd_version(void);
@@ -139,6 +145,10 @@ int gwd_layernorm_forward(const void *x, const float *gamma, const float *beta, 
                           float *rstd, int64_t rows, int32_t C, int32_t ld, int32_t gelu, int32_t dtype, void *stream);
 /* gskip (may be NULL): [rows][ld], a second gradient of x added to gx (x also feeds a skip connection); returns -4 when the shape
  * has no vector kernel (the caller then adds it).                                                                   */
+/* gelu, backward: bit 0 = GELU behind the norm (as forward); bit 1 (GWD_LN_ELU_INPUT) = x is the output of an ELU (alpha 1) whose
+ * own backward pass is left to this call: gx = (gx + gskip) * elu'(x) (upconv1 -> norm of src/models/dense_upsample.py:163-166);
+ * -4 when the shape has no vector kernel.                                                                             */
+#define GWD_LN_ELU_INPUT 2
 int gwd_layernorm_backward(const void *gy, const void *x, const float *gamma, const float *beta,
                            const float *mean, const float *rstd, void *gx, float *dgamma, float *dbeta,
                            int64_t rows, int32_t C, int32_t ld, int32_t gelu, const void *gskip, int32_t dtype, void *stream);
@@ -365,8 +375,10 @@ enum { GWD_RESAMPLE_BILINEAR_AC = 0, GWD_RESAMPLE_NEAREST = 1 };
  * points_sample.py:114-122 without a concat pass); vector-sized C and ldy only, else -4.                          */
 int gwd_resample_forward(const void *x, void *y, int32_t B, int32_t Hs, int32_t Ws, int32_t Ho, int32_t Wo,
                          int32_t C, int32_t mode, int32_t ldy, int32_t dtype, void *stream);
+/* gate (may be NULL) [B][Hs][Ws][C] + gate_act (GWD_ACT_RELU / GWD_ACT_ELU): gx is multiplied by act'(.) of the activation whose
+ * OUTPUT is `gate` (the source map of an up-sampling convolution, see gwd_conv_desc.gate); nearest mode with C a multiple of 4, else -4. */
 int gwd_resample_backward(const void *gy, void *gx, int32_t B, int32_t Hs, int32_t Ws, int32_t Ho, int32_t Wo,
-                          int32_t C, int32_t mode, int32_t dtype, void *stream);
+                          int32_t C, int32_t mode, const void *gate, int32_t gate_act, int32_t dtype, void *stream);
 /* gwd_resample_backward as two separable passes (x, then y) through a caller-provided fp32 scratch tmp[B][Ho][Ws][C]:
  * the same sums in the same order, but 2r+2 taps per thread instead of (2r+2)^2 (13x faster at the 16x pyramid
  * branches).  Returns -4 when C is not a multiple of 16 bytes (use gwd_resample_backward).                       */

@@ -92,7 +92,7 @@ class FakeDevice:
         return out.permute(0, 2, 3, 1)
 
     def conv_forward(self, x, w, y, dims, z=None, scale=None, shift=None, residual=None, stride=1, pad=0,
-                     gather=hip.GATHER_CONV, virt=(0, 0), act=hip.ACT_NONE, act_scale=1.0, mult=None):
+                     gather=hip.GATHER_CONV, virt=(0, 0), act=hip.ACT_NONE, act_scale=1.0, mult=None, gate=None, gate_act=hip.ACT_NONE):
         v = self._conv_core(x, w, dims, stride, pad, gather, virt)
         if scale is not None:
             v = v * scale
@@ -107,6 +107,9 @@ class FakeDevice:
             out = out * mult.reshape(v.shape).float()
             if residual is not None:
                 out = out + residual.reshape(v.shape).float()
+        if gate is not None:                          # gwd_conv_desc.gate: act'(.) of the activation whose output is `gate`, last
+            r = gate.reshape(v.shape).float()
+            out = out * ((r > 0).float() if gate_act == hip.ACT_RELU else torch.where(r > 0, torch.ones_like(r), r + 1))
         y.copy_(out.reshape(y.shape))
 
     def conv_wgrad(self, x, gy, dw, dims, stride=1, pad=0, gather=hip.GATHER_CONV, virt=(0, 0), scale=None, **_):
@@ -425,10 +428,14 @@ class FakeDevice:
         for src, dst, N, taps, G, Cg, Cgp in jobs:
             dst.view(N, taps, G, Cg).add_(src.view(-1, taps, G, Cgp)[:N, :, :, :Cg])
 
-    def layernorm_backward(self, gy, x, gamma, beta, mean, rstd, gx, dgamma, dbeta, rows, C, gelu, ld=0, gskip=None):
-        if gskip is not None:
+    def layernorm_backward(self, gy, x, gamma, beta, mean, rstd, gx, dgamma, dbeta, rows, C, gelu, ld=0, gskip=None, elu_input=False):
+        if gskip is not None or elu_input:
             self.layernorm_backward(gy, x, gamma, beta, mean, rstd, gx, dgamma, dbeta, rows, C, gelu, ld)
-            gx.add_(gskip.reshape(gx.shape).to(gx.dtype))
+            if gskip is not None:
+                gx.add_(gskip.reshape(gx.shape).to(gx.dtype))
+            if elu_input:
+                r = x.reshape(gx.shape).float()
+                gx.mul_(torch.where(r > 0, torch.ones_like(r), r + 1).to(gx.dtype))
             return True
         if ld and ld != C:
             gxv = gx.view(rows, ld)
@@ -515,13 +522,18 @@ class FakeDevice:
             F.interpolate(xn, size=(Ho, Wo), mode="bilinear", align_corners=True)
         y.copy_(o.permute(0, 2, 3, 1).reshape(y.shape))
 
-    def resample_backward(self, gy, gx, B, Hs, Ws, Ho, Wo, C, mode):
+    def resample_backward(self, gy, gx, B, Hs, Ws, Ho, Wo, C, mode, gate=None, gate_act=hip.ACT_NONE):
         x0 = torch.zeros(B, C, Hs, Ws, requires_grad=True)
         with torch.enable_grad():
             o = F.interpolate(x0, size=(Ho, Wo), mode="nearest") if mode == hip.RESAMPLE_NEAREST else \
                 F.interpolate(x0, size=(Ho, Wo), mode="bilinear", align_corners=True)
             (g,) = torch.autograd.grad(o, x0, gy.reshape(B, Ho, Wo, C).permute(0, 3, 1, 2).float())
-        gx.copy_(g.permute(0, 2, 3, 1).reshape(gx.shape))
+        g = g.permute(0, 2, 3, 1).reshape(gx.shape)
+        if gate is not None:
+            r = gate.reshape(gx.shape).float()
+            g = g * ((r > 0).float() if gate_act == hip.ACT_RELU else torch.where(r > 0, torch.ones_like(r), r + 1))
+        gx.copy_(g)
+        return True
 
     def stride_place(self, src, residual, dst, stride):
         out = torch.zeros(dst.shape) if residual is None else residual.float().clone()

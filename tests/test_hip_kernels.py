@@ -1014,3 +1014,155 @@ def test_fused_set_criterion_equals_the_torch_formulation(dev, sizes, monkeypatc
     for k in a[0]:
         assert abs(a[0][k] - b[0][k]) <= 1e-5 * max(1.0, abs(b[0][k])), (k, a[0][k], b[0][k])
     assert rel(a[1], b[1]) < 1e-5 and rel(a[2], b[2]) < 1e-5
+
+
+GATE_CASES = [
+    # B, H, W, Cin(gy channels), Cout(gx channels), K, stride of the forward layer, residual
+    (2, 12, 16, 64, 256, 1, 1, True),            # 1x1 data gradient + skip gradient (Bottleneck conv1 with the fan-out)
+    (2, 12, 16, 128, 128, 3, 1, False),          # 3x3 transposed gather
+    (2, 12, 16, 128, 128, 3, 2, False),          # 3x3 stride 2 (Bottleneck conv2 of a layer's first block)
+    (8, 120, 160, 160, 160, 3, 1, False),        # the 256 x 160 tiles
+    (2, 12, 16, 30, 60, 3, 1, False),            # odd widths: register-staged kernel, scalar epilogue
+    (2, 256, 320, 32, 64, 3, 1, True),           # halo-tile kernel (>= 131 072 pixels, 64 <- 32 channels)
+    (2, 64, 80, 1, 32, 3, 1, False),             # thin data gradient (depth head)
+    (3, 37, 45, 2, 32, 3, 1, False),             # thin data gradient (seg head), ragged tiles
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("gate_act", [hip.ACT_RELU, hip.ACT_ELU])
+@pytest.mark.parametrize("case", GATE_CASES, ids=["%dx%dx%dx%d_%d_k%ds%d%s" % (c[0], c[1], c[2], c[3], c[4], c[5], c[6], "r" * c[7]) for c in GATE_CASES])
+def test_conv_data_gradient_with_activation_gate(dev, case, gate_act, dtype):
+    """gwd_conv_desc.gate: the epilogue's last step multiplies by act'(.) of the activation whose output is `gate` - a data-gradient
+    launch then returns the gradient w.r.t. the producer's pre-activation value (every kernel family that can run a data gradient)."""
+    B, H, W, Cg, Cx, K, stride, with_res = case
+    if dtype == torch.float32 and B * H * W > 40000:
+        pytest.skip("big maps in bf16 only")
+    pad = K // 2
+    Ho, Wo = conv_out(H, K, stride, pad), conv_out(W, K, stride, pad)
+    gy = rnd(B, Ho, Wo, Cg, dtype=dtype, seed=1)
+    wt = rnd(Cx, K, K, Cg, dtype=dtype, seed=2, scale=0.1)          # the transposed (data-gradient) weight layout
+    xin = rnd(B, H, W, Cx, dtype=dtype, seed=3)                     # the layer's input = output of the producer's activation
+    if gate_act == hip.ACT_RELU:
+        xin = xin.clamp_min(0)
+    else:
+        xin = torch.where(xin > 0, xin, torch.expm1(xin.float()).to(dtype))
+    res = rnd(B, H, W, Cx, dtype=dtype, seed=4) if with_res else None
+    dims = (B, Ho, Wo, Cg, H, W, Cx, K, K)
+    want = torch.empty(B, H, W, Cx)
+    FakeDevice().conv_forward(gy, wt, want, dims, stride=stride, pad=pad, gather=hip.GATHER_TRANSPOSED, residual=res, gate=xin, gate_act=gate_act)
+    got = torch.empty(B, H, W, Cx, dtype=dtype, device="cuda")
+    dev.conv_forward(gy.cuda(), wt.cuda(), got, dims, stride=stride, pad=pad, gather=hip.GATHER_TRANSPOSED,
+                     residual=None if res is None else res.cuda(), gate=xin.cuda(), gate_act=gate_act)
+    torch.cuda.synchronize()
+    assert rel(got, want) < TOL[dtype]
+    if gate_act == hip.ACT_RELU:                                    # exactly zero wherever the producer's output was zero
+        assert torch.equal(got.cpu() == 0, (xin <= 0) | (got.cpu() == 0)) and bool((got.cpu()[xin <= 0] == 0).all())
+
+
+def test_conv_gate_rejects_what_it_cannot_do(dev):
+    x, w, y = (torch.zeros(s, device="cuda", dtype=torch.bfloat16) for s in ((1, 8, 8, 32), (32, 1, 1, 32), (1, 8, 8, 32)))
+    dims = (1, 8, 8, 32, 8, 8, 32, 1, 1)
+    with pytest.raises(RuntimeError):
+        dev.conv_forward(x, w, y, dims, gate=x, gate_act=hip.ACT_GELU)
+    with pytest.raises(RuntimeError):
+        dev.conv_forward(x, w, y, dims, gate=x, gate_act=hip.ACT_RELU, mult=x)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", [hip.ACT_RELU, hip.ACT_ELU])
+def test_deferred_activation_backward_equals_the_separate_pass(dev, act, dtype):
+    """ops.conv2d(defer=True) -> ops.conv2d(in_gate=act) (+ the fan-out skip, + an upsampled consumer) against the same chain with
+    every layer running its own activation backward: same outputs, same gradients for the input and all weights."""
+    from gw_depth_amd import ops
+    torch.manual_seed(12)
+    B, H, W, C = 2, 24, 32, 64
+    x0 = torch.randn(B, H, W, C, device="cuda").to(dtype)
+    ws = [(torch.randn(C, k, k, C, device="cuda") * (0.3 / k)) for k in (1, 3, 3)]
+    b0 = torch.randn(C, device="cuda") * 0.1
+    res = {}
+    for mode in (True, False):
+        x = x0.clone().requires_grad_(True)
+        w = [t.clone().requires_grad_(True) for t in ws]
+        b = b0.clone().requires_grad_(True)
+        g = act if mode else hip.ACT_NONE
+        h = ops.conv2d(x, w[0], b, act=act, defer=mode)                             # producer with a bias: its gradient moves to the column-sum queue
+        h2, h = ops.conv2d(h, w[1], pad=1, act=act, in_gate=g, defer=mode, fanout=True)       # consumer + producer, input used twice
+        out = ops.conv2d(h2, w[2], pad=1, in_gate=g, upsample_to=(2 * H, 2 * W))    # upsampled consumer: gate after the footprint sum
+        loss = (out.float() ** 2).mean() + (h.float() * 0.37).sum() * 1e-3           # second consumer of h behind the fan-out
+        loss.backward()
+        torch.cuda.synchronize()
+        res[mode] = [out.detach().float(), x.grad.float(), b.grad.float()] + [t.grad.float() for t in w]
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for a, r in zip(res[True], res[False]):
+        assert rel(a, r) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,C,skip", [(614400 // 64, 64, False), (777, 64, True), (130, 160, True), (65, 24, False), (33, 7, False)])
+def test_layernorm_backward_applies_the_elu_gate_of_its_input(dev, rows, C, skip, dtype):
+    """GWD_LN_ELU_INPUT: gx = (LN backward + gskip) * elu'(x), x = the ELU output the norm was applied to (C = 7: no vector kernel,
+    the binding reports it and ops falls back to a separate pass)."""
+    x = rnd(rows, C, dtype=dtype, seed=1)
+    x = torch.where(x > 0, x, torch.expm1(x.float()).to(dtype))
+    gy, ga, be = rnd(rows, C, dtype=dtype, seed=2), rnd(C, seed=3) + 1.0, rnd(C, seed=4)
+    gs = rnd(rows, C, dtype=dtype, seed=5) if skip else None
+    fake = FakeDevice()
+    y, mean, rstd = torch.empty(rows, C), torch.empty(rows), torch.empty(rows)
+    fake.layernorm_forward(x, ga, be, y, mean, rstd, rows, C, False)
+    want, dg_r, db_r = torch.empty(rows, C), torch.zeros(C), torch.zeros(C)
+    fake.layernorm_backward(gy, x, ga, be, mean, rstd, want, dg_r, db_r, rows, C, False, gskip=gs, elu_input=True)
+    got, dg, db = torch.empty(rows, C, dtype=dtype, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    done = dev.layernorm_backward(gy.cuda(), x.cuda(), ga.cuda(), be.cuda(), mean.cuda(), rstd.cuda(), got, dg, db, rows, C, False,
+                                  gskip=None if gs is None else gs.cuda(), elu_input=True)
+    torch.cuda.synchronize()
+    if C == 7:
+        assert done is False
+        return
+    assert done is True
+    assert rel(got, want) < TOL[dtype] and rel(dg, dg_r) < TOL[dtype] * 2 and rel(db, db_r) < TOL[dtype] * 2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("gate_act", [hip.ACT_RELU, hip.ACT_ELU])
+@pytest.mark.parametrize("shape", [(2, 12, 16, 24, 32, 64), (1, 9, 11, 24, 32, 32), (2, 30, 40, 60, 80, 12)])
+def test_nearest_upsample_backward_with_activation_gate(dev, shape, gate_act, dtype):
+    B, Hs, Ws, Ho, Wo, C = shape
+    gy = rnd(B, Ho, Wo, C, dtype=dtype, seed=1)
+    src = rnd(B, Hs, Ws, C, dtype=dtype, seed=2)
+    src = src.clamp_min(0) if gate_act == hip.ACT_RELU else torch.where(src > 0, src, torch.expm1(src.float()).to(dtype))
+    want = torch.empty(B, Hs, Ws, C)
+    FakeDevice().resample_backward(gy, want, B, Hs, Ws, Ho, Wo, C, hip.RESAMPLE_NEAREST, gate=src, gate_act=gate_act)
+    got = torch.empty(B, Hs, Ws, C, dtype=dtype, device="cuda")
+    assert dev.resample_backward(gy.cuda(), got, B, Hs, Ws, Ho, Wo, C, hip.RESAMPLE_NEAREST, gate=src.cuda(), gate_act=gate_act) is True
+    torch.cuda.synchronize()
+    assert rel(got, want) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_deferred_elu_chain_of_the_decoder_equals_the_separate_passes(dev, dtype):
+    """upconv (ELU, defer) -> LayerNorm(in_gate) -> conv (ELU, defer) -> upconv(in_gate; ELU, defer) -> conv(in_gate; ELU, defer) ->
+    thin head(in_gate): the decoder branch of model.DensePrediction with and without the deferred activation backward."""
+    from gw_depth_amd import ops
+    torch.manual_seed(13)
+    B, H, W, C = 2, 20, 24, 64
+    x0 = torch.randn(B, H, W, C, device="cuda").to(dtype)
+    ws = [torch.randn(co, 3, 3, ci, device="cuda") * (0.5 / (3 * ci ** 0.5)) * 3 for co, ci in ((64, 64), (64, 64), (32, 64), (32, 32), (1, 32))]
+    ga, be = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.1
+    res = {}
+    for mode in (True, False):
+        x = x0.clone().requires_grad_(True)
+        w = [t.clone().requires_grad_(True) for t in ws]
+        g_, b_ = ga.clone().requires_grad_(True), be.clone().requires_grad_(True)
+        g = hip.ACT_ELU if mode else hip.ACT_NONE
+        u1 = ops.layer_norm(ops.conv2d(x, w[0], pad=1, act=hip.ACT_ELU, upsample_to=(2 * H, 2 * W), defer=mode), g_, b_, in_gate=g)
+        c1 = ops.conv2d(u1, w[1], pad=1, act=hip.ACT_ELU, defer=mode)
+        u2 = ops.conv2d(c1, w[2], pad=1, act=hip.ACT_ELU, upsample_to=(4 * H, 4 * W), in_gate=g, defer=mode)
+        c2 = ops.conv2d(u2, w[3], pad=1, act=hip.ACT_ELU, in_gate=g, defer=mode)
+        out = ops.conv2d(c2, w[4], pad=1, act=hip.ACT_SIGMOID, act_scale=10.0, in_gate=g)
+        (out.float() ** 2).mean().backward()
+        torch.cuda.synchronize()
+        res[mode] = [out.detach().float(), x.grad.float(), g_.grad.float(), b_.grad.float()] + [t.grad.float() for t in w]
+    tol = 1e-5 if dtype == torch.float32 else 3e-2
+    for a, r in zip(res[True], res[False]):
+        assert rel(a, r) < tol
