@@ -87,6 +87,17 @@ __global__ __launch_bounds__(256) void thin_dgrad_kernel(const gwd_conv_desc d) 
     t /= tw;
     const int h0 = (t % th) * TILE, b = t / th;
     const __bf16 *wgt = (const __bf16 *)d.w;
+    // desc.gate (the layer's input = the producer's activation output): this thread's 64 bytes, requested before anything else so
+    // that they arrive behind the staging and the 288 x NO multiply-adds (loaded in the epilogue they cost 110-150 us of exposed latency)
+    bf16x8 gg[4] = {};
+    {
+        const int oh_ = h0 + (int)threadIdx.x / TILE, ow_ = w0 + (int)threadIdx.x % TILE;
+        if (d.gate && oh_ < H && ow_ < W) {
+            const __bf16 *gte = (const __bf16 *)d.gate + (((size_t)b * H + oh_) * W + ow_) * C;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) gg[v] = *(const bf16x8 *)(gte + v * 8);
+        }
+    }
     for (int i = threadIdx.x; i < 9 * NO * C; i += 256) {
         const int c = i % C, n = (i / C) % NO, tap = i / (C * NO);
         ws[i] = (float)wgt[(c * 9 + tap) * NO + n];
@@ -125,14 +136,12 @@ __global__ __launch_bounds__(256) void thin_dgrad_kernel(const gwd_conv_desc d) 
     const int oh = h0 + ty, ow = w0 + tx;
     if (oh < H && ow < W) {
         __bf16 *gx = (__bf16 *)d.y + (((size_t)b * H + oh) * W + ow) * C;
-        const __bf16 *gte = d.gate ? (const __bf16 *)d.gate + (((size_t)b * H + oh) * W + ow) * C : nullptr;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             bf16x8 o;
-            if (gte) {                                    // backward of the activation that produced this layer's input (desc.gate)
-                const bf16x8 gg = *(const bf16x8 *)(gte + v * 8);
+            if (d.gate) {                                 // backward of the activation that produced this layer's input (desc.gate)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (__bf16)gate_grad(acc[v * 8 + e], (float)gg[e], d.gate_act);
+                for (int e = 0; e < 8; ++e) o[e] = (__bf16)gate_grad(acc[v * 8 + e], (float)gg[v][e], d.gate_act);
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[v * 8 + e];

@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgwdepth_hip.so")
+LIB_PATH = os.environ.get("GWD_LIB") or os.path.join(_HERE, "libgwdepth_hip.so")     # GWD_LIB: another build of the same ABI (same-box A/B of kernel variants)
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3, 4

@@ -894,14 +894,16 @@ class DensePrediction(nn.Module):
         B, H, W, _ = fuse_in.shape
         f = fuse(cast("decoder_fuse", fuse_in))
         f = cast("decoder_up1", f)
-        # the ELU backward of all four convolutions runs inside the backward of the layer behind each: the LayerNorm (upconv1), the
-        # footprint sum of the up-sampling conv (conv1), the data-gradient epilogue of conv2 (upconv2) and of the depth / seg head (conv2)
+        # the ELU backward of three of the four convolutions runs inside the backward of the layer behind each: the LayerNorm (upconv1),
+        # the footprint sum of the up-sampling conv (conv1), the data-gradient epilogue of conv2 (upconv2)
         g = ACT_ELU if ops.act_gate_enabled() else ACT_NONE
         u1 = getattr(self, f"norm_{tag}")(getattr(self, f"upconv1_{tag}")(f, (2 * H, 2 * W), defer=g != ACT_NONE), in_gate=g)
         c1 = ops.conv2d(u1, getattr(self, f"conv1_{tag}")[0].weight, pad=1, act=ACT_ELU, defer=g != ACT_NONE)
         c1 = cast("decoder_up2", c1)
         u2 = getattr(self, f"upconv2_{tag}")(c1, size, defer=g != ACT_NONE, in_gate=g)
-        return cast("decoder_head", ops.conv2d(u2, getattr(self, f"conv2_{tag}")[0].weight, pad=1, act=ACT_ELU, in_gate=g, defer=g != ACT_NONE))
+        # conv2 keeps its own pass: in the 1- / 2-channel heads' data gradient (one thread per pixel, 64 bytes of gate each) the gate
+        # costs 90-140 us inside the step against the 87 us of the pass it would replace (tools/gatebench.py, per-kernel trace)
+        return cast("decoder_head", ops.conv2d(u2, getattr(self, f"conv2_{tag}")[0].weight, pad=1, act=ACT_ELU, in_gate=g))
 
     def forward(self, feat, depth3, dtok, stok, size, cast=None):
         cast = cast or (lambda stage, t: t)
@@ -912,10 +914,9 @@ class DensePrediction(nn.Module):
         if pad and feat.is_cuda:
             parts.append(self.zero_channels(feat, pad))
         d = self.branch(torch.cat(parts, dim=-1), "depth", self.fuse_padded, size, cast)
-        g = ACT_ELU if ops.act_gate_enabled() else ACT_NONE
-        depth = ops.conv2d(d, self.get_depth[0].weight, pad=1, act=ACT_SIGMOID, act_scale=float(self.max_depth), in_gate=g)
+        depth = ops.conv2d(d, self.get_depth[0].weight, pad=1, act=ACT_SIGMOID, act_scale=float(self.max_depth))
         s = self.branch(torch.cat([feat, stok], dim=-1), "seg", self.seg_token_fuse, size, cast)
-        seg = ops.conv2d(s, self.get_seg.weight, pad=1, in_gate=g)
+        seg = ops.conv2d(s, self.get_seg.weight, pad=1)
         return depth.float().view(B, 1, size[0], size[1]), seg.permute(0, 3, 1, 2)
 
 
