@@ -1212,6 +1212,202 @@ static int fwd_variant() {                   // experiment switch (tools/convben
     return v;
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// long reductions on few rows: K split over the waves of a workgroup
+// ----------------------------------------------------------------------------------------------
+// The FFN 2048 -> 256 GEMMs of the DETR layers (800 / 2 400 rows) and the 1 024- / 2 048-deep 1x1 layers of ResNet layer3 / 4 fill
+// 50-600 tiles of 64 x 64 - at most a workgroup or two per CU - and then walk K / 32 = 32-64 steps, each one a barrier, an LDS round
+// trip and two dependent MFMAs per wave: 0.34 us per step whatever the ring depth (8 stages measured: no change), 22 us for 0.4 GFLOP.
+// Here every WAVE owns the whole 64 x 64 tile (4 independent accumulators: 8 MFMAs per step instead of 2) over every fourth K step,
+// with a private LDS-DMA ring (no workgroup barrier in the loop); the four partial tiles meet in LDS and the usual epilogue runs once.
+// Plain GEMM only: 1x1, stride 1, no padding (conv or transposed gather - the same thing), bf16, K % 32 == 0, N % 8 == 0.
+template <int STAGES, bool MULT>
+__global__ __launch_bounds__(256) void gemm_ksplit_kernel(const gwd_conv_desc d, const int tile_count) {
+    typedef __bf16 T;
+    constexpr int BM = 64, BN = 64, STAGE_BYTES = (BM + BN) * 64, WAVE_BYTES = STAGES * STAGE_BYTES, RP = 68;    // RP: fp32 pitch of the partial tiles
+    static_assert(4 * BM * RP * 4 <= 4 * WAVE_BYTES, "the partial tiles reuse the rings");
+    extern __shared__ __attribute__((aligned(1024))) char ks_smem[];
+    const int M = d.B * d.Ho * d.Wo, N = d.Cout, K = d.Cin;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_tiles = (N + BN - 1) / BN;
+    const int tile = xcd_band(blockIdx.x, tile_count);
+    const int m0 = (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;
+    const T *x = (const T *)d.x;
+    const T *wgt = (const T *)d.w;
+    const char *zero = (const char *)d.zero_page;
+    char *ring = ks_smem + wave * WAVE_BYTES;
+
+    // one DMA instruction moves 16 rows x 64 B; lane (r, c) fetches source chunk c ^ swizzle(row) so that the fragment reads below
+    // are bank-conflict free (same scheme as igemm_dma_kernel)
+    const char *a_src[4], *b_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 16 * i + (lane >> 2);
+        const int ck = ((lane & 3) ^ ((row >> 2) & 3)) * 8;
+        const int m = m0 + row, n = n0 + row;
+        a_src[i] = m < M ? (const char *)(x + (size_t)m * K + ck) : nullptr;
+        b_src[i] = n < N ? (const char *)(wgt + (size_t)n * K + ck) : nullptr;
+    }
+    const int KT = K / 32;
+    const int steps = (KT - wave + 3) / 4;                // this wave's K tiles: wave, wave + 4, ... (the four waves read 256 contiguous bytes of a row)
+    auto issue = [&](int s, int stage) {
+        char *sb = ring + stage * STAGE_BYTES;
+        const size_t koff = (size_t)(wave + 4 * s) * 64;  // bytes
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const char *sa = a_src[i] ? a_src[i] + koff : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sa,
+                                             (__attribute__((address_space(3))) void *)(sb + i * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const char *sw = b_src[i] ? b_src[i] + koff : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sw,
+                                             (__attribute__((address_space(3))) void *)(sb + BM * 64 + i * 1024), 16, 0, 0);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < STAGES - 1; ++t)
+        if (t < steps) issue(t, t);
+    for (int s = 0; s < steps; ++s) {
+        if (s + STAGES - 2 < steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (STAGES - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the buffer refilled now was read by the MFMAs of the previous step, which have issued (their operands had arrived)
+        if (s + STAGES - 1 < steps) issue(s + STAGES - 1, (s + STAGES - 1) % STAGES);
+        const T *As = (const T *)(ring + (s % STAGES) * STAGE_BYTES);
+        const T *Bs = As + BM * 32;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = i * 32 + fr;
+                af[i] = *(const bf16x8 *)(As + row * 32 + (((ks * 2 + fh) ^ ((row >> 2) & 3)) * 8));
+                bfr[i] = *(const bf16x8 *)(Bs + row * 32 + (((ks * 2 + fh) ^ ((row >> 2) & 3)) * 8));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mma(af[i], bfr[j], acc[i][j]);
+        }
+    }
+    __syncthreads();                                      // every ring is drained: the partial tiles take their place
+    float *red = (float *)ks_smem;                        // [wave][64][RP]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                red[(wave * BM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * RP + j * 32 + fr] = acc[i][j][r];
+    __syncthreads();
+    // epilogue: thread = (row, 16 consecutive columns) = two 16-byte vectors; same arithmetic and order as igemm_dma_kernel
+    const int row = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 16;
+    const int m = m0 + row;
+    if (m >= M) return;
+    T *y = (T *)d.y;
+    T *z = (T *)d.z;
+    const T *res = (const T *)d.residual;
+    const T *mul = MULT ? (const T *)d.mult : nullptr;
+    const T *gate = MULT ? nullptr : (const T *)d.gate;
+#pragma unroll
+    for (int hv = 0; hv < 2; ++hv) {
+        const int nb = n0 + c0 + 8 * hv;
+        if (nb >= N) continue;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f32x4 sum = *(const f32x4 *)(red + (size_t)row * RP + c0 + 8 * hv + 4 * q);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const f32x4 p = *(const f32x4 *)(red + (size_t)(w * BM + row) * RP + c0 + 8 * hv + 4 * q);
+                sum[0] += p[0]; sum[1] += p[1]; sum[2] += p[2]; sum[3] += p[3];
+            }
+            v[4 * q] = sum[0]; v[4 * q + 1] = sum[1]; v[4 * q + 2] = sum[2]; v[4 * q + 3] = sum[3];
+        }
+        const size_t o = (size_t)m * N + nb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * (d.scale ? d.scale[nb + e] : 1.0f) + (d.shift ? d.shift[nb + e] : 0.0f);
+        if (res && !mul) {
+            const bf16x8 rv = *(const bf16x8 *)(res + o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+        }
+        bf16x8 out;
+        if (z) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) out[e] = (__bf16)v[e];
+            *(bf16x8 *)(z + o) = out;
+        }
+        if (mul) {                                        // y = act_scale * act(v) * mult + residual (dropout, then the skip)
+            const bf16x8 mv = *(const bf16x8 *)(mul + o);
+            bf16x8 rv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rv[e] = (__bf16)0.0f;
+            if (res) rv = *(const bf16x8 *)(res + o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) out[e] = (__bf16)(apply_act(v[e], d.act) * d.act_scale * (float)mv[e] + (float)rv[e]);
+        } else {
+            float gm[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gm[e] = d.act_scale;
+            if (gate) {
+                const bf16x8 gv = *(const bf16x8 *)(gate + o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gm[e] = gate_grad(d.act_scale, (float)gv[e], d.gate_act);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) out[e] = (__bf16)(apply_act(v[e], d.act) * gm[e]);
+        }
+        *(bf16x8 *)(y + o) = out;
+    }
+}
+
+static int ksplit_min_k() {                  // A/B switch: GWD_IGEMM_KSPLIT=0 keeps these GEMMs on igemm_dma_kernel
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GWD_IGEMM_KSPLIT");
+        v = e ? atoi(e) : 1024;
+    }
+    return v;
+}
+
+// 1 = launched
+static int launch_ksplit(const gwd_conv_desc *d, hipStream_t s) {
+    const int M = d->B * d->Ho * d->Wo, N = d->Cout, K = d->Cin;
+    if (ksplit_min_k() <= 0 || K < ksplit_min_k() || d->dtype != GWD_BF16 || !d->zero_page) return 0;
+    if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad != 0 || d->Hi != d->Ho || d->Wi != d->Wo || d->gather == GWD_GATHER_UPSAMPLED) return 0;
+    if ((K % 32) || (N % 8)) return 0;
+    const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+    if (tiles > 320) return 0;                            // one workgroup (128 KiB of LDS) per CU: beyond ~one round the ordinary tiles win (600 tiles: 17 -> 21 us)
+    constexpr int ST = 4, LDS = 4 * ST * (64 + 64) * 64;  // 128 KiB: one workgroup per CU
+    if (d->mult) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void *)gemm_ksplit_kernel<ST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            attr = true;
+        }
+        gemm_ksplit_kernel<ST, true><<<(unsigned)tiles, 256, LDS, s>>>(*d, (int)tiles);
+    } else {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void *)gemm_ksplit_kernel<ST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            attr = true;
+        }
+        gemm_ksplit_kernel<ST, false><<<(unsigned)tiles, 256, LDS, s>>>(*d, (int)tiles);
+    }
+    return 1;
+}
+
 static bool dma_enabled() {
     static int v = -1;
     if (v < 0) {
@@ -1226,6 +1422,12 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
     const int M = d->B * d->Ho * d->Wo, N = d->Cout;
     constexpr int BK = Cfg<T>::BK;
     const unsigned gm = (M + 127) / 128;
+    if constexpr (sizeof(T) == 2) {
+        if (launch_ksplit(d, s)) {
+            GWD_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (d->mult) {
         // element-wise multiplier in the epilogue (dropout + skip of the DETR sub-layers: GEMMs with M <= a few thousand rows):
         // dedicated instantiations of the 64x64 tiles, so that the multiplier path costs the other kernels nothing

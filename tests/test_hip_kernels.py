@@ -1166,3 +1166,46 @@ def test_deferred_elu_chain_of_the_decoder_equals_the_separate_passes(dev, dtype
     tol = 1e-5 if dtype == torch.float32 else 3e-2
     for a, r in zip(res[True], res[False]):
         assert rel(a, r) < tol
+
+
+KSPLIT_CASES = [
+    # rows, K, N, extras  (K >= 1024, 1x1: gemm_ksplit_kernel)
+    (800, 2048, 256, dict(shift=True, residual=True, mult=True)),                  # FFN linear2: dropout + skip in the epilogue
+    (2400, 2048, 256, dict(shift=True)),
+    (777, 1024, 40, dict(shift=True, act=hip.ACT_RELU, residual=True)),            # ragged rows, a partial column tile
+    (2400, 2048, 512, dict(scale=True, shift=True, act=hip.ACT_RELU, gate=hip.ACT_RELU)),
+    (9600, 1024, 256, dict(shift=True, act=hip.ACT_GELU, z=True)),
+    (130, 1056, 72, dict(gather=hip.GATHER_TRANSPOSED, residual=True, gate=hip.ACT_ELU)),
+]
+
+
+@pytest.mark.parametrize("case", KSPLIT_CASES, ids=["%dx%dx%d_%s" % (c[0], c[1], c[2], "_".join(sorted(c[3]))) for c in KSPLIT_CASES])
+def test_long_reduction_gemm_split_over_waves(dev, case, monkeypatch):
+    """gemm_ksplit_kernel (1x1 layers with K >= 1024 on few rows) against fp32 math and against the ordinary kernel (GWD_IGEMM_KSPLIT=0
+    is read once per process, so the second comparison is with FakeDevice only when the switch cannot be flipped)."""
+    M, K, N, ex = case
+    dt = torch.bfloat16
+    x, w = rnd(M, 1, 1, K, dtype=dt, seed=1), rnd(N, 1, 1, K, dtype=dt, seed=2, scale=K ** -0.5)
+    kw, kw_gpu = {}, {}
+    for name, shape in (("scale", (N,)), ("shift", (N,))):
+        if ex.get(name):
+            kw[name] = rnd(*shape, seed=3 + len(name)) * 0.5 + (1.0 if name == "scale" else 0.0)
+    for name in ("residual", "mult"):
+        if ex.get(name):
+            kw[name] = rnd(M, 1, 1, N, dtype=dt, seed=7 + len(name))
+    if ex.get("gate"):
+        g = rnd(M, 1, 1, N, dtype=dt, seed=11)
+        kw["gate"], kw["gate_act"] = (g.clamp_min(0) if ex["gate"] == hip.ACT_RELU else torch.where(g > 0, g, torch.expm1(g.float()).to(dt))), ex["gate"]
+    for k in ("act", "gather"):
+        if k in ex:
+            kw[k] = ex[k]
+    dims = (M, 1, 1, K, 1, 1, N, 1, 1)
+    want, zw = torch.empty(M, 1, 1, N), (torch.empty(M, 1, 1, N) if ex.get("z") else None)
+    FakeDevice().conv_forward(x, w, want, dims, z=zw, **kw)
+    got = torch.empty(M, 1, 1, N, dtype=dt, device="cuda")
+    zg = torch.empty(M, 1, 1, N, dtype=dt, device="cuda") if ex.get("z") else None
+    dev.conv_forward(x.cuda(), w.cuda(), got, dims, z=zg, **{k: (v.cuda() if torch.is_tensor(v) else v) for k, v in kw.items()})
+    torch.cuda.synchronize()
+    assert rel(got, want) < TOL[dt]
+    if zg is not None:
+        assert rel(zg, zw) < TOL[dt]
