@@ -387,7 +387,9 @@ __device__ __forceinline__ int xcd_band(int id, int total) {
 
 // TAIL: Cin is a multiple of 8 but not of 32 (the 80-channel pyramid layers): the last 32-channel K tile of every tap is part data,
 // part zero page - compile-time variant, like MULT, so that the common kernels pay nothing for the per-lane channel bound.
-template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false, bool TAIL = false>
+// GATE: desc.gate in the epilogue, compile-time as well - as a run-time branch it cost EVERY launch ~3 % (0.122 -> 0.126 ms on the
+// 160 -> 160 layer, 0.2 ms per step), and only the data gradients of the ResNet blocks carry one (never the 160-wide tiles).
+template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false, bool TAIL = false, bool GATE = false>
 __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_desc d, const int tile_base, const int tile_count) {
     typedef __bf16 T;
     constexpr int BK = 32, NW = WM * WN;                 // 4 or 8 waves
@@ -581,7 +583,7 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
     T *z = (T *)d.z;
     const T *res = (const T *)d.residual;
     const T *mul = MULT ? (const T *)d.mult : nullptr;       // compile-time: the multiplier path costs the plain kernels registers
-    const T *gate = MULT ? nullptr : (const T *)d.gate;      // never together with a multiplier (check_desc)
+    const T *gate = (GATE && !MULT) ? (const T *)d.gate : nullptr;      // never together with a multiplier (check_desc)
     float *stage = (float *)smem + wave * (32 * 36);
     const int vr = lane >> 2, vc = (lane & 3) * 8;
 #pragma unroll
@@ -1446,7 +1448,7 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         // Cin = 8 (mod 32) multiples such as the 80-channel pyramid: the LDS-DMA kernels with a zero-page channel tail (big maps, the two
         // hot tile shapes, plain and stride-1 transposed gathers) instead of the register-staged kernel (112-166 us per launch)
-        if (dma_enabled() && tail_enabled() && d->zero_page && (d->Cin % 32) != 0 && (d->Cin % 8) == 0 && d->Cin > 32 && (N % 8) == 0 && M >= 256 * 512 &&
+        if (dma_enabled() && tail_enabled() && !d->gate && d->zero_page && (d->Cin % 32) != 0 && (d->Cin % 8) == 0 && d->Cin > 32 && (N % 8) == 0 && M >= 256 * 512 &&
             (d->gather == GWD_GATHER_CONV || (d->gather == GWD_GATHER_TRANSPOSED && d->stride == 1))) {
             const bool tr = d->gather != GWD_GATHER_CONV;
             const unsigned gm2 = (M + 255) / 256;
@@ -1465,14 +1467,18 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
                 return 0;
             }
         }
-        if (dma_enabled() && d->zero_page && (d->Cin % 32) == 0 && (N % 8) == 0) {
+        // a gate on a 160-wide layer (none in the model) goes to the register-staged kernel below: the 160-wide tiles stay gate-free
+        if (dma_enabled() && d->zero_page && (d->Cin % 32) == 0 && (N % 8) == 0 && !(d->gate && N % 160 == 0)) {
             const int gmk = d->gather == GWD_GATHER_CONV ? 0 : ((d->gather == GWD_GATHER_TRANSPOSED && d->stride == 1) ? 1 : 2);
-#define DMA_LAUNCH(BM_, BN_, WM_, WN_, ST_, GRID)                                                              \
+#define DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, G_)                                                        \
     switch (gmk) {                                                                                              \
-        case 0: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 0><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;       \
-        case 1: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 1><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;       \
-        default: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 2><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;      \
+        case 0: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 0, false, false, G_><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;       \
+        case 1: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 1, false, false, G_><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;       \
+        default: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 2, false, false, G_><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;      \
     }
+#define DMA_LAUNCH(BM_, BN_, WM_, WN_, ST_, GRID)                                                              \
+    if (BN_ % 160 != 0 && d->gate) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, (BN_ % 160 != 0)) }            \
+    else { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false) }
             const bool big = big_tiles_enabled() && M >= 256 * 512;      // >= 2 workgroups per CU with 256-row tiles
             const unsigned gm2 = (M + 255) / 256;
             if (N % 160 == 0) {
@@ -1494,6 +1500,7 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
                 DMA_LAUNCH(128, 32, 4, 1, 4, dim3(gm))
             }
 #undef DMA_LAUNCH
+#undef DMA_LAUNCH_G
             GWD_CHECK_LAUNCH();
             return 0;
         }
