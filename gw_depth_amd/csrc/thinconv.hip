@@ -87,17 +87,6 @@ __global__ __launch_bounds__(256) void thin_dgrad_kernel(const gwd_conv_desc d) 
     t /= tw;
     const int h0 = (t % th) * TILE, b = t / th;
     const __bf16 *wgt = (const __bf16 *)d.w;
-    // desc.gate (the layer's input = the producer's activation output): this thread's 64 bytes, requested before anything else so
-    // that they arrive behind the staging and the 288 x NO multiply-adds (loaded in the epilogue they cost 110-150 us of exposed latency)
-    bf16x8 gg[4] = {};
-    {
-        const int oh_ = h0 + (int)threadIdx.x / TILE, ow_ = w0 + (int)threadIdx.x % TILE;
-        if (d.gate && oh_ < H && ow_ < W) {
-            const __bf16 *gte = (const __bf16 *)d.gate + (((size_t)b * H + oh_) * W + ow_) * C;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) gg[v] = *(const bf16x8 *)(gte + v * 8);
-        }
-    }
     for (int i = threadIdx.x; i < 9 * NO * C; i += 256) {
         const int c = i % C, n = (i / C) % NO, tap = i / (C * NO);
         ws[i] = (float)wgt[(c * 9 + tap) * NO + n];
@@ -139,13 +128,8 @@ __global__ __launch_bounds__(256) void thin_dgrad_kernel(const gwd_conv_desc d) 
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             bf16x8 o;
-            if (d.gate) {                                 // backward of the activation that produced this layer's input (desc.gate)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (__bf16)gate_grad(acc[v * 8 + e], (float)gg[v][e], d.gate_act);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[v * 8 + e];
-            }
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[v * 8 + e];
             *(bf16x8 *)(gx + v * 8) = o;
         }
     }
@@ -205,8 +189,11 @@ bool thin_common(const gwd_conv_desc *d) {
 int gwd_thin_conv_forward(const gwd_conv_desc *d, hipStream_t s) {
     if (!thin_common(d) || d->mult) return 0;
     const unsigned tiles = (unsigned)(d->B * ((d->Hi + TILE - 1) / TILE) * ((d->Wi + TILE - 1) / TILE));
-    if (d->gate && ((uintptr_t)d->gate % 16)) return 0;
-    if (d->gather == GWD_GATHER_CONV && d->Cin == C && (d->Cout == 1 || d->Cout == 2) && !d->residual && !d->gate) {
+    // desc.gate: not here - any per-element gate in thin_dgrad_kernel's epilogue tips the compiler into a 256-VGPR schedule of the
+    // whole kernel (occupancy 8 -> 1, 78 -> 176 us even for launches WITHOUT a gate; operand prefetch, raw-word extraction, launch bounds
+    // and a scheduling barrier all tried); a gated thin problem runs on the implicit GEMM, and the model keeps conv2's own ELU pass
+    if (d->gate) return 0;
+    if (d->gather == GWD_GATHER_CONV && d->Cin == C && (d->Cout == 1 || d->Cout == 2) && !d->residual) {
         if (d->Cout == 1) thin_fwd_kernel<1><<<tiles, 256, 0, s>>>(*d);
         else thin_fwd_kernel<2><<<tiles, 256, 0, s>>>(*d);
         return 1;
