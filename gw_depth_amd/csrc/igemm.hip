@@ -1223,14 +1223,15 @@ static int fwd_variant() {                   // experiment switch (tools/convben
 // trip and two dependent MFMAs per wave: 0.34 us per step whatever the ring depth (8 stages measured: no change), 22 us for 0.4 GFLOP.
 // Here every WAVE owns the whole 64 x 64 tile (4 independent accumulators: 8 MFMAs per step instead of 2) over every fourth K step,
 // with a private LDS-DMA ring (no workgroup barrier in the loop); the four partial tiles meet in LDS and the usual epilogue runs once.
-// Plain GEMM only: 1x1, stride 1, no padding (conv or transposed gather - the same thing), bf16, K % 32 == 0, N % 8 == 0.
+// The 3x3 layers of ResNet layer4 and of the 1/32- and 1/64-resolution pyramid levels (K = 1 440 ... 4 608 on 560 / 2 400 pixels) are the
+// same problem with a gather: plain gather with any stride or transposed gather with stride 1, bf16, Cin % 32 == 0, N % 8 == 0.
 template <int STAGES, bool MULT>
 __global__ __launch_bounds__(256) void gemm_ksplit_kernel(const gwd_conv_desc d, const int tile_count) {
     typedef __bf16 T;
     constexpr int BM = 64, BN = 64, STAGE_BYTES = (BM + BN) * 64, WAVE_BYTES = STAGES * STAGE_BYTES, RP = 68;    // RP: fp32 pitch of the partial tiles
     static_assert(4 * BM * RP * 4 <= 4 * WAVE_BYTES, "the partial tiles reuse the rings");
     extern __shared__ __attribute__((aligned(1024))) char ks_smem[];
-    const int M = d.B * d.Ho * d.Wo, N = d.Cout, K = d.Cin;
+    const int M = d.B * d.Ho * d.Wo, N = d.Cout, K = d.KH * d.KW * d.Cin;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n_tiles = (N + BN - 1) / BN;
     const int tile = xcd_band(blockIdx.x, tile_count);
@@ -1241,27 +1242,46 @@ __global__ __launch_bounds__(256) void gemm_ksplit_kernel(const gwd_conv_desc d,
     char *ring = ks_smem + wave * WAVE_BYTES;
 
     // one DMA instruction moves 16 rows x 64 B; lane (r, c) fetches source chunk c ^ swizzle(row) so that the fragment reads below
-    // are bank-conflict free (same scheme as igemm_dma_kernel)
-    const char *a_src[4], *b_src[4];
+    // are bank-conflict free (same scheme as igemm_dma_kernel).  K tile kt = (filter tap, 32-channel slice): kt * 32 is the offset in
+    // a weight row ([Cout][KH][KW][Cin]); the A row of an output pixel comes from the tap's source pixel or from the zero page.
+    const bool transposed = d.gather == GWD_GATHER_TRANSPOSED;
+    const int cpt = d.Cin / 32;                           // K tiles per filter tap
+    int a_ph[4], a_pw[4], a_ck[4];
+    size_t a_pix[4];
+    bool a_ok[4];
+    const char *b_src[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = 16 * i + (lane >> 2);
         const int ck = ((lane & 3) ^ ((row >> 2) & 3)) * 8;
         const int m = m0 + row, n = n0 + row;
-        a_src[i] = m < M ? (const char *)(x + (size_t)m * K + ck) : nullptr;
+        a_ok[i] = m < M;
+        const int mm = a_ok[i] ? m : 0;
+        const int b = mm / (d.Ho * d.Wo);
+        const int rem = mm - b * (d.Ho * d.Wo);
+        const int oh = rem / d.Wo, ow = rem - oh * d.Wo;
+        a_pix[i] = (size_t)b * d.Hi * d.Wi;
+        a_ph[i] = transposed ? oh + d.pad : oh * d.stride - d.pad;
+        a_pw[i] = transposed ? ow + d.pad : ow * d.stride - d.pad;
+        a_ck[i] = ck;
         b_src[i] = n < N ? (const char *)(wgt + (size_t)n * K + ck) : nullptr;
     }
     const int KT = K / 32;
     const int steps = (KT - wave + 3) / 4;                // this wave's K tiles: wave, wave + 4, ... (the four waves read 256 contiguous bytes of a row)
     auto issue = [&](int s, int stage) {
         char *sb = ring + stage * STAGE_BYTES;
-        const size_t koff = (size_t)(wave + 4 * s) * 64;  // bytes
+        const int kt = wave + 4 * s;
+        const int tap = kt / cpt, c0 = (kt - tap * cpt) * 32;
+        const int kh = tap / d.KW, kw = tap - kh * d.KW;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const char *sa = a_src[i] ? a_src[i] + koff : zero;
+            const int ih = transposed ? a_ph[i] - kh : a_ph[i] + kh, iw = transposed ? a_pw[i] - kw : a_pw[i] + kw;
+            const bool ok = a_ok[i] & ((unsigned)ih < (unsigned)d.Hi) & ((unsigned)iw < (unsigned)d.Wi);
+            const char *sa = ok ? (const char *)(x + (a_pix[i] + (size_t)ih * d.Wi + iw) * d.Cin + c0 + a_ck[i]) : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sa,
                                              (__attribute__((address_space(3))) void *)(sb + i * 1024), 16, 0, 0);
         }
+        const size_t koff = (size_t)kt * 64;              // bytes
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const char *sw = b_src[i] ? b_src[i] + koff : zero;
@@ -1385,12 +1405,12 @@ static int ksplit_min_k() {                  // A/B switch: GWD_IGEMM_KSPLIT=0 k
 
 // 1 = launched
 static int launch_ksplit(const gwd_conv_desc *d, hipStream_t s) {
-    const int M = d->B * d->Ho * d->Wo, N = d->Cout, K = d->Cin;
+    const int M = d->B * d->Ho * d->Wo, N = d->Cout, K = d->KH * d->KW * d->Cin;
     if (ksplit_min_k() <= 0 || K < ksplit_min_k() || d->dtype != GWD_BF16 || !d->zero_page) return 0;
-    if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad != 0 || d->Hi != d->Ho || d->Wi != d->Wo || d->gather == GWD_GATHER_UPSAMPLED) return 0;
-    if ((K % 32) || (N % 8)) return 0;
+    if (d->gather == GWD_GATHER_UPSAMPLED || (d->gather == GWD_GATHER_TRANSPOSED && d->stride != 1)) return 0;
+    if ((d->Cin % 32) || (N % 8)) return 0;
     const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
-    if (tiles > 320) return 0;                            // one workgroup (128 KiB of LDS) per CU: beyond ~one round the ordinary tiles win (600 tiles: 17 -> 21 us)
+    if (tiles > 256) return 0;                            // one workgroup (128 KiB of LDS) per CU: beyond one round the ordinary tiles win (304 tiles, K = 4 608: 54 -> 58 us; 600 tiles: 17 -> 21 us)
     constexpr int ST = 4, LDS = 4 * ST * (64 + 64) * 64;  // 128 KiB: one workgroup per CU
     if (d->mult) {
         static bool attr = false;

@@ -51,6 +51,12 @@ CONV_CASES = [
     ("lin_800x2048_256", 800, 1, 1, 2048, 256, 1, 1, 0, None, dict(shift=True)),
     ("lin_1176x64_128_gelu", 1176, 1, 1, 64, 128, 1, 1, 0, None, dict(shift=True, act=hip.ACT_GELU, z=True)),
     ("lin_5x384_384", 5, 1, 1, 384, 384, 1, 1, 0, None, dict()),
+    # long reductions on few pixels: gemm_ksplit_kernel with a gather (ResNet layer4, the 1/32 and 1/64 pyramid levels)
+    ("3x3_512_512_l4", 8, 15, 20, 512, 512, 3, 1, 1, None, dict(shift=True, act=hip.ACT_RELU)),
+    ("3x3_s2_512_512_l4", 2, 30, 40, 512, 512, 3, 2, 1, None, dict(shift=True, act=hip.ACT_RELU)),
+    ("3x3_160_160_p32", 8, 15, 20, 160, 160, 3, 1, 1, None, dict(shift=True)),
+    ("3x3_160_160_p64_ragged", 3, 7, 10, 160, 160, 3, 1, 1, None, dict(residual=True)),
+    ("3x3_128_72_ragged_n", 1, 9, 11, 128, 72, 3, 1, 1, None, dict(act=hip.ACT_GELU, z=True, shift=True)),
 ]
 
 
