@@ -389,7 +389,10 @@ __device__ __forceinline__ int xcd_band(int id, int total) {
 // part zero page - compile-time variant, like MULT, so that the common kernels pay nothing for the per-lane channel bound.
 // GATE: desc.gate in the epilogue, compile-time as well - as a run-time branch it cost EVERY launch ~3 % (0.122 -> 0.126 ms on the
 // 160 -> 160 layer, 0.2 ms per step), and only the data gradients of the ResNet blocks carry one (never the 160-wide tiles).
-template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false, bool TAIL = false, bool GATE = false>
+// LEAN: no activation, no pre-activation copy (every data gradient, every conv in front of a LayerNorm, every plain Linear) - the
+// activation switch (erf / expm1 / exp paths, inlined 8 x TM x TN x 2 times) is most of the epilogue's code: without it the 160 -> 160
+// layer runs 0.122 -> 0.108 ms (same-box, 3 runs each).  Gated launches are always lean (the dispatcher sends the rest elsewhere).
+template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false, bool TAIL = false, bool GATE = false, bool LEAN = false>
 __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_desc d, const int tile_base, const int tile_count) {
     typedef __bf16 T;
     constexpr int BK = 32, NW = WM * WN;                 // 4 or 8 waves
@@ -580,7 +583,7 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
 
     // ---- epilogue (identical to igemm_fwd_kernel's vector path; N % 8 == 0 is a launch precondition)
     T *y = (T *)d.y;
-    T *z = (T *)d.z;
+    T *z = LEAN ? nullptr : (T *)d.z;
     const T *res = (const T *)d.residual;
     const T *mul = MULT ? (const T *)d.mult : nullptr;       // compile-time: the multiplier path costs the plain kernels registers
     const T *gate = (GATE && !MULT) ? (const T *)d.gate : nullptr;      // never together with a multiplier (check_desc)
@@ -643,7 +646,7 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
                             for (int e = 0; e < 8; ++e) gm[e] = gate_grad(d.act_scale, (float)gv[e], d.gate_act);
                         }
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) out[e] = (__bf16)(apply_act(v[e], d.act) * gm[e]);
+                        for (int e = 0; e < 8; ++e) out[e] = (__bf16)((LEAN ? v[e] : apply_act(v[e], d.act)) * gm[e]);
                     }
                     *(bf16x8 *)(y + o) = out;
                 }
@@ -1468,37 +1471,46 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         // Cin = 8 (mod 32) multiples such as the 80-channel pyramid: the LDS-DMA kernels with a zero-page channel tail (big maps, the two
         // hot tile shapes, plain and stride-1 transposed gathers) instead of the register-staged kernel (112-166 us per launch)
+        const bool lean = d->act == GWD_ACT_NONE && !d->z;
         if (dma_enabled() && tail_enabled() && !d->gate && d->zero_page && (d->Cin % 32) != 0 && (d->Cin % 8) == 0 && d->Cin > 32 && (N % 8) == 0 && M >= 256 * 512 &&
             (d->gather == GWD_GATHER_CONV || (d->gather == GWD_GATHER_TRANSPOSED && d->stride == 1))) {
             const bool tr = d->gather != GWD_GATHER_CONV;
             const unsigned gm2 = (M + 255) / 256;
             if (N % 160 == 0) {
                 const dim3 g(gm2 * (N / 160));
-                if (tr) igemm_dma_kernel<256, 160, 8, 1, 3, 1, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
+                if (lean) {
+                    if (tr) igemm_dma_kernel<256, 160, 8, 1, 3, 1, false, true, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
+                    else igemm_dma_kernel<256, 160, 8, 1, 3, 0, false, true, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
+                } else if (tr) igemm_dma_kernel<256, 160, 8, 1, 3, 1, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
                 else igemm_dma_kernel<256, 160, 8, 1, 3, 0, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
                 GWD_CHECK_LAUNCH();
                 return 0;
             }
             if (N > 64) {
                 const dim3 g(gm2 * ((N + 127) / 128));
-                if (tr) igemm_dma_kernel<256, 128, 4, 2, 3, 1, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
+                if (lean) {
+                    if (tr) igemm_dma_kernel<256, 128, 4, 2, 3, 1, false, true, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
+                    else igemm_dma_kernel<256, 128, 4, 2, 3, 0, false, true, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
+                } else if (tr) igemm_dma_kernel<256, 128, 4, 2, 3, 1, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
                 else igemm_dma_kernel<256, 128, 4, 2, 3, 0, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
                 GWD_CHECK_LAUNCH();
                 return 0;
             }
         }
-        // a gate on a 160-wide layer (none in the model) goes to the register-staged kernel below: the 160-wide tiles stay gate-free
-        if (dma_enabled() && d->zero_page && (d->Cin % 32) == 0 && (N % 8) == 0 && !(d->gate && N % 160 == 0)) {
+        // a gate on a 160-wide layer or together with an activation / a pre-activation copy (none in the model) goes to the
+        // register-staged kernel below: the 160-wide tiles stay gate-free, the gated variants lean
+        if (dma_enabled() && d->zero_page && (d->Cin % 32) == 0 && (N % 8) == 0 && !(d->gate && (N % 160 == 0 || !lean))) {
             const int gmk = d->gather == GWD_GATHER_CONV ? 0 : ((d->gather == GWD_GATHER_TRANSPOSED && d->stride == 1) ? 1 : 2);
-#define DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, G_)                                                        \
+#define DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, G_, L_)                                                    \
     switch (gmk) {                                                                                              \
-        case 0: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 0, false, false, G_><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;       \
-        case 1: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 1, false, false, G_><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;       \
-        default: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 2, false, false, G_><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;      \
+        case 0: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 0, false, false, G_, L_><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;   \
+        case 1: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 1, false, false, G_, L_><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;   \
+        default: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 2, false, false, G_, L_><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;  \
     }
 #define DMA_LAUNCH(BM_, BN_, WM_, WN_, ST_, GRID)                                                              \
-    if (BN_ % 160 != 0 && d->gate) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, (BN_ % 160 != 0)) }            \
-    else { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false) }
+    if (BN_ % 160 != 0 && d->gate) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, (BN_ % 160 != 0), true) }      \
+    else if (lean) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, true) }                                 \
+    else { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, false) }
             const bool big = big_tiles_enabled() && M >= 256 * 512;      // >= 2 workgroups per CU with 256-row tiles
             const unsigned gm2 = (M + 255) / 256;
             if (N % 160 == 0) {
