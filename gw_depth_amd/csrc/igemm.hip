@@ -392,7 +392,9 @@ __device__ __forceinline__ int xcd_band(int id, int total) {
 // LEAN: no activation, no pre-activation copy (every data gradient, every conv in front of a LayerNorm, every plain Linear) - the
 // activation switch (erf / expm1 / exp paths, inlined 8 x TM x TN x 2 times) is most of the epilogue's code: without it the 160 -> 160
 // layer runs 0.122 -> 0.108 ms (same-box, 3 runs each).  Gated launches are always lean (the dispatcher sends the rest elsewhere).
-template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false, bool TAIL = false, bool GATE = false, bool LEAN = false>
+// (ACTK: -1 = any activation, decided at run time, + the pre-activation copy; 0 = none = "lean"; 1 = ReLU, a single v_max - the
+// Bottleneck convolutions.)
+template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false, bool TAIL = false, bool GATE = false, int ACTK = -1>
 __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_desc d, const int tile_base, const int tile_count) {
     typedef __bf16 T;
     constexpr int BK = 32, NW = WM * WN;                 // 4 or 8 waves
@@ -583,7 +585,7 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
 
     // ---- epilogue (identical to igemm_fwd_kernel's vector path; N % 8 == 0 is a launch precondition)
     T *y = (T *)d.y;
-    T *z = LEAN ? nullptr : (T *)d.z;
+    T *z = ACTK >= 0 ? nullptr : (T *)d.z;
     const T *res = (const T *)d.residual;
     const T *mul = MULT ? (const T *)d.mult : nullptr;       // compile-time: the multiplier path costs the plain kernels registers
     const T *gate = (GATE && !MULT) ? (const T *)d.gate : nullptr;      // never together with a multiplier (check_desc)
@@ -646,7 +648,8 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
                             for (int e = 0; e < 8; ++e) gm[e] = gate_grad(d.act_scale, (float)gv[e], d.gate_act);
                         }
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) out[e] = (__bf16)((LEAN ? v[e] : apply_act(v[e], d.act)) * gm[e]);
+                        for (int e = 0; e < 8; ++e)
+                            out[e] = (__bf16)((ACTK == 0 ? v[e] : (ACTK == 1 ? (v[e] > 0.f ? v[e] : 0.f) : apply_act(v[e], d.act))) * gm[e]);
                     }
                     *(bf16x8 *)(y + o) = out;
                 }
@@ -1228,7 +1231,7 @@ static int fwd_variant() {                   // experiment switch (tools/convben
 // with a private LDS-DMA ring (no workgroup barrier in the loop); the four partial tiles meet in LDS and the usual epilogue runs once.
 // The 3x3 layers of ResNet layer4 and of the 1/32- and 1/64-resolution pyramid levels (K = 1 440 ... 4 608 on 560 / 2 400 pixels) are the
 // same problem with a gather: plain gather with any stride or transposed gather with stride 1, bf16, Cin % 32 == 0, N % 8 == 0.
-template <int STAGES, bool MULT>
+template <int STAGES, bool MULT, bool LEAN = false>
 __global__ __launch_bounds__(256) void gemm_ksplit_kernel(const gwd_conv_desc d, const int tile_count) {
     typedef __bf16 T;
     constexpr int BM = 64, BN = 64, STAGE_BYTES = (BM + BN) * 64, WAVE_BYTES = STAGES * STAGE_BYTES, RP = 68;    // RP: fp32 pitch of the partial tiles
@@ -1340,7 +1343,7 @@ __global__ __launch_bounds__(256) void gemm_ksplit_kernel(const gwd_conv_desc d,
     const int m = m0 + row;
     if (m >= M) return;
     T *y = (T *)d.y;
-    T *z = (T *)d.z;
+    T *z = LEAN ? nullptr : (T *)d.z;
     const T *res = (const T *)d.residual;
     const T *mul = MULT ? (const T *)d.mult : nullptr;
     const T *gate = MULT ? nullptr : (const T *)d.gate;
@@ -1380,7 +1383,7 @@ __global__ __launch_bounds__(256) void gemm_ksplit_kernel(const gwd_conv_desc d,
             for (int e = 0; e < 8; ++e) rv[e] = (__bf16)0.0f;
             if (res) rv = *(const bf16x8 *)(res + o);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) out[e] = (__bf16)(apply_act(v[e], d.act) * d.act_scale * (float)mv[e] + (float)rv[e]);
+            for (int e = 0; e < 8; ++e) out[e] = (__bf16)((LEAN ? v[e] : apply_act(v[e], d.act)) * d.act_scale * (float)mv[e] + (float)rv[e]);
         } else {
             float gm[8];
 #pragma unroll
@@ -1391,7 +1394,7 @@ __global__ __launch_bounds__(256) void gemm_ksplit_kernel(const gwd_conv_desc d,
                 for (int e = 0; e < 8; ++e) gm[e] = gate_grad(d.act_scale, (float)gv[e], d.gate_act);
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) out[e] = (__bf16)(apply_act(v[e], d.act) * gm[e]);
+            for (int e = 0; e < 8; ++e) out[e] = (__bf16)((LEAN ? v[e] : apply_act(v[e], d.act)) * gm[e]);
         }
         *(bf16x8 *)(y + o) = out;
     }
@@ -1415,21 +1418,22 @@ static int launch_ksplit(const gwd_conv_desc *d, hipStream_t s) {
     const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
     if (tiles > 256) return 0;                            // one workgroup (128 KiB of LDS) per CU: beyond one round the ordinary tiles win (304 tiles, K = 4 608: 54 -> 58 us; 600 tiles: 17 -> 21 us)
     constexpr int ST = 4, LDS = 4 * ST * (64 + 64) * 64;  // 128 KiB: one workgroup per CU
-    if (d->mult) {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void *)gemm_ksplit_kernel<ST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            attr = true;
-        }
-        gemm_ksplit_kernel<ST, true><<<(unsigned)tiles, 256, LDS, s>>>(*d, (int)tiles);
-    } else {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void *)gemm_ksplit_kernel<ST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            attr = true;
-        }
-        gemm_ksplit_kernel<ST, false><<<(unsigned)tiles, 256, LDS, s>>>(*d, (int)tiles);
+    const bool lean = d->act == GWD_ACT_NONE && !d->z;
+#define KS_LAUNCH(MULT_, LEAN_)                                                                                                    \
+    {                                                                                                                              \
+        static bool attr = false;                                                                                                  \
+        if (!attr) {                                                                                                               \
+            (void)hipFuncSetAttribute((const void *)gemm_ksplit_kernel<ST, MULT_, LEAN_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
+            attr = true;                                                                                                           \
+        }                                                                                                                          \
+        gemm_ksplit_kernel<ST, MULT_, LEAN_><<<(unsigned)tiles, 256, LDS, s>>>(*d, (int)tiles);                                     \
     }
+    if (d->mult) {
+        if (lean) KS_LAUNCH(true, true) else KS_LAUNCH(true, false)
+    } else {
+        if (lean) KS_LAUNCH(false, true) else KS_LAUNCH(false, false)
+    }
+#undef KS_LAUNCH
     return 1;
 }
 
@@ -1471,7 +1475,8 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         // Cin = 8 (mod 32) multiples such as the 80-channel pyramid: the LDS-DMA kernels with a zero-page channel tail (big maps, the two
         // hot tile shapes, plain and stride-1 transposed gathers) instead of the register-staged kernel (112-166 us per launch)
-        const bool lean = d->act == GWD_ACT_NONE && !d->z;
+        const int actk = d->z ? -1 : (d->act == GWD_ACT_NONE ? 0 : (d->act == GWD_ACT_RELU ? 1 : -1));
+        const bool lean = actk == 0;
         if (dma_enabled() && tail_enabled() && !d->gate && d->zero_page && (d->Cin % 32) != 0 && (d->Cin % 8) == 0 && d->Cin > 32 && (N % 8) == 0 && M >= 256 * 512 &&
             (d->gather == GWD_GATHER_CONV || (d->gather == GWD_GATHER_TRANSPOSED && d->stride == 1))) {
             const bool tr = d->gather != GWD_GATHER_CONV;
@@ -1479,8 +1484,8 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
             if (N % 160 == 0) {
                 const dim3 g(gm2 * (N / 160));
                 if (lean) {
-                    if (tr) igemm_dma_kernel<256, 160, 8, 1, 3, 1, false, true, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
-                    else igemm_dma_kernel<256, 160, 8, 1, 3, 0, false, true, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
+                    if (tr) igemm_dma_kernel<256, 160, 8, 1, 3, 1, false, true, false, 0><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
+                    else igemm_dma_kernel<256, 160, 8, 1, 3, 0, false, true, false, 0><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
                 } else if (tr) igemm_dma_kernel<256, 160, 8, 1, 3, 1, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
                 else igemm_dma_kernel<256, 160, 8, 1, 3, 0, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
                 GWD_CHECK_LAUNCH();
@@ -1489,8 +1494,8 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
             if (N > 64) {
                 const dim3 g(gm2 * ((N + 127) / 128));
                 if (lean) {
-                    if (tr) igemm_dma_kernel<256, 128, 4, 2, 3, 1, false, true, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
-                    else igemm_dma_kernel<256, 128, 4, 2, 3, 0, false, true, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
+                    if (tr) igemm_dma_kernel<256, 128, 4, 2, 3, 1, false, true, false, 0><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
+                    else igemm_dma_kernel<256, 128, 4, 2, 3, 0, false, true, false, 0><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
                 } else if (tr) igemm_dma_kernel<256, 128, 4, 2, 3, 1, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
                 else igemm_dma_kernel<256, 128, 4, 2, 3, 0, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
                 GWD_CHECK_LAUNCH();
@@ -1508,9 +1513,10 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
         default: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 2, false, false, G_, L_><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;  \
     }
 #define DMA_LAUNCH(BM_, BN_, WM_, WN_, ST_, GRID)                                                              \
-    if (BN_ % 160 != 0 && d->gate) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, (BN_ % 160 != 0), true) }      \
-    else if (lean) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, true) }                                 \
-    else { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, false) }
+    if (BN_ % 160 != 0 && d->gate) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, (BN_ % 160 != 0), 0) }         \
+    else if (actk == 0) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, 0) }                               \
+    else if (actk == 1 && BN_ % 160 != 0) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, (BN_ % 160 != 0 ? 1 : -1)) } \
+    else { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, -1) }
             const bool big = big_tiles_enabled() && M >= 256 * 512;      // >= 2 workgroups per CU with 256-row tiles
             const unsigned gm2 = (M + 255) / 256;
             if (N % 160 == 0) {
