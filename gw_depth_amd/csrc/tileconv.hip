@@ -59,7 +59,9 @@ __device__ __forceinline__ void halo_put(__bf16 *halo, int chunk, const u32x4 &v
 // ------------------------------------------------------------------------------------------------ forward / data gradient
 // x: [B][Hs][Ws][CIN] (Hs = Hv / 2 when UP), w: [COUT][3][3][CIN] bf16 (already scaled / transposed by gwd_weight_prep),
 // y: [B][Hv][Wv][COUT].  FLIP: the data-gradient gather (source = pixel + 1 - tap).
-template <int CIN, int COUT, int TH, bool UP, bool FLIP, int RPW = 2>
+// ACTK: the epilogue's activation as a compile-time constant (GWD_ACT_NONE: data gradients, GWD_ACT_ELU: the decoder) or -1 = decided at
+// run time - the four-way switch with its erf / expm1 / exp paths, inlined once per output register, was most of the epilogue's code.
+template <int CIN, int COUT, int TH, bool UP, bool FLIP, int RPW = 2, int ACTK = -1>
 __global__ __launch_bounds__(64 * TH / RPW) void tconv_fwd_kernel(const gwd_conv_desc d, int tiles_y, int tiles_x, int ntiles) {
     // RPW = output rows per wave: 2 halves the weight-fragment reads per MFMA; 1 doubles the waves of a workgroup - for the layers whose
     // LDS footprint (weights + halo) allows ONE workgroup per CU, that is the difference between one and two waves per SIMD
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(64 * TH / RPW) void tconv_fwd_kernel(const gwd_conv
                         if (rsd) rr.u = *(const uint2 *)(rsd + 32 * nt + 8 * g + 4 * h);         // added before the activation, as the implicit GEMM does
                         float f[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) f[j] = apply_act(acc[mt][nt][4 * g + j] + sh[nt][4 * g + j] + (float)rr.e[j], d.act) * d.act_scale;
+                        for (int j = 0; j < 4; ++j) f[j] = apply_act(acc[mt][nt][4 * g + j] + sh[nt][4 * g + j] + (float)rr.e[j], ACTK < 0 ? d.act : ACTK) * d.act_scale;
                         if (gte) {                                             // backward of the producer's activation (desc.gate), last
                             union { uint2 u; __bf16 e[4]; } gg;
                             gg.u = *(const uint2 *)(gte + 32 * nt + 8 * g + 4 * h);
@@ -193,11 +195,6 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
     const int ty = (d->Ho + TH - 1) / TH, tx = (d->Wo + TW - 1) / TW;
     const long ntiles = (long)d->B * ty * tx;
     const size_t lds = fwd_lds<CIN, COUT, TH>();
-    static bool attr = false;
-    if (!attr) {                                            // dynamic LDS beyond 64 KiB has to be requested once per kernel
-        (void)hipFuncSetAttribute((const void *)tconv_fwd_kernel<CIN, COUT, TH, UP, FLIP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
     const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
     long grid = 256L * per_cu;
     if (grid > ntiles) grid = ntiles;
@@ -207,19 +204,27 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
         rpw1 = e ? atoi(e) : 1;
     }
     constexpr int bit = (CIN == 64 && COUT == 64) ? 1 : (CIN == 64 && COUT == 32) ? 2 : (CIN == 32 && COUT == 64) ? 4 : (CIN == 32 && COUT == 32) ? 8 : 0;
-    if constexpr (bit != 0) {
-        if (rpw1 & bit) {
-            static bool attr1 = false;
-            if (!attr1) {
-                (void)hipFuncSetAttribute((const void *)tconv_fwd_kernel<CIN, COUT, TH, UP, FLIP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                attr1 = true;
-            }
-            tconv_fwd_kernel<CIN, COUT, TH, UP, FLIP, 1><<<(unsigned)grid, 64 * TH, lds, s>>>(*d, ty, tx, (int)ntiles);
-            return 1;
-        }
+#define TC_GO(RPW_, ACTK_)                                                                                                       \
+    {                                                                                                                            \
+        static bool attr = false;                                                                                                \
+        if (!attr) {                                            /* dynamic LDS beyond 64 KiB has to be requested once per kernel */ \
+            (void)hipFuncSetAttribute((const void *)tconv_fwd_kernel<CIN, COUT, TH, UP, FLIP, RPW_, ACTK_>,                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
+            attr = true;                                                                                                         \
+        }                                                                                                                        \
+        tconv_fwd_kernel<CIN, COUT, TH, UP, FLIP, RPW_, ACTK_><<<(unsigned)grid, 64 * TH / RPW_, lds, s>>>(*d, ty, tx, (int)ntiles); \
+        return 1;                                                                                                                \
     }
-    tconv_fwd_kernel<CIN, COUT, TH, UP, FLIP><<<(unsigned)grid, 32 * TH, lds, s>>>(*d, ty, tx, (int)ntiles);
-    return 1;
+#define TC_ACT(RPW_)                                                                                                             \
+    if (d->act == GWD_ACT_NONE) TC_GO(RPW_, GWD_ACT_NONE)                                                                        \
+    if (d->act == GWD_ACT_ELU) TC_GO(RPW_, GWD_ACT_ELU)                                                                          \
+    TC_GO(RPW_, -1)
+    if constexpr (bit != 0) {
+        if (rpw1 & bit) { TC_ACT(1) }
+    }
+    TC_ACT(2)
+#undef TC_ACT
+#undef TC_GO
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
