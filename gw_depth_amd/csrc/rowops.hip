@@ -295,7 +295,7 @@ template <int VB> struct Raw;
 template <> struct Raw<16> { uint4 v; };
 template <> struct Raw<8> { uint2 v; };
 
-template <typename T, int LPR, int NCH, int VB, bool PAD = false>
+template <typename T, int LPR, int NCH, int VB, bool PAD = false, bool GELU = false>
 __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T *__restrict__ x, const float *__restrict__ gamma,
                                                                 const float *__restrict__ beta, T *__restrict__ y,
                                                                 float *__restrict__ mean, float *__restrict__ rstd,
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T *__restr
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 float o = (v[c][e] - mu) * rs * g[c][e] + b[c][e];
-                if (gelu) o = gelu_f(o);
+                if (GELU) o = gelu_f(o);         // compile-time: the erf code is not in the plain kernels
                 if (res) o += to_f32(pr[e]);
                 if (PAD && (sub + c * LPR) * VEC + e >= C) o = 0.f;
                 outv[e] = from_f32<T>(o);
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T *__restr
 
 // NWV waves per workgroup: 4, or 16 for narrow rows - the affine-gradient reduction ends in one atomic per channel per
 // WORKGROUP, and with hundreds of small workgroups those serialise on the same few cache lines (10-18 us of a 25 us call)
-template <typename T, int LPR, int NCH, int VB, int NWV, bool PAD = false>
+template <typename T, int LPR, int NCH, int VB, int NWV, bool PAD = false, bool GELU = false>
 __global__ __launch_bounds__(NWV * 64) void layernorm_bwd_vec_kernel(const T *__restrict__ gy, const T *__restrict__ x,
                                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                 const float *__restrict__ mean, const float *__restrict__ rstd,
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(NWV * 64) void layernorm_bwd_vec_kernel(const T *__
                 const bool ok = okv && (!PAD || (sub + c * LPR) * VEC + e < C);
                 xh[c][e] = ok ? (to_f32(px[e]) - mu) * rs : 0.f;
                 float gg = ok ? to_f32(pg[e]) : 0.f;
-                if (gelu & 1) gg *= gelu_grad_f(xh[c][e] * g[c][e] + b[c][e]);
+                if (GELU) gg *= gelu_grad_f(xh[c][e] * g[c][e] + b[c][e]);     // compile-time (bit 0 of the flags): no erf / exp code in the plain kernels
                 ag[c][e] += gg * xh[c][e];
                 ab[c][e] += gg;
                 gw[c][e] = gg * g[c][e];
@@ -669,7 +669,8 @@ int launch_ln_fwd_vec(const T *x, const float *ga, const float *be, T *y, float 
         /* ~20 KiB of rows per workgroup: measured optimum between 10 MB (512 workgroups) and 49 MB (2048) tensors */  \
         int64_t cap = rows * C * (int64_t)sizeof(T) / 20480;                                                        \
         cap = cap < 256 ? 256 : (cap > 2048 ? 2048 : cap);                                                          \
-        layernorm_fwd_vec_kernel<T, LPR, NCH, VB, PAD><<<row_grid(wv, 4, (int)cap), 256, 0, s>>>(x, ga, be, y, mean, rstd, rows, C, gelu, res, ld); \
+        if (gelu) layernorm_fwd_vec_kernel<T, LPR, NCH, VB, PAD, true><<<row_grid(wv, 4, (int)cap), 256, 0, s>>>(x, ga, be, y, mean, rstd, rows, C, gelu, res, ld); \
+        else layernorm_fwd_vec_kernel<T, LPR, NCH, VB, PAD, false><<<row_grid(wv, 4, (int)cap), 256, 0, s>>>(x, ga, be, y, mean, rstd, rows, C, gelu, res, ld); \
         return 0;                                                                                                   \
     }
     if (need <= 8) LN_FWD(8, 1)
@@ -693,12 +694,14 @@ int launch_ln_bwd_vec(const T *gy, const T *x, const float *ga, const float *be,
         if (LPR * NCH * VEC <= 512 && dg) {                     /* narrow rows: 16-wave workgroups, one per CU */   \
             int grid = row_grid(wv, 16);                                                                            \
             if (grid > 256) grid = 256;                                                                             \
-            layernorm_bwd_vec_kernel<T, LPR, NCH, VB, 16, PAD><<<grid, 1024, 0, s>>>(gy, x, ga, be, mean, rstd, gx, dg, db, rows, C, gelu, ld, gskip); \
+            if (gelu & 1) layernorm_bwd_vec_kernel<T, LPR, NCH, VB, 16, PAD, true><<<grid, 1024, 0, s>>>(gy, x, ga, be, mean, rstd, gx, dg, db, rows, C, gelu, ld, gskip); \
+            else layernorm_bwd_vec_kernel<T, LPR, NCH, VB, 16, PAD, false><<<grid, 1024, 0, s>>>(gy, x, ga, be, mean, rstd, gx, dg, db, rows, C, gelu, ld, gskip); \
             return 0;                                                                                               \
         }                                                                                                           \
         int grid = row_grid(wv, 4);                                                                                 \
         if (grid > 768) grid = 768;                                                                                 \
-        layernorm_bwd_vec_kernel<T, LPR, NCH, VB, 4, PAD><<<grid, 256, 0, s>>>(gy, x, ga, be, mean, rstd, gx, dg, db, rows, C, gelu, ld, gskip); \
+        if (gelu & 1) layernorm_bwd_vec_kernel<T, LPR, NCH, VB, 4, PAD, true><<<grid, 256, 0, s>>>(gy, x, ga, be, mean, rstd, gx, dg, db, rows, C, gelu, ld, gskip); \
+        else layernorm_bwd_vec_kernel<T, LPR, NCH, VB, 4, PAD, false><<<grid, 256, 0, s>>>(gy, x, ga, be, mean, rstd, gx, dg, db, rows, C, gelu, ld, gskip); \
         return 0;                                                                                                   \
     }
     if (need <= 8) LN_BWD(8, 1)
