@@ -637,7 +637,8 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
                         for (int e = 0; e < 8; ++e) rv[e] = (__bf16)0.0f;
                         if (res) rv = *(const bf16x8 *)(res + o);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) out[e] = (__bf16)(apply_act(v[e], d.act) * d.act_scale * (float)mv[e] + (float)rv[e]);
+                        for (int e = 0; e < 8; ++e)
+                            out[e] = (__bf16)((ACTK == 0 ? v[e] : (ACTK == 1 ? (v[e] > 0.f ? v[e] : 0.f) : apply_act(v[e], d.act))) * d.act_scale * (float)mv[e] + (float)rv[e]);
                     } else {
                         float gm[8];                         // desc.gate: backward of the producer's activation, from its output
 #pragma unroll
@@ -1463,7 +1464,9 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
         if constexpr (sizeof(T) == 2) {
             if (dma_enabled() && d->zero_page && (d->Cin % 32) == 0 && (N % 8) == 0 && d->gather == GWD_GATHER_CONV) {
                 const dim3 g(((M + 63) / 64) * ((N + 63) / 64));
-                igemm_dma_kernel<64, 64, 2, 2, 4, 0, true><<<g, 256, 0, s>>>(*d, 0, (int)g.x);
+                if (!d->z && d->act == GWD_ACT_NONE) igemm_dma_kernel<64, 64, 2, 2, 4, 0, true, false, false, 0><<<g, 256, 0, s>>>(*d, 0, (int)g.x);
+                else if (!d->z && d->act == GWD_ACT_RELU) igemm_dma_kernel<64, 64, 2, 2, 4, 0, true, false, false, 1><<<g, 256, 0, s>>>(*d, 0, (int)g.x);
+                else igemm_dma_kernel<64, 64, 2, 2, 4, 0, true><<<g, 256, 0, s>>>(*d, 0, (int)g.x);
                 GWD_CHECK_LAUNCH();
                 return 0;
             }

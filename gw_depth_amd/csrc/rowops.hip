@@ -600,10 +600,12 @@ __global__ void act_bwd_vec_kernel(const T *__restrict__ gy, const T *__restrict
 
 // Activation backward and the bias gradient in one pass: gx = act'(ref) * gy (16-byte vectors), and the column sums
 // of gx (= dBias of the layer) accumulated in registers, reduced through LDS, one atomic per channel per workgroup.
-template <typename T>
+// ACTK: the activation as a compile-time constant (none / ReLU / GELU), -1 = the run-time switch
+template <typename T, int ACTK = -1>
 __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const T *__restrict__ gy, const T *__restrict__ ref, T *__restrict__ gx,
-                                                             float *__restrict__ dbias, int64_t rows, int C, int act, float act_scale,
+                                                             float *__restrict__ dbias, int64_t rows, int C, int act_rt, float act_scale,
                                                              const T *__restrict__ mult) {
+    const int act = ACTK < 0 ? act_rt : ACTK;
     constexpr int VEC = VecOf<T>::N;
     __shared__ float red[256 * VEC];
     const int vpr = C / VEC, rpb = 256 / vpr;
@@ -911,9 +913,14 @@ extern "C" int gwd_act_backward_colsum(const void *gy, const void *ref, void *gx
     const int rpb = 256 / (C / vec);
     int64_t nb = (rows + (int64_t)rpb * 8 - 1) / ((int64_t)rpb * 8);
     const int grid = (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
-    if (dtype == GWD_BF16)
-        act_bwd_colsum_kernel<__bf16><<<grid, 256, 0, s>>>((const __bf16 *)gy, (const __bf16 *)ref, (__bf16 *)gx, dbias, rows, C, act, act_scale, (const __bf16 *)mult);
-    else
+    if (dtype == GWD_BF16) {
+#define ABC(K_) act_bwd_colsum_kernel<__bf16, K_><<<grid, 256, 0, s>>>((const __bf16 *)gy, (const __bf16 *)ref, (__bf16 *)gx, dbias, rows, C, act, act_scale, (const __bf16 *)mult)
+        if (act == GWD_ACT_NONE) ABC(GWD_ACT_NONE);
+        else if (act == GWD_ACT_RELU) ABC(GWD_ACT_RELU);
+        else if (act == GWD_ACT_GELU) ABC(GWD_ACT_GELU);
+        else ABC(-1);
+#undef ABC
+    } else
         act_bwd_colsum_kernel<float><<<grid, 256, 0, s>>>((const float *)gy, (const float *)ref, (float *)gx, dbias, rows, C, act, act_scale, (const float *)mult);
     GWD_CHECK_LAUNCH();
     return 0;
