@@ -585,7 +585,7 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
 
     // ---- epilogue (identical to igemm_fwd_kernel's vector path; N % 8 == 0 is a launch precondition)
     T *y = (T *)d.y;
-    T *z = ACTK >= 0 ? nullptr : (T *)d.z;
+    T *z = (ACTK == 0 || ACTK == 1) ? nullptr : (T *)d.z;       // ACTK 2 = GELU keeps the pre-activation copy its backward needs
     const T *res = (const T *)d.residual;
     const T *mul = MULT ? (const T *)d.mult : nullptr;       // compile-time: the multiplier path costs the plain kernels registers
     const T *gate = (GATE && !MULT) ? (const T *)d.gate : nullptr;      // never together with a multiplier (check_desc)
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
                         }
 #pragma unroll
                         for (int e = 0; e < 8; ++e)
-                            out[e] = (__bf16)((ACTK == 0 ? v[e] : (ACTK == 1 ? (v[e] > 0.f ? v[e] : 0.f) : apply_act(v[e], d.act))) * gm[e]);
+                            out[e] = (__bf16)((ACTK == 0 ? v[e] : (ACTK == 1 ? (v[e] > 0.f ? v[e] : 0.f) : (ACTK == 2 ? gelu_f(v[e]) : apply_act(v[e], d.act)))) * gm[e]);
                     }
                     *(bf16x8 *)(y + o) = out;
                 }
@@ -1478,7 +1478,7 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         // Cin = 8 (mod 32) multiples such as the 80-channel pyramid: the LDS-DMA kernels with a zero-page channel tail (big maps, the two
         // hot tile shapes, plain and stride-1 transposed gathers) instead of the register-staged kernel (112-166 us per launch)
-        const int actk = d->z ? -1 : (d->act == GWD_ACT_NONE ? 0 : (d->act == GWD_ACT_RELU ? 1 : -1));
+        const int actk = d->act == GWD_ACT_GELU ? 2 : (d->z ? -1 : (d->act == GWD_ACT_NONE ? 0 : (d->act == GWD_ACT_RELU ? 1 : -1)));
         const bool lean = actk == 0;
         if (dma_enabled() && tail_enabled() && !d->gate && d->zero_page && (d->Cin % 32) != 0 && (d->Cin % 8) == 0 && d->Cin > 32 && (N % 8) == 0 && M >= 256 * 512 &&
             (d->gather == GWD_GATHER_CONV || (d->gather == GWD_GATHER_TRANSPOSED && d->stride == 1))) {
@@ -1519,6 +1519,7 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
     if (BN_ % 160 != 0 && d->gate) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, (BN_ % 160 != 0), 0) }         \
     else if (actk == 0) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, 0) }                               \
     else if (actk == 1 && BN_ % 160 != 0) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, (BN_ % 160 != 0 ? 1 : -1)) } \
+    else if (actk == 2 && BN_ % 160 != 0) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, (BN_ % 160 != 0 ? 2 : -1)) } \
     else { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, -1) }
             const bool big = big_tiles_enabled() && M >= 256 * 512;      // >= 2 workgroups per CU with 256-row tiles
             const unsigned gm2 = (M + 255) / 256;
