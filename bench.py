@@ -348,7 +348,7 @@ def dominant_kernel_roofline(lib, dtype):
     except (OSError, KeyError, ValueError):
         pass
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "traffic": traffic, "kernel": "igemm_dma_kernel<256,160,8,1,3,0> (%s) conv3x3 160->160 @ 8x120x160" % ("bf16" if dtype == torch.bfloat16 else "f32"),
+            "traffic": traffic, "kernel": "igemm_dma_kernel<256,160,8,1,3,0,false,false,false,0> (%s) conv3x3 160->160 @ 8x120x160" % ("bf16" if dtype == torch.bfloat16 else "f32"),
             "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(flops / 1e9, 2)}
 
 
