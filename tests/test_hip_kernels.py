@@ -1215,3 +1215,37 @@ def test_long_reduction_gemm_split_over_waves(dev, case, monkeypatch):
     assert rel(got, want) < TOL[dt]
     if zg is not None:
         assert rel(zg, zw) < TOL[dt]
+
+
+ACTK_TILES = [
+    # rows, K, N -> tile family of the LDS-DMA dispatcher
+    (131072, 64, 128),      # 256 x 128 (big)
+    (131072, 32, 160),      # 256 x 160 (big, 160-wide: activation-free variant or the run-time switch only)
+    (40000, 64, 128),       # 128 x 128
+    (9600, 64, 256),        # 64 x 64 quarter tiles
+    (40000, 128, 64),       # 128 x 64
+    (40000, 64, 32),        # 128 x 32
+]
+
+
+@pytest.mark.parametrize("act", [hip.ACT_NONE, hip.ACT_RELU, hip.ACT_GELU, hip.ACT_ELU, hip.ACT_SIGMOID])
+@pytest.mark.parametrize("tile", ACTK_TILES, ids=["%dx%dx%d" % t for t in ACTK_TILES])
+def test_compile_time_activation_variants_of_every_tile_family(dev, tile, act):
+    """igemm_dma_kernel<..., ACTK>: none / ReLU / GELU (+ pre-activation copy) as compile-time epilogues, ELU / sigmoid through the
+    run-time switch - every tile family the dispatcher can pick, plain and transposed gather, with shift and skip."""
+    M, K, N = tile
+    dt = torch.bfloat16
+    x, w = rnd(M, 1, 1, K, dtype=dt, seed=1), rnd(N, 1, 1, K, dtype=dt, seed=2, scale=K ** -0.5)
+    shift, res = rnd(N, seed=3) * 0.3, rnd(M, 1, 1, N, dtype=dt, seed=4)
+    dims = (M, 1, 1, K, 1, 1, N, 1, 1)
+    for gather in (hip.GATHER_CONV, hip.GATHER_TRANSPOSED):
+        want = torch.empty(M, 1, 1, N)
+        zw = torch.empty(M, 1, 1, N) if act == hip.ACT_GELU else None
+        FakeDevice().conv_forward(x, w, want, dims, z=zw, shift=shift, residual=res, act=act, gather=gather)
+        got = torch.empty(M, 1, 1, N, dtype=dt, device="cuda")
+        zg = torch.empty(M, 1, 1, N, dtype=dt, device="cuda") if zw is not None else None
+        dev.conv_forward(x.cuda(), w.cuda(), got, dims, z=zg, shift=shift.cuda(), residual=res.cuda(), act=act, gather=gather)
+        torch.cuda.synchronize()
+        assert rel(got, want) < TOL[dt], gather
+        if zg is not None:
+            assert rel(zg, zw) < TOL[dt], gather
