@@ -29,15 +29,15 @@ __device__ __forceinline__ void load_x_tile(char *xs, const __bf16 *x, int b, in
 template <int NO>
 __global__ __launch_bounds__(256) void thin_fwd_kernel(const gwd_conv_desc d) {
     __shared__ __attribute__((aligned(16))) char xs[HALO * HALO * PIX];
-    __shared__ __attribute__((aligned(16))) float ws[NO * 9 * C];
     const int H = d.Hi, W = d.Wi;
     const int tw = (W + TILE - 1) / TILE, th = (H + TILE - 1) / TILE;
     int t = blockIdx.x;
     const int w0 = (t % tw) * TILE;
     t /= tw;
     const int h0 = (t % th) * TILE, b = t / th;
-    const __bf16 *wgt = (const __bf16 *)d.w;
-    for (int i = threadIdx.x; i < NO * 9 * C; i += 256) ws[i] = (float)wgt[i];
+    // the 9 x 32 x NO weights are wave-uniform: read through the scalar cache as packed bf16 pairs (one dword = channels 2j, 2j + 1)
+    // and used as SGPR operands - as fp32 copies in LDS they were 2/3 (NO = 1) to 4/5 (NO = 2) of the kernel's LDS traffic
+    const uint32_t *__restrict__ wq = (const uint32_t *)d.w;
     load_x_tile(xs, (const __bf16 *)d.x, b, h0, w0, H, W, 256);
     __syncthreads();
     const int ty = threadIdx.x / TILE, tx = threadIdx.x % TILE;
@@ -54,10 +54,12 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(const gwd_conv_desc d) {
             const bf16x8 xv = *(const bf16x8 *)(px + v * 16);
 #pragma unroll
             for (int n = 0; n < NO; ++n) {
-                const float *wp = ws + (n * 9 + tap) * C + v * 8;
-                const f32x4 w0v = *(const f32x4 *)wp, w1v = *(const f32x4 *)(wp + 4);
-                acc[n] += (float)xv[0] * w0v[0] + (float)xv[1] * w0v[1] + (float)xv[2] * w0v[2] + (float)xv[3] * w0v[3] +
-                          (float)xv[4] * w1v[0] + (float)xv[5] * w1v[1] + (float)xv[6] * w1v[2] + (float)xv[7] * w1v[3];
+                const uint32_t *wp = wq + ((n * 9 + tap) * C + v * 8) / 2;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t pr = wp[j];
+                    acc[n] += (float)xv[2 * j] * __builtin_bit_cast(float, pr << 16) + (float)xv[2 * j + 1] * __builtin_bit_cast(float, pr & 0xffff0000u);
+                }
             }
         }
     }
