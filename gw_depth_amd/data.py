@@ -168,7 +168,8 @@ def device_resize_nearest(mat, size, hflip=False, vflip=False):
     return out
 
 
-# --- the same transforms on the line targets (host tensors, a few dozen rows): the reference's arithmetic, line for line ---------
+# --- the same transforms on the line targets (host tensors, a few dozen rows); pinned by tests/golden/line_transforms.npz, which
+# oracle/make_golden_lines.py produces with the reference's own crop / hflip / vflip / resize / Normalize ---------------------------
 def hflip_lines(lines, w):
     """transforms_depth.py:218-222: end points swapped, x -> w - x."""
     return lines[:, [2, 3, 0, 1]] * torch.as_tensor([-1.0, 1.0, -1.0, 1.0]) + torch.as_tensor([float(w), 0.0, float(w), 0.0])
@@ -203,48 +204,168 @@ def resize_lines(lines, w, h, ow, oh):
     return lines * torch.as_tensor([rw, rh, rw, rh])
 
 
+# crop(): the eight clipping rules in the order the reference applies them (transforms_depth.py:95-121).  Each rule moves ONE end
+# point P of a line onto a window edge and slides it along the line through the other end point Q:
+#   (P, axis, edge): when P[axis] is beyond that edge, P[axis] = edge and the other coordinate of P follows from Q and the slope
+#   (x-rule: P.y = Q.y + (P.x - Q.x) * slope;  y-rule: P.x = Q.x + (P.y - Q.y) / slope - the reference writes rules 2 and 6 as
+#   Q.x - (Q.y - P.y) / slope, the same fp32 value: negation is exact and commutes with the division).
+_CLIP_RULES = ((0, 0, "lo"), (0, 1, "lo"), (1, 0, "hi"), (1, 1, "hi"), (1, 0, "lo"), (1, 1, "lo"), (0, 0, "hi"), (0, 1, "hi"))
+
+
 def crop_lines(lines, region):
-    """transforms_depth.py:59-128: shift into the crop window (i, j, h, w), drop lines wholly outside, clip the rest to the window
-    edge by edge along their slope, clamp.  Returns (lines, keep mask)."""
+    """Line targets under a crop window (i, j, h, w), transforms_depth.py:59-128: shift into the window, drop the lines that lie
+    wholly beyond one edge, clip the others edge by edge along their slope (the rule table above, all lines at once), clamp.
+    Returns (lines (m,4), keep mask over the input rows).  Pinned by tests/golden/line_transforms.npz (the reference's own crop)."""
     i, j, h, w = region
-    cl = lines - torch.as_tensor([j, i, j, i], dtype=lines.dtype)
-    rx = torch.logical_or(torch.logical_and(cl[:, 0] < 0, cl[:, 2] < 0), torch.logical_and(cl[:, 0] > w, cl[:, 2] > w))
-    ry = torch.logical_or(torch.logical_and(cl[:, 1] < 0, cl[:, 3] < 0), torch.logical_and(cl[:, 1] > h, cl[:, 3] > h))
-    keep = torch.logical_and(~rx, ~ry)
-    cl = cl[keep]
-    out = torch.zeros_like(cl)
-    eps = 1e-12
-    for n, line in enumerate(cl):
-        x1, y1, x2, y2 = line
-        slope = (y2 - y1) / (x2 - x1 + eps)
-        if x1 < 0:
-            x1 = 0
-            y1 = y2 + (x1 - x2) * slope
-        if y1 < 0:
-            y1 = 0
-            x1 = x2 - (y2 - y1) / slope
-        if x2 > w:
-            x2 = w
-            y2 = y1 + (x2 - x1) * slope
-        if y2 > h:
-            y2 = h
-            x2 = x1 + (y2 - y1) / slope
-        if x2 < 0:
-            x2 = 0
-            y2 = y1 + (x2 - x1) * slope
-        if y2 < 0:
-            y2 = 0
-            x2 = x1 - (y1 - y2) / slope
-        if x1 > w:
-            x1 = w
-            y1 = y2 + (x1 - x2) * slope
-        if y1 > h:
-            y1 = h
-            x1 = x2 + (y1 - y2) / slope
-        out[n, :] = torch.tensor([x1, y1, x2, y2])
-    out[:, 0::2].clamp_(min=0, max=w)
-    out[:, 1::2].clamp_(min=0, max=h)
-    return out, keep
+    shifted = lines - torch.as_tensor([j, i, j, i], dtype=lines.dtype)
+    pts = shifted.view(-1, 2, 2)                                     # (line, end point, axis)
+    hi = torch.as_tensor([w, h], dtype=lines.dtype)
+    beyond = ((pts < 0).all(dim=1) | (pts > hi).all(dim=1)).any(dim=1)         # both end points past the same edge, on either axis
+    keep = ~beyond
+    p = pts[keep].clone()
+    slope = (p[:, 1, 1] - p[:, 0, 1]) / (p[:, 1, 0] - p[:, 0, 0] + 1e-12)
+    # The reference assigns the window edge as a Python int; where BOTH coordinates of a y-rule's difference are such edge values the
+    # quotient is `int / tensor`, which torch evaluates as tensor.reciprocal() * int - one rounding more than a division.  `on_edge`
+    # tracks which coordinates are edge values so that the result is the reference's to the last bit.
+    on_edge = torch.zeros(p.shape, dtype=torch.bool)
+    for end, axis, side in _CLIP_RULES:
+        edge = 0.0 if side == "lo" else float(hi[axis])
+        coord = p[:, end, axis]
+        hit = coord < 0 if side == "lo" else coord > edge
+        moved = torch.where(hit, torch.full_like(coord, edge), coord)
+        delta = moved - p[:, 1 - end, axis]
+        if axis == 0:
+            step = delta * slope
+        else:
+            step = torch.where(on_edge[:, 1 - end, axis], delta * (1.0 / slope), delta / slope)
+        p[:, end, 1 - axis] = torch.where(hit, p[:, 1 - end, 1 - axis] + step, p[:, end, 1 - axis])
+        p[:, end, axis] = moved
+        on_edge[:, end, axis] |= hit
+        on_edge[:, end, 1 - axis] &= ~hit                           # re-computed along the slope: a tensor value again
+    p = torch.minimum(torch.maximum(p, torch.zeros_like(hi)), hi)
+    return p.reshape(-1, 4), keep
+
+
+def chain_points(poly_lines):
+    """The vertex list the reference averages for a polygon's centre: both end points of the first line, then the END point of
+    every further line - for a closed polygon the first vertex therefore counts twice (transforms_depth.py:150,
+    glassrgbd_norhint.py:180-181).  (m,4) -> (m+1, 2)."""
+    return torch.cat([poly_lines[0].view(2, 2), poly_lines[1:, 2:]], 0)
+
+
+def _clip_polygon(pts, x0, y0, x1, y1):
+    """Sutherland-Hodgman clip of a polygon (list of (x, y)) against an axis-aligned window."""
+    def clip(points, inside, cross):
+        out = []
+        for k, cur in enumerate(points):
+            prev = points[k - 1]
+            if inside(cur):
+                if not inside(prev):
+                    out.append(cross(prev, cur))
+                out.append(cur)
+            elif inside(prev):
+                out.append(cross(prev, cur))
+        return out
+
+    def at_x(x):
+        return lambda a, b: (x, a[1] + (b[1] - a[1]) * (x - a[0]) / (b[0] - a[0]))
+
+    def at_y(y):
+        return lambda a, b: (a[0] + (b[0] - a[0]) * (y - a[1]) / (b[1] - a[1]), y)
+
+    for inside, cross in ((lambda q: q[0] >= x0, at_x(x0)), (lambda q: q[0] <= x1, at_x(x1)),
+                          (lambda q: q[1] >= y0, at_y(y0)), (lambda q: q[1] <= y1, at_y(y1))):
+        if not pts:
+            break
+        pts = clip(pts, inside, cross)
+    return pts
+
+
+def crop_targets(lines, poly_ids, centres, region):
+    """crop() on the whole target (transforms_depth.py:59-186): clipped lines, surviving polygon ids and the re-computed polygon
+    centres.  A polygon that keeps more than three lines gets the mean of its clipped chain's vertices (chain_points; pinned by the
+    reference's own crop through tests/golden/line_transforms.npz).  One that keeps three or fewer gets the vertex mean of
+    (window INTERSECT original polygon), for which the reference calls shapely (absent here and unpinned by the reference): the
+    intersection is restated as a Sutherland-Hodgman clip with the ring closed the way shapely's `exterior.coords` closes it
+    (first vertex repeated), the vertex ORDER GEOS would emit is not reproducible without it - that branch is parity-unpinned."""
+    i, j, h, w = region
+    out, keep = crop_lines(lines, region)
+    ids = poly_ids[keep]
+    if centres is None:
+        return out, ids, None, keep
+    flipped = bool(lines.shape[0] > 1 and lines[0, 0] == lines[1, 2] and lines[0, 1] == lines[1, 3])      # :139-141
+    new_c = torch.zeros((out.shape[0], 2), dtype=centres.dtype)
+
+    def chain(pl):
+        return chain_points(pl.view(-1, 2, 2).flip(1).reshape(-1, 4) if flipped else pl)
+
+    for pid in torch.unique(ids):
+        sel = ids == pid
+        if int(sel.sum()) > 3:
+            new_c[sel] = chain(out[sel]).mean(0)
+            continue
+        ring = _clip_polygon([tuple(q) for q in chain(lines[poly_ids == pid]).tolist()], j, i, j + w - 1, i + h - 1)
+        if len(ring) >= 3:
+            ring = ring + [ring[0]]
+            c = torch.tensor([sum(q[0] for q in ring) / len(ring) - j, sum(q[1] for q in ring) / len(ring) - i], dtype=centres.dtype)
+            new_c[sel] = torch.minimum(torch.maximum(c, torch.zeros(2)), torch.tensor([float(w), float(h)]))
+        else:
+            pl = out[sel]                                            # the reference flips an already flipped chain back here (:165-167)
+            new_c[sel] = chain_points(pl).mean(0)
+    return out, ids, new_c, keep
+
+
+def normalize_lines(lines, w, h, centres=None):
+    """Normalize.__call__ on the targets (transforms_depth.py:632-641): pixel coordinates -> fractions of the final image size."""
+    lines = lines / torch.tensor([w, h, w, h], dtype=torch.float32)
+    if centres is None:
+        return lines
+    return lines, centres / torch.tensor([w, h], dtype=torch.float32)
+
+
+def polygon_lines(shapes):
+    """generate_line_labels (glassrgbd_norhint.py:161-193): every labelled polygon (a dict with 'points' and 'poly_id') becomes the
+    closed chain of its edges; returns (lines (n,4), poly_ids (n,), centres (n,2)) as float64 / int64 numpy arrays, the centre of
+    a polygon being the mean of chain_points (first vertex counted twice)."""
+    import numpy as np
+    lines, ids, centres = [], [], []
+    for poly in shapes:
+        pts = np.asarray(poly["points"], dtype=np.float64)
+        if len(pts) == 0:
+            continue
+        edges = np.concatenate([pts, np.roll(pts, -1, axis=0)], axis=1)           # (x1, y1, x2, y2), the last edge closes the ring
+        chain = np.concatenate([pts, pts[:1]], axis=0)
+        c = (sum(chain[:, 0].tolist()) / len(chain), sum(chain[:, 1].tolist()) / len(chain))
+        lines += edges.tolist()
+        ids += [poly["poly_id"]] * len(edges)
+        centres += [c] * len(edges)
+    return np.array(lines), np.array(ids), centres
+
+
+def assemble_item(rgb, depth_mm, labels, shapes, image_id, with_center=True, params=None, mean=MEAN, std=STD):
+    """One dataset item from DECODED arrays - DataLoadPreprocess.__getitem__ without the file handling
+    (glassrgbd_norhint.py:236-299 with ConvertLinePolysToMask :121-148): polygon JSON -> line targets (clamped to the frame),
+    the transform chain on the device (DeviceAugment.apply with `params`, None = no geometric / photometric step), then the
+    per-item tail (lines / centres as fractions of the final size, centres appended to the lines under --with_center).  The
+    pixel tail (ToTensor + Normalize, depth / 1000, label > 0) is NOT applied here: device_collate does it for the whole batch in
+    one launch.  rgb uint8 (h,w,3), depth_mm integer (h,w), labels uint8 (h,w): device tensors.
+    Returns (rgb, depth_mm, labels, target) with target = {lines, labels, poly_ids, image_id, orig_size, size}."""
+    h, w = int(rgb.shape[0]), int(rgb.shape[1])
+    ln, ids, cs = polygon_lines(shapes)
+    lines = torch.as_tensor(ln, dtype=torch.float32).reshape(-1, 4)
+    centres = torch.as_tensor(cs, dtype=torch.float32).reshape(-1, 2)
+    ids = torch.as_tensor(ids, dtype=torch.int64).reshape(-1)
+    if len(lines) > 0:
+        lines = torch.minimum(torch.maximum(lines, torch.zeros(4)), torch.tensor([w, h, w, h], dtype=torch.float32))
+        centres = torch.minimum(torch.maximum(centres, torch.zeros(2)), torch.tensor([w, h], dtype=torch.float32))
+    if params is not None:
+        rgb, depth_mm, labels, lines, ids, centres = DeviceAugment.apply(rgb, depth_mm, labels, lines, params, poly_ids=ids, centres=centres)
+    fh, fw = int(rgb.shape[0]), int(rgb.shape[1])
+    lines, centres = normalize_lines(lines, fw, fh, centres)
+    target = {"lines": torch.cat([lines, centres], dim=1) if with_center else lines,
+              "labels": torch.zeros(lines.shape[0], dtype=torch.int64), "poly_ids": ids,
+              "image_id": torch.tensor([image_id]), "orig_size": torch.as_tensor([h, w]), "size": torch.as_tensor([fh, fw])}
+    return rgb, depth_mm, labels, target
 
 
 class DeviceAugment:
@@ -276,17 +397,25 @@ class DeviceAugment:
         return {"flip": flip, "steps": steps, "jitter": jitter_params(r)}          # T.ColorJitter() with its defaults (coco.py:107)
 
     @staticmethod
-    def apply(rgb, depth_mm, labels, lines, p):
+    def apply(rgb, depth_mm, labels, lines, p, poly_ids=None, centres=None):
         """rgb uint8 (h,w,3), depth_mm int32 (h,w), labels uint8 (h,w) device tensors, lines (n,4) host fp32 in pixels.
-        Returns the transformed (rgb, depth_mm, labels, lines [still in pixels], keep mask over the input lines)."""
+        Returns the transformed (rgb, depth_mm, labels, lines [still in pixels], keep mask over the input lines); with poly_ids
+        (n,) and centres (n,2) - the polygon bookkeeping of the dataset's targets - (rgb, depth_mm, labels, lines, poly_ids, centres)."""
         h, w = rgb.shape[:2]
         hf, vf = p["flip"] == "h", p["flip"] == "v"
         lines = lines.clone().float()
         keep = torch.ones(lines.shape[0], dtype=torch.bool)
+        full = poly_ids is not None
+        if full:
+            poly_ids, centres = poly_ids.clone(), centres.clone().float()
         if hf:
             lines = hflip_lines(lines, w)
+            if full:                                                # transforms_depth.py:223-225
+                centres = centres * torch.as_tensor([-1.0, 1.0]) + torch.as_tensor([float(w), 0.0])
         if vf:
             lines = vflip_lines(lines, h)
+            if full:                                                # :251-253
+                centres = centres * torch.as_tensor([1.0, -1.0]) + torch.as_tensor([0.0, float(h)])
         first = True
         for step in p["steps"]:
             if step[0] == "resize":
@@ -296,6 +425,8 @@ class DeviceAugment:
                 depth_mm = device_resize_nearest(depth_mm, (oh, ow), *f) if depth_mm is not None else None
                 labels = device_resize_nearest(labels, (oh, ow), *f) if labels is not None else None
                 lines = resize_lines(lines, w, h, ow, oh)
+                if full:                                            # :356-357
+                    centres = centres * torch.as_tensor([float(ow) / float(w), float(oh) / float(h)])
                 h, w = oh, ow
                 first = False
             else:
@@ -303,7 +434,10 @@ class DeviceAugment:
                 rgb = rgb[i:i + ch, j:j + cw]                       # window views: the next resize reads them in place
                 depth_mm = depth_mm[i:i + ch, j:j + cw] if depth_mm is not None else None
                 labels = labels[i:i + ch, j:j + cw] if labels is not None else None
-                lines, k = crop_lines(lines, step[1])
+                if full:
+                    lines, poly_ids, centres, k = crop_targets(lines, poly_ids, centres, step[1])
+                else:
+                    lines, k = crop_lines(lines, step[1])
                 idx = torch.nonzero(keep).flatten()
                 keep = torch.zeros_like(keep)
                 keep[idx[k]] = True
@@ -314,7 +448,12 @@ class DeviceAugment:
             labels = device_resize_nearest(labels, (h, w), hf, vf) if labels is not None else None
         if p.get("jitter"):
             rgb = device_color_jitter(rgb, p["jitter"])
-        return rgb.contiguous(), None if depth_mm is None else depth_mm.contiguous(), None if labels is None else labels.contiguous(), lines, keep
+        rgb = rgb.contiguous()
+        depth_mm = None if depth_mm is None else depth_mm.contiguous()
+        labels = None if labels is None else labels.contiguous()
+        if full:
+            return rgb, depth_mm, labels, lines, poly_ids, centres
+        return rgb, depth_mm, labels, lines, keep
 
 
 # --- third slice: the photometric jitter (transforms_depth.py:551-600) ------------------------------------------------------------

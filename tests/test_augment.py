@@ -241,3 +241,109 @@ def test_device_colour_jitter_bit_exact(cgold):
     for name, f in ops:
         want = fn[name](want, f)
     np.testing.assert_array_equal(data.device_color_jitter(torch.from_numpy(img).cuda(), ops).cpu().numpy(), want)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Target arithmetic against the reference's OWN crop / hflip / vflip / resize / Normalize and dataset item assembly
+# (tests/golden/line_transforms.npz, made by oracle/make_golden_lines.py from /root/reference/src/datasets/transforms_depth.py and
+# glassrgbd_norhint.py).  Host tensors only: runs without a GPU.
+def _golden_lines():
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "line_transforms.npz"))
+    return z, [str(n) for n in z["names"]]
+
+
+def _apply_op(lines, ids, w, h, op, arg):
+    if op == "crop":
+        lines, ids, _, _ = data.crop_targets(lines, ids, None, arg)
+        return lines, ids, arg[3], arg[2]
+    if op == "hflip":
+        return data.hflip_lines(lines, w), ids, w, h
+    if op == "vflip":
+        return data.vflip_lines(lines, h), ids, w, h
+    if op == "resize":
+        oh, ow = data.resized_shape(w, h, arg[0], arg[1])
+        return data.resize_lines(lines, w, h, ow, oh), ids, ow, oh
+    assert op == "normalize"
+    return data.normalize_lines(lines, w, h), ids, w, h
+
+
+def test_line_targets_equal_the_references_transforms_bit_for_bit():
+    from oracle import make_golden_lines as G            # the case table (inputs + operations); the expected values come from the fixture
+    z, names = _golden_lines()
+    seen = 0
+    for name, w, h, lines, ids, op, arg in G.line_cases():
+        assert name in names
+        assert np.array_equal(z[name + "_in"], lines.numpy())
+        cur, cid, cw, ch = lines.clone(), ids.clone(), w, h
+        for o, a in (arg if op == "chain" else [(op, arg)]):
+            cur, cid, cw, ch = _apply_op(cur, cid, cw, ch, o, a)
+        want = z[name + "_out"]
+        assert cur.shape == want.shape, name
+        assert np.array_equal(cur.numpy(), want, equal_nan=True), (name, np.abs(cur.numpy() - want).max())
+        assert np.array_equal(cid.numpy(), z[name + "_ids_out"]), name
+        assert [w, h, cw, ch] == z[name + "_size"].tolist(), name
+        seen += 1
+    assert seen >= 18
+    # every clipping rule fired somewhere: a crop that moves each of the four coordinates to each of its two edges
+    moved = set()
+    for k in range(7):
+        i, j, hh, ww = G.line_cases()[k][6]
+        out = z["crop%d_out" % k]
+        for c, edge in ((0, 0.0), (0, float(ww)), (1, 0.0), (1, float(hh)), (2, 0.0), (2, float(ww)), (3, 0.0), (3, float(hh))):
+            if (out[:, c] == edge).any():
+                moved.add((c, edge > 0))
+    assert len(moved) == 8
+
+
+def test_polygon_centres_follow_the_references_crop():
+    from oracle import make_golden_lines as G
+    z, names = _golden_lines()
+    for name, w, h, lines, ids, centres, region, flipped in G.centre_cases():
+        cur, cid, cc = lines.clone(), ids.clone(), centres.clone()
+        if flipped:
+            cur = data.hflip_lines(cur, w)
+            cc = cc * torch.as_tensor([-1.0, 1.0]) + torch.as_tensor([float(w), 0.0])
+            assert np.array_equal(cur.numpy(), z[name + "_flipped_in"]) and np.array_equal(cc.numpy(), z[name + "_flipped_centres"])
+        cur, cid, cc, _ = data.crop_targets(cur, cid, cc, region)
+        oh, ow = data.resized_shape(region[3], region[2], 512, 1024)
+        cc = cc * torch.as_tensor([float(ow) / float(region[3]), float(oh) / float(region[2])])
+        cur = data.resize_lines(cur, region[3], region[2], ow, oh)
+        cur, cc = data.normalize_lines(cur, ow, oh, cc)
+        assert np.array_equal(cid.numpy(), z[name + "_ids_out"]), name
+        assert np.array_equal(cur.numpy(), z[name + "_out"]), name
+        assert np.array_equal(cc.numpy(), z[name + "_centres_out"]), (name, cc.numpy(), z[name + "_centres_out"])
+
+
+def test_item_assembly_equals_the_references_dataset_item():
+    """Decoded arrays + polygon JSON -> target dict: the reference's DataLoadPreprocess.__getitem__ (fixture) vs data.assemble_item;
+    the pixel tail is device_collate's (checked against the same item on the CPU stand-in)."""
+    import json
+    z, _ = _golden_lines()
+    shapes = json.loads(str(z["item_shapes"]))
+    rgb, dmm, lab = torch.from_numpy(z["item_rgb"]), torch.from_numpy(z["item_depth_mm"]), torch.from_numpy(z["item_labels"])
+    r2, d2, l2, target = data.assemble_item(rgb, dmm, lab, shapes, 31, with_center=True)
+    assert sorted(target.keys()) == [str(k) for k in z["item_keys"]]
+    for k in ("lines", "labels", "poly_ids", "image_id", "orig_size", "size"):
+        want = z["item_t_" + k]
+        assert target[k].dtype == torch.from_numpy(want).dtype, k
+        assert np.array_equal(target[k].numpy(), want), (k, target[k], want)
+    hip.set_library(FakeDevice())
+    try:
+        batch = data.device_collate([(r2, d2, l2)], device="cpu")
+    finally:
+        hip.set_library(None)
+    assert np.array_equal(batch["images"][0].numpy(), z["item_image"])
+    assert np.array_equal(batch["depth"][0].numpy(), z["item_depth"])
+    assert np.array_equal(batch["seg"][0].numpy(), z["item_seg"])
+
+
+def test_crop_of_a_polygon_that_keeps_three_lines_uses_the_window_intersection():
+    """The shapely branch (parity-unpinned, see data.crop_targets): the centre is the vertex mean of window INTERSECT polygon."""
+    sq = torch.tensor([[10.0, 10.0, 50.0, 10.0], [50.0, 10.0, 50.0, 50.0], [50.0, 50.0, 10.0, 50.0], [10.0, 50.0, 10.0, 10.0]])
+    ids = torch.zeros(4, dtype=torch.int64)
+    centres = torch.full((4, 2), 30.0)
+    lines, pid, cc, keep = data.crop_targets(sq, ids, centres, (0, 30, 100, 100))       # the window cuts the square's left edge away
+    assert keep.tolist() == [True, True, True, False] and pid.tolist() == [0, 0, 0]
+    # intersection = [30, 50] x [10, 50], shifted by the window origin (30, 0): the vertex mean lies inside [0, 20] x [10, 50]
+    assert ((cc[:, 0] > 0) & (cc[:, 0] < 20.0) & (cc[:, 1] > 10.0) & (cc[:, 1] < 50.0)).all()
+    assert torch.equal(cc[0], cc[1]) and torch.equal(cc[1], cc[2])
