@@ -31,6 +31,7 @@ PEAK_MFMA_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-
 PEAK_HBM_GBPS = 8000.0
 STEP_GFLOP_PER_IMAGE = 1049.5      # fwd + losses + bwd, conv/mm/addmm/bmm only
 BACKBONE_GFLOP_PER_IMAGE = 128.4   # 50.05 fwd + 78.33 bwd
+HBM_STEP_FILE = "r02_hbm_step.json"
 
 
 def parse():
@@ -108,8 +109,44 @@ def cpu_baseline(sd_cpu, cfg, budget_s):
         el = time.time() - t0
         if el + el / n > budget_s or n >= 8:
             break
-    return {"value": round(n / el, 4), "unit": "images/s", "cores": cores, "kind": "port",
+    return {"value": round(n / el, 4), "unit": "images/s", "cores": cores, "kind": "port", "batch": 1, "cpu_model": cpu_model(),
             "sample": "%d fp32 train step(s), batch 1, 480x640, oracle/gwdepth_ref.py on %d host threads (%.1f s)" % (n, cores, el)}
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def fp32_leg(sd_cpu, cfg, a, steps=3):
+    """ms per step of the fp32 PARITY mode (the mode that meets north_star's 1e-3 tolerance) on the same workload, beside the timed
+    bf16 number: a fresh model + TrainStep, eager launches, 1 untimed + `steps` timed steps bracketed by synchronize."""
+    from gw_depth_amd import build_model
+    from gw_depth_amd.engine import TrainStep
+    from gw_depth_amd.synth import synth_batch
+    model, crits, _ = build_model(cfg)
+    model.load_state_dict(sd_cpu)
+    model.cuda()
+    crits[0].cuda()
+    step = TrainStep(model, crits, cfg, compute_dtype=torch.float32, graph=False)
+    b = synth_batch(a.batch, a.height, a.width, seed=1)
+    batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    batch["targets"] = [{k: v.cuda() for k, v in t.items()} for t in b["targets"]]
+    step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(batch)
+    torch.cuda.synchronize()
+    ms = 1000 * (time.perf_counter() - t0) / steps
+    return {"ms_per_step": round(ms, 2), "images_per_s": round(a.batch * 1000 / ms, 2), "steps": steps, "launch": "eager",
+            "note": "fp32 parity mode (exact v_mfma_f32_32x32x2_f32), same workload; the mode whose depth RMSE is within 1e-3 of the reference"}
 
 
 def depth_rmse_leg(sd_cpu, cfg, dtype):
@@ -262,21 +299,33 @@ def main():
     if comm is not None:
         out["comm"] = comm
     try:                            # step-level HBM-side traffic: PMC bytes of one step (committed profile) over the measured step time
-        with open(os.path.join(ROOT, "profiles", "r02_hbm_step.json")) as f:
-            hb = json.load(f)["hbm_bytes_per_step"]
+        with open(os.path.join(ROOT, "profiles", HBM_STEP_FILE)) as f:
+            hrec = json.load(f)
+        hb = hrec["hbm_bytes_per_step"]
         if a.batch == 8 and a.height == 480 and a.width == 640 and a.dtype == "bf16":
             gbps = hb / (el / a.steps) / 1e9
             out["hbm"] = {"bytes_per_step_pmc": hb, "achieved_GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / PEAK_HBM_GBPS, 4),
-                          "source": "profiles/r02_hbm_step.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction)"}
+                          "bytes_measured": "%s, commit %s - a committed PMC measurement divided by THIS run's step time" % (hrec.get("measured", "?"), hrec.get("commit", "?")),
+                          "source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction)" % HBM_STEP_FILE}
     except (OSError, KeyError, ValueError):
         pass
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         print("[bench] GPU leg done: %.2f images/s; timing the CPU baseline (oracle) ..." % ips, file=sys.stderr, flush=True)
         out["cpu_baseline"] = cpu_baseline(sd_cpu, cfg, a.cpu_baseline_budget_s)
         out["depth_rmse"] = depth_rmse_leg(sd_cpu, cfg, dtype)
+        if a.dtype == "bf16":
+            try:
+                del step
+                torch.cuda.empty_cache()
+                out["fp32_parity_mode"] = fp32_leg(sd_cpu, cfg, a)
+            except Exception as exc:
+                out["fp32_parity_mode"] = {"error": repr(exc)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        # rank 0's post-timed legs (roofline, in-step trace) run while the other ranks wait HERE: nobody tears the group down under a
+        # rank that may still issue a collective, and a rank that died makes the barrier raise on the others (non-zero exit)
+        dist.barrier()
         dist.destroy_process_group()
 
 
@@ -341,14 +390,17 @@ def dominant_kernel_roofline(lib, dtype):
     flops = 2.0 * B * H * W * 9 * C * C
     ach = flops / (ms * 1e-3) / 1e12
     peak = PEAK_MFMA_BF16_TFLOPS if dtype == torch.bfloat16 else 157.3
-    traffic = None      # HBM bytes per launch from the committed rocprofv3 --pmc passes on this exact launch (profiles/)
-    try:
+    traffic = stamp = None      # HBM bytes per launch from the committed rocprofv3 --pmc passes on this exact launch (profiles/): a
+    try:                        # committed measurement, not taken in this run - stamped with when / at which commit it was made
         with open(os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")) as f:
-            traffic = json.load(f)["traffic_bytes_per_launch"] if dtype == torch.bfloat16 else None
+            rec = json.load(f)
+        if dtype == torch.bfloat16:
+            traffic = rec["traffic_bytes_per_launch"]
+            stamp = "%s, commit %s (profiles/pmc_dominant_kernel.json)" % (rec.get("measured", "?"), rec.get("commit", "?"))
     except (OSError, KeyError, ValueError):
         pass
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "traffic": traffic, "kernel": "igemm_dma_kernel<256,160,8,1,3,0,false,false,false,0> (%s) conv3x3 160->160 @ 8x120x160" % ("bf16" if dtype == torch.bfloat16 else "f32"),
+            "traffic": traffic, "traffic_measured": stamp, "kernel": "igemm_dma_kernel<256,160,8,1,3,0,false,false,false,0> (%s) conv3x3 160->160 @ 8x120x160" % ("bf16" if dtype == torch.bfloat16 else "f32"),
             "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(flops / 1e9, 2)}
 
 

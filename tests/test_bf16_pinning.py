@@ -1,0 +1,141 @@
+"""The TIMED path (bf16 storage, fp32 accumulate; eager and HIP-graph) pinned end to end.
+
+The fp32 golden test (test_gpu_parity.py) cannot see a mis-wired bf16-only route: several kernels exist only in bf16 (stem, every
+MFMA attention kernel, the halo-tile convolutions, the K-split GEMM, the zero-padded 30-point pyramid, the LDS-DMA tail / gate /
+activation variants, the fused ConvLn epilogue).  Here one train step runs twice on the SAME bf16-rounded weights - once in the fp32
+parity mode (itself pinned to the reference's fixtures at 1e-3 / 5e-3 by test_gpu_parity.py), once in bf16 - with the same teacher
+forcing (reference's matcher assignments, top-k ids and sampled points, so that every tensor downstream of an index op sees the
+same operands), and compares
+  * every output and every loss term,
+  * every parameter's gradient: L2 norm and direction (cosine) - a fan-out that drops a branch, a deferred activation gate applied
+    to the wrong tensor, a padded weight gradient folded back onto the wrong slot or a packed in-projection gradient written to the
+    wrong rows changes a norm by tens of percent or turns the direction,
+  * the set of parameters that receive no gradient at all (the reference's list).
+Then the HIP-graph replay of the bf16 step against the eager bf16 step on its own (device) index choices.
+Tolerances are stated where they are applied; bf16 keeps 8 significant bits, a step runs ~150 layers deep."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gw_depth_amd import hip
+from gw_depth_amd.engine import TrainStep
+from gw_depth_amd.synth import synth_batch
+from oracle.make_golden import CASES
+from tests.golden_check import build, rel, to_device
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def real_library():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    hip.set_library(None)
+    assert not getattr(hip.library(), "is_fake", False)
+    yield
+
+
+class ForcedMatcher(torch.nn.Module):
+    """The reference's assignments, whatever this mode's own cost matrix says (bf16 costs tie differently)."""
+
+    def __init__(self, golden):
+        super().__init__()
+        self.golden, self.calls = golden, 0
+
+    def forward(self, outputs, targets):
+        out = [(torch.as_tensor(self.golden[f"match{self.calls}_b{bi}_src"]), torch.as_tensor(self.golden[f"match{self.calls}_b{bi}_tgt"]))
+               for bi in range(len(targets))]
+        self.calls += 1
+        return out
+
+
+def rounded_model(case):
+    cfg, model, crits = build(device="cuda", case=CASES[case])
+    sd = {k: (v.detach().float().bfloat16().float() if v.is_floating_point() else v.detach().clone()) for k, v in model.state_dict().items()}
+    model.load_state_dict(sd, strict=True)
+    return cfg, model, crits
+
+
+def forced_step(case, g, dtype):
+    c = CASES[case]
+    cfg, model, crits = rounded_model(case)
+    b = to_device(synth_batch(c["batch"], c["height"], c["width"], seed=c["seed"], n_lines=c["n_lines"], sizes=c["sizes"]), "cuda")
+    step = TrainStep(model, crits, cfg, compute_dtype=dtype)
+    step.criterion.matcher = ForcedMatcher(g)
+    step.device_matcher = False
+    taps = {"force_points1": torch.as_tensor(g["points1"]).cuda(), "force_points2": torch.as_tensor(g["points2"]).cuda(),
+            "force_topk_ids": torch.as_tensor(g["topk_ids"]).cuda()}
+    out, total, terms = step(b, taps=taps)
+    torch.cuda.synchronize()
+    grads = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.requires_grad}
+    flat = lambda o: {"pred_logits": o["pred_logits"], "pred_lines": o["pred_lines"], "pred_seg": o["pred_seg"],
+                      **{"pred_depth%d" % i: d for i, d in enumerate(o["pred_depth"])},
+                      **{"aux%d_%s" % (i, k): a[k] for i, a in enumerate(o["aux_outputs"]) for k in ("pred_logits", "pred_lines")}}
+    return ({k: v.detach().float().cpu() for k, v in flat(out).items()}, float(total), {k: float(v.detach()) for k, v in terms.items()}, grads)
+
+
+@pytest.mark.parametrize("case", ["tiny_b2_96x128", "mid_b1_224x288"])
+def test_bf16_step_against_the_fp32_parity_mode_on_the_same_rounded_weights(golden_dir, case):
+    g = np.load(os.path.join(golden_dir, case + ".npz"))
+    o32, t32, terms32, g32 = forced_step(case, g, torch.float32)
+    o16, t16, terms16, g16 = forced_step(case, g, torch.bfloat16)
+
+    # outputs: 3e-2 relative (L2 over the tensor); the weights are identical, what differs is bf16 storage of activations
+    worst_out = max((rel(o16[k], o32[k]), k) for k in o32)
+    assert worst_out[0] < 3e-2, worst_out
+    # loss terms: 2e-2 of max(1, |term|)
+    worst_term = max((abs(terms16[k] - terms32[k]) / max(1.0, abs(terms32[k])), k) for k in terms32)
+    assert worst_term[0] < 2e-2, worst_term
+    assert abs(t16 - t32) / abs(t32) < 2e-2
+
+    # the reference's dead-gradient list, in both modes
+    for grads in (g32, g16):
+        dead = sorted(n for n, v in grads.items() if float(v.abs().max()) == 0.0)
+        assert dead == list(g["nograd_names"])
+
+    # per-parameter gradients.  Parameters whose fp32 gradient is below 1e-4 of the largest are rounding noise in either mode
+    # (first-layer biases behind a LayerNorm, saturated sigmoid heads) and are only required to stay small.
+    n32 = {n: float(v.double().norm()) for n, v in g32.items()}
+    top = max(n32.values())
+    bad, checked = [], 0
+    for n, v32 in g32.items():
+        v16 = g16[n]
+        if n32[n] <= 1e-4 * top:
+            assert float(v16.double().norm()) <= 1e-3 * top, n
+            continue
+        checked += 1
+        ratio = float(v16.double().norm()) / n32[n]
+        cos = float((v16.double().flatten() @ v32.double().flatten()) / (v16.double().norm() * v32.double().norm() + 1e-300))
+        if abs(ratio - 1.0) > 0.05 or cos < 0.995:
+            bad.append((n, round(ratio, 4), round(cos, 5), n32[n] / top))
+    print(case, "gradients checked:", checked, "outside 5 % / cos 0.995:", len(bad), "worst output", worst_out, "worst term", worst_term)
+    assert checked > 600
+    assert not bad, bad[:20]
+
+
+def test_bf16_graph_replay_equals_the_eager_bf16_step():
+    """Same weights, same batch, no teacher forcing (the device matcher and CertainSample choose): the captured chain must reproduce
+    the eager step.  Step 1 tightly (loss terms 2e-3, flat gradient 1e-2 in L2: fp32 atomics arrive in a different order, the
+    kernels are the same); step 2 - a replay on the memory the first replay left behind - loosely, because AdamW's first update is
+    ~lr * sign(g) and amplifies that noise in near-zero gradients."""
+    b = to_device(synth_batch(2, 96, 128, seed=41, n_lines=[4, 6]), "cuda")
+    res = []
+    for graph in (False, True):
+        cfg, model, crits = build(device="cuda")
+        step = TrainStep(model, crits, cfg, compute_dtype=torch.bfloat16, graph=graph)
+        rec = []
+        for _ in range(2):
+            out, total, terms = step(b)
+            torch.cuda.synchronize()
+            rec.append((float(total), {k: float(v) for k, v in terms.items()}, step.flat_g.detach().clone()))
+        if graph:
+            assert step._graphs and all(e["graph"] is not None for e in step._graphs.values()), "the bf16 step was not captured"
+        res.append(rec)
+    for i, (term_tol, grad_tol) in enumerate(((2e-3, 1e-2), (2e-2, 5e-2))):
+        (t0, terms0, g0), (t1, terms1, g1) = res[0][i], res[1][i]
+        assert set(terms0) == set(terms1)
+        for k, v in terms0.items():
+            assert abs(v - terms1[k]) <= term_tol * max(1.0, abs(v)), (i, k, v, terms1[k])
+        assert rel(g1, g0) < grad_tol, (i, rel(g1, g0))
