@@ -394,8 +394,22 @@ __device__ __forceinline__ int xcd_band(int id, int total) {
 // layer runs 0.122 -> 0.108 ms (same-box, 3 runs each).  Gated launches are always lean (the dispatcher sends the rest elsewhere).
 // (ACTK: -1 = any activation, decided at run time, + the pre-activation copy; 0 = none = "lean"; 1 = ReLU, a single v_max - the
 // Bottleneck convolutions.)
-template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false, bool TAIL = false, bool GATE = false, int ACTK = -1>
-__global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_desc d, const int tile_base, const int tile_count) {
+template <int BM, int BN, int WM, int WN, int STAGES>
+struct DmaTileCfg {
+    static constexpr int NW = WM * WN;
+    static constexpr int B_INSTR = (BN + 15) / 16;
+    static constexpr int BROWS = B_INSTR * 16;
+    static constexpr int STAGE_BYTES = (BM + BROWS) * 64;
+    static constexpr int EPI_BYTES = NW * 32 * 36 * 4;
+    static constexpr int SMEM = STAGES * STAGE_BYTES > EPI_BYTES ? STAGES * STAGE_BYTES : EPI_BYTES;
+};
+
+// One output tile [m0, m0 + BM) x [n0, n0 + BN).  MINI: only the first `rows` rows of the tile belong to this workgroup (the tail
+// pass of igemm_dma_persist_kernel deals the rows of a half-empty last round out evenly): rows beyond are neither fetched nor
+// stored, and a wave whose rows all lie beyond takes part in the tile traffic and the barriers but skips fragment reads, MFMAs and
+// the epilogue.  Without MINI (`rows` unused) the code is what igemm_dma_kernel always was.
+template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT, bool TAIL, bool GATE, int ACTK, bool MINI>
+__device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, const int m0, const int n0, const int rows, const int tid) {
     typedef __bf16 T;
     constexpr int BK = 32, NW = WM * WN;                 // 4 or 8 waves
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -403,22 +417,13 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
     constexpr int B_INSTR = (BN + 15) / 16;              // wave w issues B instructions w, w+NW, ...
     constexpr int B_IT = (B_INSTR + NW - 1) / NW;
     constexpr int B_FULL = B_INSTR % NW;                 // waves below this index issue B_IT, the others B_IT-1 (0: all B_IT)
-    constexpr int BROWS = B_INSTR * 16;
-    constexpr int STAGE_BYTES = (BM + BROWS) * 64;
-    constexpr int EPI_BYTES = NW * 32 * 36 * 4;
-    constexpr int SMEM = STAGES * STAGE_BYTES > EPI_BYTES ? STAGES * STAGE_BYTES : EPI_BYTES;
+    constexpr int STAGE_BYTES = DmaTileCfg<BM, BN, WM, WN, STAGES>::STAGE_BYTES;
     static_assert((BM / 16) % NW == 0 && TM >= 1 && TN >= 1, "tile / wave layout");
-    __shared__ __attribute__((aligned(1024))) char smem[SMEM];
 
     const int M = d.B * d.Ho * d.Wo, N = d.Cout, K = d.KH * d.KW * d.Cin;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int n_tiles = (N + BN - 1) / BN;
-    // this launch covers tiles tile_base .. tile_base + tile_count - 1 of the logical order.  (Cutting a big problem into a body of
-    // whole rounds of 256-row tiles and a tail of 128-row tiles was measured in round 2: 0.125 -> 0.134 ms on the 160 -> 160
-    // layer, the second launch and the lone waves of the tail cost more than the half-empty round they replace.)
-    const int tile = tile_base + xcd_band(blockIdx.x, tile_count);             // column tiles of a row tile are adjacent
-    const int m0 = (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;
+    const bool active = !MINI || wm * (BM / WM) < rows;  // wave-uniform
     const T *x = (const T *)d.x;
     const T *wgt = (const T *)d.w;
     const char *zero = (const char *)d.zero_page;
@@ -436,7 +441,7 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
         const int row = 16 * (wave * A_IT + i) + (lane >> 2);
         a_ck[i] = ((lane & 3) ^ ((row >> 2) & 3)) * 8;
         const int m = m0 + row;
-        a_ok[i] = m < M;
+        a_ok[i] = MINI ? (row < rows) : (m < M);
         const int mm = a_ok[i] ? m : 0;
         const int b = mm / (d.Ho * d.Wo);
         const int rem = mm - b * (d.Ho * d.Wo);
@@ -579,9 +584,10 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
         }
         __builtin_amdgcn_s_barrier();                     // everybody's part of tile kt landed; compute(kt-1) is finished
         if (kt + STAGES - 1 < KT) issue((kt + STAGES - 1) % STAGES);
-        compute(kt % STAGES);
+        if (active) compute(kt % STAGES);
     }
     __syncthreads();
+    if (!active) return;
 
     // ---- epilogue (identical to igemm_fwd_kernel's vector path; N % 8 == 0 is a launch precondition)
     T *y = (T *)d.y;
@@ -611,7 +617,7 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
                 for (int half = 0; half < 2; ++half) {
                     const int row = vr + 16 * half;
                     const int m = m0 + wm * (BM / WM) + i * 32 + row;
-                    if (m >= M) continue;
+                    if (MINI ? (wm * (BM / WM) + i * 32 + row >= rows) : (m >= M)) continue;
                     const f32x4 lo = *(const f32x4 *)(stage + row * 36 + vc);
                     const f32x4 hi = *(const f32x4 *)(stage + row * 36 + vc + 4);
                     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -656,6 +662,54 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
                 }
             }
         }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false, bool TAIL = false, bool GATE = false, int ACTK = -1>
+__global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_desc d, const int tile_base, const int tile_count) {
+    __shared__ __attribute__((aligned(1024))) char smem[DmaTileCfg<BM, BN, WM, WN, STAGES>::SMEM];
+    const int n_tiles = (d.Cout + BN - 1) / BN;
+    // this launch covers tiles tile_base .. tile_base + tile_count - 1 of the logical order.  (Cutting a big problem into a body of
+    // whole rounds of 256-row tiles and a tail of 128-row tiles was measured in round 2: 0.125 -> 0.134 ms on the 160 -> 160
+    // layer, the second launch and the lone waves of the tail cost more than the half-empty round they replace.)
+    const int tile = tile_base + xcd_band(blockIdx.x, tile_count);             // column tiles of a row tile are adjacent
+    dma_tile<BM, BN, WM, WN, STAGES, GM, MULT, TAIL, GATE, ACTK, false>(d, smem, (tile / n_tiles) * BM, (tile % n_tiles) * BN, BM, (int)threadIdx.x);
+}
+
+// Persistent form for tile counts that leave a mostly empty last round (600 tiles of 256 x 160 on 512 resident workgroup slots: the 88
+// tiles of the second round cost 0.035 of 0.110 ms, a workgroup alone on a CU being no faster than two - DESIGN.md section 4).  The
+// grid is ONE workgroup per slot.  Each runs `rounds` whole tiles (slot, slot + slots, ...), then its share of the remaining rows:
+// they are dealt out `tail_rows` per slot-group (a group = the n_tiles column tiles of one row range), a MINI tile in which only the
+// first ceil(tail_rows / rows per wave row) wave rows compute.  Every output row is still written by exactly one workgroup.
+template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool TAIL, int ACTK>
+__global__ __launch_bounds__(WM *WN * 64) void igemm_dma_persist_kernel(const gwd_conv_desc d, const int rounds, const int tail_m0, const int tail_rows) {
+    __shared__ __attribute__((aligned(1024))) char smem[DmaTileCfg<BM, BN, WM, WN, STAGES>::SMEM];
+    const int M = d.B * d.Ho * d.Wo;
+    const int n_tiles = (d.Cout + BN - 1) / BN;
+    const int slots = (int)gridDim.x, slot = xcd_band(blockIdx.x, slots);
+    // ONE copy of the tile code (a second, specialised copy for the whole tiles cost 33 VGPRs and the second workgroup per CU):
+    // whole tiles are MINI tiles with rows = BM
+#pragma unroll 1
+    for (int r = 0; r <= rounds; ++r) {
+        int m0, n0, rows;
+        if (r < rounds) {
+            const int tile = r * slots + slot;
+            m0 = (tile / n_tiles) * BM;
+            n0 = (tile % n_tiles) * BN;
+            rows = BM;
+        } else {
+            m0 = tail_m0 + (slot / n_tiles) * tail_rows;
+            n0 = (slot % n_tiles) * BN;
+            rows = min(tail_rows, M - m0);
+            if (rows <= 0) break;                         // workgroup-uniform
+        }
+        // the thread index goes through an opaque move every round: everything derived from the lane (fragment addresses, swizzles,
+        // staging slots) would otherwise be hoisted out of this loop and stay live through the K loop - 33 VGPRs, which is the
+        // difference between two workgroups per CU and one
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        dma_tile<BM, BN, WM, WN, STAGES, GM, false, TAIL, false, ACTK, true>(d, smem, m0, n0, rows, tid);
+        __syncthreads();                                  // the epilogue's staging patches are the next tile's ring
     }
 }
 
@@ -1447,6 +1501,42 @@ static bool dma_enabled() {
     return v == 1;
 }
 
+static int persist_enabled() {               // A/B switch (GWD_IGEMM_PERSIST=0: one workgroup per tile, two rounds)
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GWD_IGEMM_PERSIST");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v;
+}
+static int resident_slots_2_per_cu() {
+    static int v = 0;
+    if (!v) {
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
+        v = 2 * cu;
+    }
+    return v;
+}
+
+// 256 x 160 tiles, lean epilogue: when the tile count leaves a last round that is less than 40 % full, run whole rounds + an even split
+// of the remaining rows inside ONE grid of resident workgroups (igemm_dma_persist_kernel).  1 = launched.
+template <int GM, bool TAIL>
+static int launch_persist_256x160(const gwd_conv_desc *d, hipStream_t s) {
+    if (!persist_enabled()) return 0;
+    const int M = d->B * d->Ho * d->Wo, n_tiles = d->Cout / 160;
+    const int slots = resident_slots_2_per_cu();
+    const long total = (long)((M + 255) / 256) * n_tiles;
+    const int rounds = (int)(total / slots), rem = (int)(total % slots);
+    if (rounds < 1 || rem == 0 || rem * 5 > slots * 2 || (rem % n_tiles) || (slots % n_tiles)) return 0;
+    const int tail_m0 = (int)((long)rounds * slots / n_tiles) * 256;
+    const int groups = slots / n_tiles;
+    const int tail_rows = (M - tail_m0 + groups - 1) / groups;
+    if (tail_rows <= 0 || tail_rows > 128) return 0;
+    igemm_dma_persist_kernel<256, 160, 8, 1, 3, GM, TAIL, 0><<<slots, 512, 0, s>>>(*d, rounds, tail_m0, tail_rows);
+    return 1;
+}
+
 template <typename T>
 int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
     const int M = d->B * d->Ho * d->Wo, N = d->Cout;
@@ -1487,7 +1577,8 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
             if (N % 160 == 0) {
                 const dim3 g(gm2 * (N / 160));
                 if (lean) {
-                    if (tr) igemm_dma_kernel<256, 160, 8, 1, 3, 1, false, true, false, 0><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
+                    if (tr ? launch_persist_256x160<1, true>(d, s) : launch_persist_256x160<0, true>(d, s)) {
+                    } else if (tr) igemm_dma_kernel<256, 160, 8, 1, 3, 1, false, true, false, 0><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
                     else igemm_dma_kernel<256, 160, 8, 1, 3, 0, false, true, false, 0><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
                 } else if (tr) igemm_dma_kernel<256, 160, 8, 1, 3, 1, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
                 else igemm_dma_kernel<256, 160, 8, 1, 3, 0, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
@@ -1527,7 +1618,8 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
                 const int var = fwd_variant();
                 if (var == 1) { DMA_LAUNCH(128, 160, 4, 1, 3, dim3(gm * (N / 160))) }
                 else if (var == 2) { DMA_LAUNCH(128, 160, 4, 1, 2, dim3(gm * (N / 160))) }
-                else if (big) { DMA_LAUNCH(256, 160, 8, 1, 3, dim3(gm2 * (N / 160))) } else { DMA_LAUNCH(128, 160, 4, 1, 3, dim3(gm * (N / 160))) }
+                else if (big && actk == 0 && !d->gate && gmk < 2 && (gmk ? launch_persist_256x160<1, false>(d, s) : launch_persist_256x160<0, false>(d, s))) {
+                } else if (big) { DMA_LAUNCH(256, 160, 8, 1, 3, dim3(gm2 * (N / 160))) } else { DMA_LAUNCH(128, 160, 4, 1, 3, dim3(gm * (N / 160))) }
             } else if (N > 64) {
                 const unsigned t128 = gm * ((N + 127) / 128);
                 const int small_thr = small_tile_threshold();

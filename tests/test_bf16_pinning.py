@@ -26,6 +26,8 @@ from oracle.make_golden import CASES
 from tests.golden_check import build, rel, to_device
 
 pytestmark = pytest.mark.gpu
+OUT_TOL = 3e-2
+GRAD_NORM_TOL, GRAD_COS_MIN = 0.05, 0.995
 
 
 @pytest.fixture(autouse=True)
@@ -82,36 +84,40 @@ def test_bf16_step_against_the_fp32_parity_mode_on_the_same_rounded_weights(gold
     o32, t32, terms32, g32 = forced_step(case, g, torch.float32)
     o16, t16, terms16, g16 = forced_step(case, g, torch.bfloat16)
 
-    # outputs: 3e-2 relative (L2 over the tensor); the weights are identical, what differs is bf16 storage of activations
-    worst_out = max((rel(o16[k], o32[k]), k) for k in o32)
-    assert worst_out[0] < 3e-2, worst_out
-    # loss terms: 2e-2 of max(1, |term|)
-    worst_term = max((abs(terms16[k] - terms32[k]) / max(1.0, abs(terms32[k])), k) for k in terms32)
-    assert worst_term[0] < 2e-2, worst_term
-    assert abs(t16 - t32) / abs(t32) < 2e-2
-
-    # the reference's dead-gradient list, in both modes
-    for grads in (g32, g16):
-        dead = sorted(n for n, v in grads.items() if float(v.abs().max()) == 0.0)
-        assert dead == list(g["nograd_names"])
-
+    # ---- measure everything first, print it, then judge
+    devs = sorted(((rel(o16[k], o32[k]), k) for k in o32), reverse=True)
+    term_devs = sorted(((abs(terms16[k] - terms32[k]) / max(1.0, abs(terms32[k])), k) for k in terms32), reverse=True)
     # per-parameter gradients.  Parameters whose fp32 gradient is below 1e-4 of the largest are rounding noise in either mode
     # (first-layer biases behind a LayerNorm, saturated sigmoid heads) and are only required to stay small.
     n32 = {n: float(v.double().norm()) for n, v in g32.items()}
     top = max(n32.values())
-    bad, checked = [], 0
+    bad, small_bad, checked = [], [], 0
     for n, v32 in g32.items():
         v16 = g16[n]
         if n32[n] <= 1e-4 * top:
-            assert float(v16.double().norm()) <= 1e-3 * top, n
+            if float(v16.double().norm()) > 1e-3 * top:
+                small_bad.append(n)
             continue
         checked += 1
         ratio = float(v16.double().norm()) / n32[n]
         cos = float((v16.double().flatten() @ v32.double().flatten()) / (v16.double().norm() * v32.double().norm() + 1e-300))
-        if abs(ratio - 1.0) > 0.05 or cos < 0.995:
+        if abs(ratio - 1.0) > GRAD_NORM_TOL or cos < GRAD_COS_MIN:
             bad.append((n, round(ratio, 4), round(cos, 5), n32[n] / top))
-    print(case, "gradients checked:", checked, "outside 5 % / cos 0.995:", len(bad), "worst output", worst_out, "worst term", worst_term)
-    assert checked > 600
+    print(case, "output deviations:", ["%s %.3g" % (k, v) for v, k in devs])
+    print(case, "loss-term deviations:", ["%s %.3g" % (k, v) for v, k in term_devs[:8]], "total", abs(t16 - t32) / abs(t32))
+    print(case, "gradients checked:", checked, "outside %g / cos %g:" % (GRAD_NORM_TOL, GRAD_COS_MIN), len(bad))
+    print(case, "worst gradient entries (name, norm ratio, cosine, share of the largest norm):", sorted(bad, key=lambda t: t[2])[:16])
+
+    # outputs: relative L2 over the tensor; the weights are identical, what differs is bf16 storage of ~150 layers of activations
+    assert devs[0][0] < OUT_TOL, devs[0]
+    # loss terms: 2e-2 of max(1, |term|)
+    assert term_devs[0][0] < 2e-2, term_devs[0]
+    assert abs(t16 - t32) / abs(t32) < 2e-2
+    # the reference's dead-gradient list, in both modes
+    for grads in (g32, g16):
+        dead = sorted(n for n, v in grads.items() if float(v.abs().max()) == 0.0)
+        assert dead == list(g["nograd_names"])
+    assert checked > 600 and not small_bad, small_bad
     assert not bad, bad[:20]
 
 

@@ -61,9 +61,13 @@ def act_ref(v, act, act_scale):
 # name, (B, Hi, Wi), Cin, Cout, K, stride, pad, upsample_to, extras, tiles the dispatcher picks (documentation)
 CASES = [
     ("pyramid2_layer_160_160_3x3", (8, 120, 160), 160, 160, 3, 1, 1, None, {},
-     "fwd igemm_dma<256,160,8,1,3,0>, dgrad <256,160,..,1>, wgrad_dma<160,128,1,4,3,1>: THE roofline kernel of bench.py"),
+     "fwd igemm_dma_persist<256,160,8,1,3,0> (512 whole tiles + 44 rows per workgroup), dgrad <..,1>, wgrad_dma<160,128,1,4,3,1>: THE roofline kernel of bench.py"),
+    ("persist_ragged_tail_605_tiles", (8, 121, 160), 160, 160, 3, 1, 1, None, {},
+     "igemm_dma_persist_kernel: 605 tiles = one round of 512 + 93 tiles dealt out 47 rows per workgroup, the last groups ragged / empty"),
+    ("persist_short_tail_525_tiles", (7, 120, 160), 160, 160, 3, 1, 1, None, {},
+     "igemm_dma_persist_kernel: 13 tail tiles = 7 rows per workgroup (one active wave row, most lanes past the row limit)"),
     ("pyramid2_lastconv_800_320_3x3", (8, 120, 160), 800, 320, 3, 1, 1, None, {},
-     "fwd <256,160> two column tiles, K = 7200; dgrad 320->800 <256,160,..,1>; wgrad<160,128> 2 x 57 tiles"),
+     "fwd persist <256,160> two column tiles (2 rounds + 88 rows per group of two), K = 7200; dgrad 320->800 <256,160,..,1> (3000 tiles: plain launch); wgrad<160,128> 2 x 57 tiles"),
     ("pyramid2_firstconv_80_160_3x3", (8, 120, 160), 80, 160, 3, 1, 1, None, {},
      "Cin = 80: igemm_dma<256,160,8,1,3,0> with the channel tail (was the register-staged kernel); dgrad 160->80 <256,128,4,2,3,1>; wgrad_dma<160,128>"),
     ("pyramid2_firstconv_80_80_3x3", (8, 120, 160), 80, 80, 3, 1, 1, None, {},
