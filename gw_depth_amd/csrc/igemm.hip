@@ -400,16 +400,17 @@ struct DmaTileCfg {
     static constexpr int B_INSTR = (BN + 15) / 16;
     static constexpr int BROWS = B_INSTR * 16;
     static constexpr int STAGE_BYTES = (BM + BROWS) * 64;
-    static constexpr int EPI_BYTES = NW * 32 * 36 * 4;
+    static constexpr int EPI_BYTES = NW * 32 * 36 * 4 + NW * (BM / WM / 32) * 64 * 4;      // transposition patches + the ConvLn row statistics
     static constexpr int SMEM = STAGES * STAGE_BYTES > EPI_BYTES ? STAGES * STAGE_BYTES : EPI_BYTES;
 };
 
-// One output tile [m0, m0 + BM) x [n0, n0 + BN).  MINI: only the first `rows` rows of the tile belong to this workgroup (the tail
-// pass of igemm_dma_persist_kernel deals the rows of a half-empty last round out evenly): rows beyond are neither fetched nor
-// stored, and a wave whose rows all lie beyond takes part in the tile traffic and the barriers but skips fragment reads, MFMAs and
-// the epilogue.  Without MINI (`rows` unused) the code is what igemm_dma_kernel always was.
-template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT, bool TAIL, bool GATE, int ACTK, bool MINI>
-__device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, const int m0, const int n0, const int rows, const int tid) {
+// One output tile [m0, m0 + BM) x [n0, n0 + BN).
+// (Round 3, measured and dropped: a persistent launch of one workgroup per resident slot - whole tiles, then the rows of the
+// mostly empty last round dealt out 44 per workgroup as a tile in which only two wave rows compute.  0.112 -> 0.122 ms on the
+// 160 -> 160 layer, with or without the idle waves' tile traffic: a K step of such a tail costs ~1.1 us whatever it computes, 45
+// of them are more than the 0.035 ms the half-empty round costs.  DESIGN.md section 4.)
+template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT, bool TAIL, bool GATE, int ACTK, bool LN = false>
+__device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, const int m0, const int n0) {
     typedef __bf16 T;
     constexpr int BK = 32, NW = WM * WN;                 // 4 or 8 waves
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -421,9 +422,8 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
     static_assert((BM / 16) % NW == 0 && TM >= 1 && TN >= 1, "tile / wave layout");
 
     const int M = d.B * d.Ho * d.Wo, N = d.Cout, K = d.KH * d.KW * d.Cin;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const bool active = !MINI || wm * (BM / WM) < rows;  // wave-uniform
     const T *x = (const T *)d.x;
     const T *wgt = (const T *)d.w;
     const char *zero = (const char *)d.zero_page;
@@ -441,7 +441,7 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
         const int row = 16 * (wave * A_IT + i) + (lane >> 2);
         a_ck[i] = ((lane & 3) ^ ((row >> 2) & 3)) * 8;
         const int m = m0 + row;
-        a_ok[i] = MINI ? (row < rows) : (m < M);
+        a_ok[i] = m < M;
         const int mm = a_ok[i] ? m : 0;
         const int b = mm / (d.Ho * d.Wo);
         const int rem = mm - b * (d.Ho * d.Wo);
@@ -584,11 +584,111 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
         }
         __builtin_amdgcn_s_barrier();                     // everybody's part of tile kt landed; compute(kt-1) is finished
         if (kt + STAGES - 1 < KT) issue((kt + STAGES - 1) % STAGES);
-        if (active) compute(kt % STAGES);
+        compute(kt % STAGES);
     }
     __syncthreads();
-    if (!active) return;
 
+    if constexpr (LN) {
+        // ---- ConvLn epilogue (points_sample.py:12-25): LayerNorm over the row's C = d.ln_C real channels (eps 1e-5, biased variance)
+        // straight from the fp32 accumulators, then * gamma + beta (d.scale / d.shift, C entries), [GELU: ACTK 2], [+ residual].
+        // WN == 1 and one column tile: a wave holds complete rows - row r of accumulator tile i lives in the 32 lanes of one wave
+        // half (column = lane & 31) across the TN tiles, so mean and variance are TN adds and one 32-lane segment sum each.  Two
+        // passes (mean, then centred squares) as nn.LayerNorm computes them.  The statistics go to d.ln_mean / d.ln_rstd (the
+        // LayerNorm backward kernel reads them) and, through a wave-private LDS table, to the lanes that own the row after the
+        // transposition; d.z gets the conv output itself (what the backward normalises again).  Columns >= C are zero padding
+        // (ops._PadConvFn): they do not count and come out as zeros.
+        static_assert(WN == 1 && !MULT && !GATE, "ConvLn epilogue: complete rows per wave");
+        T *y = (T *)d.y;
+        T *z = (T *)d.z;
+        const T *res = (const T *)d.residual;
+        const int C = d.ln_C;
+        const float inv_c = 1.0f / (float)C;
+        float *stage = (float *)smem + wave * (32 * 36);
+        float *stats = (float *)smem + NW * (32 * 36) + wave * (TM * 64);
+        const int vr = lane >> 2, vc = (lane & 3) * 8;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float mu[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) sum += acc[i][j][r];
+                mu[r] = segment_sum<32>(sum) * inv_c;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sq = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float dv = acc[i][j][r] - mu[r];
+                    sq += (j * 32 + fr < C) ? dv * dv : 0.f;
+                }
+                const float rs = rsqrtf(segment_sum<32>(sq) * inv_c + 1e-5f);
+                if (fr == 0) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    stats[(i * 32 + row) * 2] = mu[r];
+                    stats[(i * 32 + row) * 2 + 1] = rs;
+                    const int rt = wm * (BM / WM) + i * 32 + row;
+                    if (m0 + rt < M) {
+                        d.ln_mean[m0 + rt] = mu[r];
+                        d.ln_rstd[m0 + rt] = rs;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * fh) * 36 + fr] = acc[i][j][r];
+                __builtin_amdgcn_wave_barrier();
+                const int nb = n0 + j * 32 + vc;
+                if (nb < N) {
+                    float sc[8], sh[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        sc[e] = nb + e < C ? d.scale[nb + e] : 0.f;
+                        sh[e] = nb + e < C ? d.shift[nb + e] : 0.f;
+                    }
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int row = vr + 16 * half;
+                        const int rt = wm * (BM / WM) + i * 32 + row;
+                        if (m0 + rt >= M) continue;
+                        const f32x4 lo = *(const f32x4 *)(stage + row * 36 + vc);
+                        const f32x4 hi = *(const f32x4 *)(stage + row * 36 + vc + 4);
+                        const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        const float m_ = stats[(i * 32 + row) * 2], rs = stats[(i * 32 + row) * 2 + 1];
+                        const size_t o = (size_t)(m0 + rt) * N + nb;
+                        bf16x8 out;
+                        if (z) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) out[e] = (__bf16)v[e];
+                            *(bf16x8 *)(z + o) = out;
+                        }
+                        float t[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            t[e] = (v[e] - m_) * rs * sc[e] + sh[e];
+                            if (ACTK == 2) t[e] = gelu_f(t[e]);
+                        }
+                        if (res) {
+                            const bf16x8 rv = *(const bf16x8 *)(res + o);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) t[e] += (float)rv[e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) out[e] = (__bf16)t[e];
+                        *(bf16x8 *)(y + o) = out;
+                    }
+                }
+            }
+        }
+        return;
+    }
     // ---- epilogue (identical to igemm_fwd_kernel's vector path; N % 8 == 0 is a launch precondition)
     T *y = (T *)d.y;
     T *z = (ACTK == 0 || ACTK == 1) ? nullptr : (T *)d.z;       // ACTK 2 = GELU keeps the pre-activation copy its backward needs
@@ -617,7 +717,7 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
                 for (int half = 0; half < 2; ++half) {
                     const int row = vr + 16 * half;
                     const int m = m0 + wm * (BM / WM) + i * 32 + row;
-                    if (MINI ? (wm * (BM / WM) + i * 32 + row >= rows) : (m >= M)) continue;
+                    if (m >= M) continue;
                     const f32x4 lo = *(const f32x4 *)(stage + row * 36 + vc);
                     const f32x4 hi = *(const f32x4 *)(stage + row * 36 + vc + 4);
                     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -665,7 +765,7 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
     }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false, bool TAIL = false, bool GATE = false, int ACTK = -1>
+template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false, bool TAIL = false, bool GATE = false, int ACTK = -1, bool LN = false>
 __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_desc d, const int tile_base, const int tile_count) {
     __shared__ __attribute__((aligned(1024))) char smem[DmaTileCfg<BM, BN, WM, WN, STAGES>::SMEM];
     const int n_tiles = (d.Cout + BN - 1) / BN;
@@ -673,44 +773,7 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
     // whole rounds of 256-row tiles and a tail of 128-row tiles was measured in round 2: 0.125 -> 0.134 ms on the 160 -> 160
     // layer, the second launch and the lone waves of the tail cost more than the half-empty round they replace.)
     const int tile = tile_base + xcd_band(blockIdx.x, tile_count);             // column tiles of a row tile are adjacent
-    dma_tile<BM, BN, WM, WN, STAGES, GM, MULT, TAIL, GATE, ACTK, false>(d, smem, (tile / n_tiles) * BM, (tile % n_tiles) * BN, BM, (int)threadIdx.x);
-}
-
-// Persistent form for tile counts that leave a mostly empty last round (600 tiles of 256 x 160 on 512 resident workgroup slots: the 88
-// tiles of the second round cost 0.035 of 0.110 ms, a workgroup alone on a CU being no faster than two - DESIGN.md section 4).  The
-// grid is ONE workgroup per slot.  Each runs `rounds` whole tiles (slot, slot + slots, ...), then its share of the remaining rows:
-// they are dealt out `tail_rows` per slot-group (a group = the n_tiles column tiles of one row range), a MINI tile in which only the
-// first ceil(tail_rows / rows per wave row) wave rows compute.  Every output row is still written by exactly one workgroup.
-template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool TAIL, int ACTK>
-__global__ __launch_bounds__(WM *WN * 64) void igemm_dma_persist_kernel(const gwd_conv_desc d, const int rounds, const int tail_m0, const int tail_rows) {
-    __shared__ __attribute__((aligned(1024))) char smem[DmaTileCfg<BM, BN, WM, WN, STAGES>::SMEM];
-    const int M = d.B * d.Ho * d.Wo;
-    const int n_tiles = (d.Cout + BN - 1) / BN;
-    const int slots = (int)gridDim.x, slot = xcd_band(blockIdx.x, slots);
-    // ONE copy of the tile code (a second, specialised copy for the whole tiles cost 33 VGPRs and the second workgroup per CU):
-    // whole tiles are MINI tiles with rows = BM
-#pragma unroll 1
-    for (int r = 0; r <= rounds; ++r) {
-        int m0, n0, rows;
-        if (r < rounds) {
-            const int tile = r * slots + slot;
-            m0 = (tile / n_tiles) * BM;
-            n0 = (tile % n_tiles) * BN;
-            rows = BM;
-        } else {
-            m0 = tail_m0 + (slot / n_tiles) * tail_rows;
-            n0 = (slot % n_tiles) * BN;
-            rows = min(tail_rows, M - m0);
-            if (rows <= 0) break;                         // workgroup-uniform
-        }
-        // the thread index goes through an opaque move every round: everything derived from the lane (fragment addresses, swizzles,
-        // staging slots) would otherwise be hoisted out of this loop and stay live through the K loop - 33 VGPRs, which is the
-        // difference between two workgroups per CU and one
-        int tid = (int)threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        dma_tile<BM, BN, WM, WN, STAGES, GM, false, TAIL, false, ACTK, true>(d, smem, m0, n0, rows, tid);
-        __syncthreads();                                  // the epilogue's staging patches are the next tile's ring
-    }
+    dma_tile<BM, BN, WM, WN, STAGES, GM, MULT, TAIL, GATE, ACTK, LN>(d, smem, (tile / n_tiles) * BM, (tile % n_tiles) * BN);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1501,40 +1564,36 @@ static bool dma_enabled() {
     return v == 1;
 }
 
-static int persist_enabled() {               // A/B switch (GWD_IGEMM_PERSIST=0: one workgroup per tile, two rounds)
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GWD_IGEMM_PERSIST");
-        v = (e && e[0] == '0') ? 0 : 1;
+// gwd_conv_desc.ln_mean != NULL: convolution with the ConvLn epilogue (dma_tile<..., LN>).  0 = launched, -4 = no fused kernel for the shape.
+static int launch_convln(const gwd_conv_desc *d, hipStream_t s) {
+    const int M = d->B * d->Ho * d->Wo, N = d->Cout;
+    if (d->dtype != GWD_BF16 || !dma_enabled() || !d->zero_page || !d->ln_rstd || !d->scale || !d->shift || d->mult || d->gate) return -4;
+    if (d->gather != GWD_GATHER_CONV || (d->act != GWD_ACT_NONE && d->act != GWD_ACT_GELU) || d->act_scale != 1.0f) return -4;
+    if (d->ln_C <= 0 || d->ln_C > N || (N % 8) || (d->Cin % 8)) return -4;
+    const bool tail = (d->Cin % 32) != 0;
+    if (tail && d->Cin < 32) return -4;
+    const bool gelu = d->act == GWD_ACT_GELU;
+#define LN_LAUNCH(BM_, BN_, WM_, WN_, ST_, TAIL_, GRID)                                                                           \
+    {                                                                                                                             \
+        const dim3 g_(GRID);                                                                                                      \
+        if (gelu) igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 0, false, TAIL_, false, 2, true><<<g_, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)g_.x); \
+        else igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 0, false, TAIL_, false, 0, true><<<g_, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)g_.x);      \
     }
-    return v;
-}
-static int resident_slots_2_per_cu() {
-    static int v = 0;
-    if (!v) {
-        int dev = 0, cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
-        v = 2 * cu;
+    if (N == 160) {
+        if (big_tiles_enabled() && M >= 256 * 512) {
+            if (tail) LN_LAUNCH(256, 160, 8, 1, 3, true, (M + 255) / 256) else LN_LAUNCH(256, 160, 8, 1, 3, false, (M + 255) / 256)
+            return 0;
+        }
+        if (tail) return -4;
+        LN_LAUNCH(128, 160, 4, 1, 3, false, (M + 127) / 128)
+        return 0;
     }
-    return v;
-}
-
-// 256 x 160 tiles, lean epilogue: when the tile count leaves a last round that is less than 40 % full, run whole rounds + an even split
-// of the remaining rows inside ONE grid of resident workgroups (igemm_dma_persist_kernel).  1 = launched.
-template <int GM, bool TAIL>
-static int launch_persist_256x160(const gwd_conv_desc *d, hipStream_t s) {
-    if (!persist_enabled()) return 0;
-    const int M = d->B * d->Ho * d->Wo, n_tiles = d->Cout / 160;
-    const int slots = resident_slots_2_per_cu();
-    const long total = (long)((M + 255) / 256) * n_tiles;
-    const int rounds = (int)(total / slots), rem = (int)(total % slots);
-    if (rounds < 1 || rem == 0 || rem * 5 > slots * 2 || (rem % n_tiles) || (slots % n_tiles)) return 0;
-    const int tail_m0 = (int)((long)rounds * slots / n_tiles) * 256;
-    const int groups = slots / n_tiles;
-    const int tail_rows = (M - tail_m0 + groups - 1) / groups;
-    if (tail_rows <= 0 || tail_rows > 128) return 0;
-    igemm_dma_persist_kernel<256, 160, 8, 1, 3, GM, TAIL, 0><<<slots, 512, 0, s>>>(*d, rounds, tail_m0, tail_rows);
-    return 1;
+    if (tail) return -4;
+    if (N <= 32) LN_LAUNCH(128, 32, 4, 1, 4, false, (M + 127) / 128)
+    else if (N <= 64) LN_LAUNCH(128, 64, 4, 1, 4, false, (M + 127) / 128)
+    else return -4;
+#undef LN_LAUNCH
+    return 0;
 }
 
 template <typename T>
@@ -1542,6 +1601,12 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
     const int M = d->B * d->Ho * d->Wo, N = d->Cout;
     constexpr int BK = Cfg<T>::BK;
     const unsigned gm = (M + 127) / 128;
+    if (d->ln_mean) {                         // ConvLn epilogue: a fused kernel or -4 (the caller runs convolution and LayerNorm apart)
+        const int rc = launch_convln(d, s);
+        if (rc) return rc;
+        GWD_CHECK_LAUNCH();
+        return 0;
+    }
     if constexpr (sizeof(T) == 2) {
         if (launch_ksplit(d, s)) {
             GWD_CHECK_LAUNCH();
@@ -1577,8 +1642,7 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
             if (N % 160 == 0) {
                 const dim3 g(gm2 * (N / 160));
                 if (lean) {
-                    if (tr ? launch_persist_256x160<1, true>(d, s) : launch_persist_256x160<0, true>(d, s)) {
-                    } else if (tr) igemm_dma_kernel<256, 160, 8, 1, 3, 1, false, true, false, 0><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
+                    if (tr) igemm_dma_kernel<256, 160, 8, 1, 3, 1, false, true, false, 0><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
                     else igemm_dma_kernel<256, 160, 8, 1, 3, 0, false, true, false, 0><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
                 } else if (tr) igemm_dma_kernel<256, 160, 8, 1, 3, 1, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
                 else igemm_dma_kernel<256, 160, 8, 1, 3, 0, false, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
@@ -1618,8 +1682,7 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
                 const int var = fwd_variant();
                 if (var == 1) { DMA_LAUNCH(128, 160, 4, 1, 3, dim3(gm * (N / 160))) }
                 else if (var == 2) { DMA_LAUNCH(128, 160, 4, 1, 2, dim3(gm * (N / 160))) }
-                else if (big && actk == 0 && !d->gate && gmk < 2 && (gmk ? launch_persist_256x160<1, false>(d, s) : launch_persist_256x160<0, false>(d, s))) {
-                } else if (big) { DMA_LAUNCH(256, 160, 8, 1, 3, dim3(gm2 * (N / 160))) } else { DMA_LAUNCH(128, 160, 4, 1, 3, dim3(gm * (N / 160))) }
+                else if (big) { DMA_LAUNCH(256, 160, 8, 1, 3, dim3(gm2 * (N / 160))) } else { DMA_LAUNCH(128, 160, 4, 1, 3, dim3(gm * (N / 160))) }
             } else if (N > 64) {
                 const unsigned t128 = gm * ((N + 127) / 128);
                 const int small_thr = small_tile_threshold();
@@ -1808,7 +1871,7 @@ extern "C" int gwd_conv_forward(const gwd_conv_desc *d, void *stream) {
     if (!d->w) return -1;
     if ((int64_t)d->B * d->Ho * d->Wo * d->Cout >= (1LL << 40)) return -7;
     if (trace_conv()) trace_line("fwd", d);
-    if (gwd_thin_conv_forward(d, (hipStream_t)stream) || gwd_tile_conv_forward(d, (hipStream_t)stream)) {
+    if (!d->ln_mean && (gwd_thin_conv_forward(d, (hipStream_t)stream) || gwd_tile_conv_forward(d, (hipStream_t)stream))) {
         GWD_CHECK_LAUNCH();
         return 0;
     }

@@ -46,7 +46,8 @@ class ConvDesc(ctypes.Structure):
                 ("zero_page", ctypes.c_void_p), ("mult", ctypes.c_void_p), ("gate", ctypes.c_void_p)] + \
                [(n, ctypes.c_int32) for n in ("B", "Hi", "Wi", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad",
                                               "gather", "Hv", "Wv", "act")] + \
-               [("act_scale", ctypes.c_float), ("dtype", ctypes.c_int32), ("gate_act", ctypes.c_int32)]
+               [("act_scale", ctypes.c_float), ("dtype", ctypes.c_int32), ("gate_act", ctypes.c_int32),
+                ("ln_mean", ctypes.c_void_p), ("ln_rstd", ctypes.c_void_p), ("ln_C", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class PrepJob(ctypes.Structure):
@@ -246,7 +247,7 @@ class HipLibrary:
     # ------------------------------------------------------------------ entry points
     @staticmethod
     def _desc(x, w, y, dims, z=None, scale=None, shift=None, residual=None, stride=1, pad=0,
-              gather=GATHER_CONV, virt=(0, 0), act=ACT_NONE, act_scale=1.0, mult=None, gate=None, gate_act=ACT_NONE):
+              gather=GATHER_CONV, virt=(0, 0), act=ACT_NONE, act_scale=1.0, mult=None, gate=None, gate_act=ACT_NONE, ln=None):
         B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW = dims
         d = ConvDesc()
         d.x, d.w, d.y, d.z = _ptr(x), _ptr(w), _ptr(y), _ptr(z)
@@ -257,13 +258,20 @@ class HipLibrary:
         d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW = B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW
         d.stride, d.pad, d.gather, d.Hv, d.Wv = stride, pad, gather, virt[0], virt[1]
         d.act, d.act_scale, d.dtype = act, act_scale, dtype_code(x)
+        if ln is not None:                              # ConvLn mode: (mean, rstd, real channel count), gwd_conv_desc.ln_*
+            d.ln_mean, d.ln_rstd, d.ln_C = _ptr(ln[0]), _ptr(ln[1]), int(ln[2])
         return d
 
     def conv_forward(self, x, w, y, dims, **kw):
         """dims = (B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW); kw: z scale shift residual stride pad gather virt act act_scale mult
-        gate gate_act (the epilogue's last step: backward of the activation whose output is `gate`)."""
+        gate gate_act (the epilogue's last step: backward of the activation whose output is `gate`); ln=(mean, rstd, C): the ConvLn
+        epilogue (LayerNorm over the first C channels, scale / shift = gamma / beta) - returns False when the library has no fused
+        kernel for the shape (nothing was launched)."""
         d = self._desc(x, w, y, dims, **kw)
-        self._check(self.lib.gwd_conv_forward(ctypes.byref(d), self._stream(x, w, y)), "gwd_conv_forward")
+        rc = self.lib.gwd_conv_forward(ctypes.byref(d), self._stream(x, w, y))
+        if rc == -4 and kw.get("ln") is not None:
+            return False                                # no fused ConvLn kernel for this shape: the caller runs the two kernels
+        self._check(rc, "gwd_conv_forward")
 
     def conv_wgrad(self, x, gy, dw, dims, **kw):
         d = self._desc(x, None, gy, dims, **kw)

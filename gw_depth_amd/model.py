@@ -589,6 +589,10 @@ class ConvLn(nn.Module):
 
     def forward(self, x, gelu=False, residual=None, geom=None, fan=False):
         """fan: also return the input again for its second consumer (the block's skip): ops._ConvFn fan-out."""
+        if x.is_cuda and x.dtype == torch.bfloat16 and ops.conv_ln_fused_enabled():
+            # one launch: the LayerNorm (+ GELU / + skip) runs in the convolution's epilogue (ops._ConvLnFn)
+            return ops.conv_ln(x, self.conv.weight, self.layer_norm.weight, self.layer_norm.bias, self.pad, gelu=gelu, residual=residual,
+                               geom=geom, fanout=fan)
         if geom is not None:                # zero-padded channel counts (PyramidLayer.padded_width); the LayerNorm sees the pitch
             y = ops.conv2d_padded(x, self.conv.weight, self.pad, geom, fanout=fan)
         else:

@@ -714,6 +714,122 @@ def layer_norm(x, gamma, beta, gelu=False, residual=None, fanout=False, in_gate=
     return _LayerNormFn.apply(x, gamma, beta, bool(gelu), sinks, residual, bool(fanout), in_gate)
 
 
+class _ConvLnFn(torch.autograd.Function):
+    """ConvLn (points_sample.py:12-25): stride-1 convolution without bias -> LayerNorm over channels [-> GELU] [+ residual] as ONE
+    forward launch - the LayerNorm runs in the implicit GEMM's epilogue on the fp32 accumulators (gwd_conv_desc.ln_*), so the
+    normalisation pass and its read of the convolution's output disappear.  The kernel leaves what the unfused pair left: the
+    convolution's output z and the row statistics, so the backward is the unfused one (gwd_layernorm_backward, then data / weight
+    gradient of the convolution).  geom = None, or (Np, Cg, Cgp) for a layer on zero-padded channel counts (_PadConvFn).  Where the
+    library has no fused kernel for the shape the two forward kernels run here instead - same results, same saved tensors."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, residual, pad, gelu, geom, w_sink, ln_sinks, fanout):
+        lib = _lib()
+        ctx.fan = bool(fanout)
+        B, Hi, Wi, Cin = x.shape
+        N, KH, KW, Cw = w.shape
+        if geom is None:
+            Np = N
+            if Cw != Cin:
+                raise ValueError("conv_ln: weight expects %d input channels, input has %d" % (Cw, Cin))
+            wk = _weight_for(w, None, x.dtype, getattr(w, "_gwd_bf16", None))
+        else:
+            Np, Cg, Cgp = geom
+            if Cin != (Cw // Cg) * Cgp:
+                raise ValueError("conv_ln: input has %d channels, the padded weight expects %d" % (Cin, (Cw // Cg) * Cgp))
+            wk = _padded_weight_for(w, geom, "fwd", x.dtype)
+        Ho, Wo = Hi + 2 * pad - KH + 1, Wi + 2 * pad - KW + 1
+        x = x.contiguous()
+        rows = B * Ho * Wo
+        y = torch.empty((B, Ho, Wo, Np), dtype=x.dtype, device=x.device)
+        need_grad = any(ctx.needs_input_grad)
+        z = torch.empty_like(y) if need_grad else None      # inference: the convolution's own output is never written
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        g, b = gamma.detach(), beta.detach()
+        res = None if residual is None else residual.contiguous()
+        dims = (B, Hi, Wi, Cin, Ho, Wo, Np, KH, KW)
+        fused = lib.conv_forward(x, wk, y, dims, z=z, scale=g, shift=b, residual=res, stride=1, pad=pad,
+                                 act=ACT_GELU if gelu else ACT_NONE, ln=(mean, rstd, N))
+        if fused is False:
+            z = torch.empty_like(y) if z is None else z
+            lib.conv_forward(x, wk, z, dims, stride=1, pad=pad)
+            lib.layernorm_forward(z, g, b, y, mean, rstd, rows, N, gelu, residual=res, ld=0 if Np == N else Np)
+        if need_grad:
+            ctx.save_for_backward(x, w, z, g, b, mean, rstd)
+        ctx.cfg = (dims, pad, bool(gelu), geom, w_sink, ln_sinks, residual is not None)
+        if fanout:
+            return y, x.view_as(x)                   # the input again, for its second consumer (the block's skip): see _ConvFn
+        return y
+
+    @staticmethod
+    def backward(ctx, gy, *g_fan):
+        lib = _lib()
+        g_in = g_fan[0].contiguous() if (ctx.fan and g_fan and g_fan[0] is not None) else None
+        x, w, z, g, b, mean, rstd = ctx.saved_tensors
+        dims, pad, gelu, geom, w_sink, ln_sinks, has_res = ctx.cfg
+        B, Hi, Wi, Cin, Ho, Wo, Np, KH, KW = dims
+        N = g.shape[0]
+        rows = B * Ho * Wo
+        gy = gy.contiguous()
+        # ---- LayerNorm backward (as _LayerNormFn.backward): gradient w.r.t. the convolution's output, d gamma / d beta into their sinks
+        gz = torch.empty_like(z)
+        dg = db = None
+        if ln_sinks is not None:
+            (dg, h1), (db, h2) = ln_sinks
+        else:
+            dg = torch.zeros(N, dtype=torch.float32, device=x.device)
+            db = torch.zeros(N, dtype=torch.float32, device=x.device)
+        lib.layernorm_backward(gy, z, g, b, mean, rstd, gz, dg, db, rows, N, gelu, ld=0 if Np == N else Np)
+        if ln_sinks is not None:
+            for h in (h1, h2):
+                if h is not None:
+                    h()
+        # ---- convolution backward (as _ConvFn / _PadConvFn.backward)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            wt = _weight_transposed(w, None, x.dtype) if geom is None else _padded_weight_for(w, geom, "t", x.dtype)
+            lib.conv_forward(gz, wt, gx, (B, Ho, Wo, Np, Hi, Wi, Cin, KH, KW), stride=1, pad=pad, gather=GATHER_TRANSPOSED, residual=g_in)
+        elif g_in is not None:
+            gx = g_in
+        if ctx.needs_input_grad[1]:
+            if geom is None:
+                if w_sink is not None:
+                    WGRADS.add(x, gz, w_sink[0], dims, dict(stride=1, pad=pad), w_sink[1])
+                else:
+                    gw = torch.zeros(w.shape, dtype=torch.float32, device=w.device)
+                    lib.conv_wgrad(x, gz, gw, dims, stride=1, pad=pad)
+            else:
+                _, Cg, Cgp = geom
+                C = w.shape[-1]
+                tmp = WGRADS.scratch((Np, KH, KW, Cin), x.device)
+                fold = (N, KH * KW, C // Cg, Cg, Cgp)
+                if w_sink is not None:
+                    WGRADS.add(x, gz, tmp, dims, dict(stride=1, pad=pad), w_sink[1], unpad=(w_sink[0].view(-1),) + fold)
+                else:
+                    lib.conv_wgrad(x, gz, tmp, dims, stride=1, pad=pad)
+                    gw = torch.zeros(w.shape, dtype=torch.float32, device=w.device)
+                    lib.unpad_add_batch([(tmp, gw.view(-1)) + fold])
+        gres = gy if has_res else None                      # y = ... + residual: the skip gets the incoming gradient as is
+        if ln_sinks is not None:
+            return gx, gw, None, None, gres, None, None, None, None, None, None
+        return gx, gw, dg, db, gres, None, None, None, None, None, None
+
+
+def conv_ln(x, w, gamma, beta, pad, gelu=False, residual=None, geom=None, fanout=False):
+    """See _ConvLnFn.  x (B,H,W,Cin) bf16 on the device; w (Cout,KH,KW,Cin') fp32 master; gamma / beta (Cout,) fp32."""
+    sg, sb = _sink(gamma), _sink(beta)
+    ln_sinks = (sg, sb) if (sg is not None and sb is not None) else None
+    return _ConvLnFn.apply(x, w, gamma, beta, residual, int(pad), bool(gelu), None if geom is None else tuple(int(v) for v in geom),
+                           _sink(w), ln_sinks, bool(fanout))
+
+
+def conv_ln_fused_enabled():
+    """A/B switch (GWD_CONVLN=0: convolution and LayerNorm as two launches, the round-2 path)."""
+    return os.environ.get("GWD_CONVLN", "1") != "0"
+
+
 class _SoftmaxFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GWD_VERSION 7
+#define GWD_VERSION 8
 
 enum { GWD_F32 = 0, GWD_BF16 = 1 };
 enum { GWD_ACT_NONE = 0, GWD_ACT_RELU = 1, GWD_ACT_GELU = 2, GWD_ACT_ELU = 3, GWD_ACT_SIGMOID = 4 };
@@ -60,6 +60,17 @@ typedef struct {
     float act_scale;      /* y = act_scale * act(v)  (max_depth * sigmoid)                      */
     int32_t dtype;        /* GWD_F32 / GWD_BF16 for x, w, y, z, residual, mult, gate            */
     int32_t gate_act;     /* GWD_ACT_RELU or GWD_ACT_ELU when gate != NULL, else ignored         */
+    /* ConvLn mode (src/models/points/points_sample.py:12-25: conv -> LayerNorm over channels [-> GELU]), when ln_mean != NULL:   */
+    /*   y = act(LN(conv) * scale + shift) + residual,  LN over the first ln_C of the Cout channels of a row (eps 1e-5; channels   */
+    /*   ln_C .. Cout-1 are zero padding and come out as zeros; scale / shift = gamma / beta with ln_C entries, both required;     */
+    /*   act NONE or GELU; the residual is added AFTER the activation, as gwd_layernorm_forward adds it).  z (optional) receives   */
+    /*   the convolution itself, ln_mean / ln_rstd [B*Ho*Wo] the row statistics - exactly what gwd_layernorm_backward takes.      */
+    /*   gwd_conv_forward returns -4 when it has no fused kernel for the shape (bf16, LDS-DMA route, a whole row inside one tile:  */
+    /*   Cout <= 64 or Cout == 160); the caller then runs the convolution and gwd_layernorm_forward separately.                  */
+    float *ln_mean;
+    float *ln_rstd;
+    int32_t ln_C;
+    int32_t reserved;
 } gwd_conv_desc;
 
 int gwd_version(void);

@@ -188,3 +188,91 @@ def test_dominant_kernel_in_exact_fp32_mode(dev):
     dev.conv_forward(x.cuda(), w.cuda(), y, (B, H, W, C, H, W, C, 3, 3), stride=1, pad=1)
     torch.cuda.synchronize()
     close(y, y_ref, TOL_F32, "fp32 160->160 forward")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# ConvLn: convolution -> LayerNorm over channels [-> GELU] [+ skip] in ONE launch (gwd_conv_desc.ln_*, dma_tile<..., LN>), against
+# fp32 torch arithmetic (F.conv2d + F.layer_norm + F.gelu: what points_sample.py:12-43 runs), at the sizes the step dispatches.
+LN_CASES = [
+    # name, (B, H, W), Cin, Cout (row pitch), C (real channels), gelu, residual, kernel
+    ("pyr2_160_160_gelu", (8, 120, 160), 160, 160, 160, True, False, "<256,160,8,1,3,0,..,2,LN>: PyrBlock conv1 at 1/4 resolution"),
+    ("pyr2_160_160_skip", (8, 120, 160), 160, 160, 160, False, True, "<256,160,..,0,LN> + residual after the normalisation: PyrBlock conv2"),
+    ("pyr2_80_160_gelu_tail", (8, 120, 160), 80, 160, 160, True, False, "<256,160,..,TAIL,2,LN>: firstconv[2], Cin = 80"),
+    ("pyr2_ragged_rows", (3, 119, 161), 160, 160, 160, True, True, "M = 57 477: <128,160,4,1,3> with a ragged last tile, GELU and skip together"),
+    ("branch_160_160_pooled", (8, 30, 40), 160, 160, 160, True, False, "<128,160,4,1,3,0,..,LN>: PSP branch on a pooled map"),
+    ("branch_tiny_map", (8, 7, 10), 160, 160, 160, True, False, "M = 560: five tiles"),
+    ("pyr1_64_64_padded_60", (8, 60, 80), 64, 64, 60, True, False, "<128,64,4,1,4,0,..,LN>: 60 real channels in 64-wide rows, padding written as zeros"),
+    ("pyr1_64_64_padded_skip", (8, 60, 80), 64, 64, 60, False, True, "the same with the skip"),
+    ("pyr1_32_32_padded_30", (8, 60, 80), 32, 32, 30, True, False, "<128,32,4,1,4,0,..,LN>: 30 real channels"),
+]
+
+
+@pytest.mark.parametrize("case", LN_CASES, ids=[c[0] for c in LN_CASES])
+def test_fused_conv_layernorm_epilogue_against_fp32_torch(dev, case):
+    name, (B, H, W), Cin, Np, C, gelu, with_res, _ = case
+    x = rnd(B, H, W, Cin, seed=51)
+    w = rnd(Np, 3, 3, Cin, seed=52, scale=(9 * Cin) ** -0.5)
+    if C < Np:
+        w[C:] = 0                                     # zero-padded rows of the kernel-side weight copy (ops._PadConvFn)
+    gamma = (torch.rand(C, generator=torch.Generator().manual_seed(53)) + 0.5)
+    beta = rnd(C, seed=54, dtype=torch.float32) * 0.3
+    res = rnd(B, H, W, Np, seed=55) if with_res else None
+    if res is not None and C < Np:
+        res[..., C:] = 0
+    conv = F.conv2d(nchw(x), w.float().permute(0, 3, 1, 2), None, padding=1).permute(0, 2, 3, 1)          # (B,H,W,Np) fp32
+    ln = F.layer_norm(conv[..., :C], (C,), gamma, beta, 1e-5)
+    if gelu:
+        ln = F.gelu(ln)
+    y_ref = torch.zeros(B, H, W, Np)
+    y_ref[..., :C] = ln
+    if res is not None:
+        y_ref = y_ref + res.float()
+    mean_ref = conv[..., :C].mean(-1).reshape(-1)
+    rstd_ref = (conv[..., :C].var(-1, unbiased=False) + 1e-5).rsqrt().reshape(-1)
+
+    rows = B * H * W
+    y = torch.full((B, H, W, Np), float("nan"), dtype=torch.bfloat16, device="cuda")
+    z = torch.full_like(y, float("nan"))
+    mean = torch.full((rows,), float("nan"), device="cuda")
+    rstd = torch.full((rows,), float("nan"), device="cuda")
+    ok = dev.conv_forward(x.cuda(), w.cuda(), y, (B, H, W, Cin, H, W, Np, 3, 3), z=z, scale=gamma.cuda(), shift=beta.cuda(),
+                          residual=None if res is None else res.cuda(), stride=1, pad=1, act=hip.ACT_GELU if gelu else hip.ACT_NONE,
+                          ln=(mean, rstd, C))
+    assert ok is not False, name + ": the library has no fused kernel for a shape the step uses"
+    torch.cuda.synchronize()
+    close(y, y_ref, TOL_BF16, name + " output")
+    close(z, conv, TOL_BF16, name + " convolution copy")
+    close(mean, mean_ref, 2e-4, name + " row means")
+    close(rstd, rstd_ref, 2e-4, name + " row rstd")
+    if C < Np:
+        assert float(y[..., C:].float().abs().max()) == 0.0, name + ": padding channels must come out as zeros"
+
+
+def test_conv_ln_autograd_node_equals_the_two_kernel_path(dev):
+    """ops.conv_ln (one forward launch) against ops.conv2d + ops.layer_norm (two): same outputs to bf16 rounding of the intermediate,
+    same gradients for input, weight, gamma, beta and the skip - forward values differ only because the fused epilogue normalises the
+    fp32 accumulators while the pair normalises their bf16 copy."""
+    from gw_depth_amd import ops
+    B, H, W, Cc = 2, 60, 80, 160
+    x0 = rnd(B, H, W, Cc, seed=61).cuda()
+    w0 = rnd(Cc, 3, 3, Cc, seed=62, scale=(9 * Cc) ** -0.5, dtype=torch.float32).cuda()
+    g0 = (torch.rand(Cc, generator=torch.Generator().manual_seed(63)) + 0.5).cuda()
+    b0 = (rnd(Cc, seed=64, dtype=torch.float32) * 0.2).cuda()
+    r0 = rnd(B, H, W, Cc, seed=65).cuda()
+    gy = rnd(B, H, W, Cc, seed=66).cuda()
+    out = []
+    for fused in (True, False):
+        x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+        w, g, b = (t.clone().requires_grad_(True) for t in (w0, g0, b0))
+        for gelu, res in ((True, None), (False, r)):
+            if fused:
+                y = ops.conv_ln(x if gelu else h, w, g, b, 1, gelu=gelu, residual=res)
+            else:
+                y = ops.layer_norm(ops.conv2d(x if gelu else h, w, pad=1), g, b, gelu, residual=res)
+            h = y
+        with ops.COLSUMS, ops.WGRADS:
+            y.backward(gy)
+        torch.cuda.synchronize()
+        out.append((y.detach(), x.grad, w.grad, g.grad, b.grad, r.grad))
+    for name, a, c in zip(("output", "d input", "d weight", "d gamma", "d beta", "d skip"), out[0], out[1]):
+        close(a, c.float().cpu(), 1e-2, "conv_ln vs conv2d + layer_norm: " + name)
