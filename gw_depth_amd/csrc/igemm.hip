@@ -409,7 +409,7 @@ struct DmaTileCfg {
 // mostly empty last round dealt out 44 per workgroup as a tile in which only two wave rows compute.  0.112 -> 0.122 ms on the
 // 160 -> 160 layer, with or without the idle waves' tile traffic: a K step of such a tail costs ~1.1 us whatever it computes, 45
 // of them are more than the 0.035 ms the half-empty round costs.  DESIGN.md section 4.)
-template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT, bool TAIL, bool GATE, int ACTK, bool LN = false>
+template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT, bool TAIL, bool GATE, int ACTK, bool LN = false, int KPB = 1>
 __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, const int m0, const int n0) {
     typedef __bf16 T;
     constexpr int BK = 32, NW = WM * WN;                 // 4 or 8 waves
@@ -569,22 +569,52 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
         }
     };
 
+    if constexpr (KPB == 1) {
 #pragma unroll
-    for (int t = 0; t < STAGES - 1; ++t)
-        if (t < KT) issue(t);
-    for (int kt = 0; kt < KT; ++kt) {
-        // tile kt has landed once at most (STAGES-2) newer tiles of this wave are still in flight
-        if (kt + STAGES - 2 < KT) {
-            if (my_b_loads == B_IT)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A_IT + B_IT) * (STAGES - 2)) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A_IT + B_IT - 1) * (STAGES - 2)) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int t = 0; t < STAGES - 1; ++t)
+            if (t < KT) issue(t);
+        for (int kt = 0; kt < KT; ++kt) {
+            // tile kt has landed once at most (STAGES-2) newer tiles of this wave are still in flight
+            if (kt + STAGES - 2 < KT) {
+                if (my_b_loads == B_IT)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A_IT + B_IT) * (STAGES - 2)) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A_IT + B_IT - 1) * (STAGES - 2)) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();                 // everybody's part of tile kt landed; compute(kt-1) is finished
+            if (kt + STAGES - 1 < KT) issue((kt + STAGES - 1) % STAGES);
+            compute(kt % STAGES);
         }
-        __builtin_amdgcn_s_barrier();                     // everybody's part of tile kt landed; compute(kt-1) is finished
-        if (kt + STAGES - 1 < KT) issue((kt + STAGES - 1) % STAGES);
-        compute(kt % STAGES);
+    } else {
+        // KPB K tiles per barrier (launch precondition: KT % KPB == 0): the small tiles of the mid-size GEMMs (ResNet layer2-4, the
+        // transformer linears) spend a K step on one barrier, one LDS round trip and two dependent MFMAs per wave - 0.34 us whatever
+        // the ring depth.  Same stages, same DMA, same fragment reads; a GROUP of KPB consecutive stages is waited for, fenced and
+        // consumed together, so the fixed cost of a step is paid per 32 * KPB channels of the reduction.
+        constexpr int SS = STAGES / KPB;                  // groups in the ring
+        static_assert(STAGES % KPB == 0 && SS >= 2, "ring = whole groups");
+        const int KG = KT / KPB;
+#pragma unroll
+        for (int t = 0; t < (SS - 1) * KPB; ++t)
+            if (t < KT) issue(t);
+        for (int kg = 0; kg < KG; ++kg) {
+            if (kg + SS - 2 < KG) {
+                if (my_b_loads == B_IT)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A_IT + B_IT) * KPB * (SS - 2)) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A_IT + B_IT - 1) * KPB * (SS - 2)) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (kg + SS - 1 < KG) {
+#pragma unroll
+                for (int u = 0; u < KPB; ++u) issue(((kg + SS - 1) * KPB + u) % STAGES);
+            }
+#pragma unroll
+            for (int u = 0; u < KPB; ++u) compute((kg * KPB + u) % STAGES);
+        }
     }
     __syncthreads();
 
@@ -765,7 +795,7 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
     }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false, bool TAIL = false, bool GATE = false, int ACTK = -1, bool LN = false>
+template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false, bool TAIL = false, bool GATE = false, int ACTK = -1, bool LN = false, int KPB = 1>
 __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_desc d, const int tile_base, const int tile_count) {
     __shared__ __attribute__((aligned(1024))) char smem[DmaTileCfg<BM, BN, WM, WN, STAGES>::SMEM];
     const int n_tiles = (d.Cout + BN - 1) / BN;
@@ -773,7 +803,7 @@ __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_d
     // whole rounds of 256-row tiles and a tail of 128-row tiles was measured in round 2: 0.125 -> 0.134 ms on the 160 -> 160
     // layer, the second launch and the lone waves of the tail cost more than the half-empty round they replace.)
     const int tile = tile_base + xcd_band(blockIdx.x, tile_count);             // column tiles of a row tile are adjacent
-    dma_tile<BM, BN, WM, WN, STAGES, GM, MULT, TAIL, GATE, ACTK, LN>(d, smem, (tile / n_tiles) * BM, (tile % n_tiles) * BN);
+    dma_tile<BM, BN, WM, WN, STAGES, GM, MULT, TAIL, GATE, ACTK, LN, KPB>(d, smem, (tile / n_tiles) * BM, (tile % n_tiles) * BN);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1204,6 +1234,137 @@ __global__ __launch_bounds__(256) void igemm_wgrad_group_kernel(const WgradGroup
     wgrad_dma_body<BNW, BKW, WN, WK, STAGES, FAST>(d, g.dw[ji], g.m_per_block[ji], id, g.blocks[ji]);
 }
 
+// ----------------------------------------------------------------------------------------------
+// weight gradient of 3x3 / stride 1 / pad 1 layers with Cout % 160 == 0: one staged pixel strip for all nine taps
+// ----------------------------------------------------------------------------------------------
+// igemm_wgrad_dma_kernel<160,128> stages 18 KB per 32-pixel step for 40 MFMAs (4 waves x 10) - 450 bytes of LDS-DMA fill per MFMA,
+// every input pixel's channels fetched once per tap by different workgroups - and runs at ~6 TB/s of fill = 21 % of the MFMA peak
+// (DESIGN.md section 4).  Here a workgroup owns ONE 32-channel slice of the input for ALL nine taps and a 160-wide slice of the
+// outputs: nine waves, wave = filter tap, 5 accumulator tiles (160 x 32) each.  A step is 32 consecutive pixels of one image row:
+// their dY rows [32][160] (10 KB) and ONE halo patch of x - rows oh-1 .. oh+1, columns ow0-1 .. ow0+32, 32 channels: 102 x 64 B -
+// land in LDS once; tap (kh, kw) reads its 32 pixels at image row kh * 34 + kw of the patch.  16.5 KB per 90 MFMAs = 183 B / MFMA.
+// Both operands are needed pixel-major (the reduction runs over pixels): ds_read_b64_tr_b16, as in wgrad_dma_body; pitches of 320 B
+// and 64 B put the four rows of a transposed read 16 banks apart - conflict free without a swizzle.  One workgroup per CU (nine
+// waves hold 80 accumulator registers each), a ring of WT_STAGES steps in dynamic LDS, counted vmcnt + one barrier per step.
+// The reduction over pixels is split over workgroups (tiles x splits ~ one per CU), fp32 atomics into the flat gradient.
+constexpr int WT_STAGES = 8, WT_YB = 10240, WT_XB = 7168, WT_STAGE = WT_YB + WT_XB;
+__global__ __launch_bounds__(576) void wgrad_taps_kernel(const gwd_conv_desc d, float *__restrict__ dw, const int chunks_per_split, const int wg_count) {
+    typedef __bf16 T;
+    extern __shared__ __attribute__((aligned(1024))) char wt_smem[];
+    const int N = d.Cout, Cin = d.Cin, H = d.Ho, W = d.Wo, K = 9 * Cin;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;          // wave = tap
+    const int tiles_c = (Cin + 31) / 32, tiles = tiles_c * (N / 160);
+    const int band = xcd_band((int)blockIdx.x, wg_count);                // the tiles of one pixel range are neighbours on one XCD
+    const int tile = band % tiles, split = band / tiles;
+    const int c0 = (tile % tiles_c) * 32, n0 = (tile / tiles_c) * 160;
+    const int cpr = (W + 31) / 32, total = d.B * H * cpr;
+    const int s0 = split * chunks_per_split, s1 = min(total, s0 + chunks_per_split);
+    const int steps = s1 - s0;
+    if (steps <= 0) return;                                               // workgroup-uniform
+    const T *gy = (const T *)d.y;
+    const T *x = (const T *)d.x;
+    const char *zero = (const char *)d.zero_page;
+
+    // ---- this lane's part of the 17 DMA instructions of a step: wave w issues instructions w and w + 9 (wave 8: one only)
+    // j < 10: dY, 16-byte piece q = j * 64 + lane of the [32 pixels][160 channels] block; j >= 10: x patch, piece q of [102][4]
+    int y_p[2], y_off[2], x_kr[2], x_px[2], x_co[2];
+    bool is_y[2], x_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = wave + 9 * i;
+        is_y[i] = j < 10;
+        const int q = (is_y[i] ? j : j - 10) * 64 + lane;
+        y_p[i] = q / 20;
+        y_off[i] = n0 + (q - y_p[i] * 20) * 8;
+        const int pr = q >> 2;
+        x_kr[i] = pr / 34;
+        x_px[i] = pr - x_kr[i] * 34;
+        x_co[i] = c0 + (q & 3) * 8;
+        x_ok[i] = q < 408 && x_co[i] < Cin;
+    }
+    const int my_loads = wave < 8 ? 2 : 1;
+    int issued = 0;
+    auto issue = [&](int stage) {
+        char *sb = wt_smem + stage * WT_STAGE;
+        const int ci = s0 + issued;
+        const int b = ci / (H * cpr);
+        const int rem = ci - b * (H * cpr);
+        const int oh = rem / cpr, ow0 = (rem - oh * cpr) * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i >= my_loads) break;                                     // wave-uniform
+            const int j = wave + 9 * i;
+            const char *src = zero;
+            if (is_y[i]) {                                                // wave-uniform
+                if (ow0 + y_p[i] < W) src = (const char *)(gy + ((size_t)(b * H + oh) * W + ow0 + y_p[i]) * N + y_off[i]);
+            } else {
+                const int ih = oh + x_kr[i] - 1, iw = ow0 + x_px[i] - 1;
+                if (x_ok[i] & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W))
+                    src = (const char *)(x + ((size_t)(b * H + ih) * W + iw) * Cin + x_co[i]);
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(sb + j * 1024), 16, 0, 0);
+        }
+        ++issued;
+    };
+
+    f32x16 acc[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const int g = lane >> 4, t = lane & 15;
+    const int kh = wave / 3, kw = wave - kh * 3;
+    const int r_lo = 8 * (g >> 1) + (t >> 2), cw = 16 * (g & 1) + 4 * (t & 3);
+    const int x_base = ((kh * 34 + kw + r_lo) * 64) + cw * 2;             // byte offset of this lane's first transposed read in the patch
+    const int y_base = r_lo * 320 + cw * 2;
+
+#pragma unroll 1
+    for (int s = 0; s < WT_STAGES - 1; ++s)
+        if (s < steps) issue(s);
+#pragma unroll 1
+    for (int s = 0; s < steps; ++s) {
+        if (s + WT_STAGES - 2 < steps) {
+            if (my_loads == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WT_STAGES - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WT_STAGES - 2) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (s + WT_STAGES - 1 < steps) issue((s + WT_STAGES - 1) % WT_STAGES);
+        const char *Yb = wt_smem + (s % WT_STAGES) * WT_STAGE;
+        const char *Xb = Yb + WT_YB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            union { s16x4 h[2]; bf16x8 v; } bx;
+            bx.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(Xb + x_base + ks * 16 * 64));
+            bx.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(Xb + x_base + (ks * 16 + 4) * 64));
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                union { s16x4 h[2]; bf16x8 v; } ay;
+                ay.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(Yb + y_base + ks * 16 * 320 + i * 64));
+                ay.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(Yb + y_base + (ks * 16 + 4) * 320 + i * 64));
+                acc[i] = mma(ay.v, bx.v, acc[i]);
+            }
+        }
+    }
+
+    // ---- flush: D[row = n][col = c]; one register of a tile = two 128-byte row segments per wave instruction (full atomic rate)
+    const int fr = lane & 31, fh = lane >> 5;
+    const int c = c0 + fr;
+    if (c < Cin) {
+        const size_t kcol = (size_t)wave * Cin + c;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                unsafeAtomicAdd(dw + (size_t)n * K + kcol, d.scale ? acc[i][r] * d.scale[n] : acc[i][r]);
+            }
+    }
+}
+
 template <typename T>
 __global__ void weight_prep_kernel(const float *__restrict__ w, const float *__restrict__ rs, T *__restrict__ wf,
                                    T *__restrict__ wd, int N, int taps, int C) {
@@ -1564,6 +1725,17 @@ static bool dma_enabled() {
     return v == 1;
 }
 
+static int kpb_enabled() {                   // experiment switch GWD_IGEMM_KPB: 0/1 = one K tile per barrier; 2 = two, 64x64 tiles; 3 = + 128x128; 4 = + 128x64
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GWD_IGEMM_KPB");
+        v = e ? atoi(e) : 2;
+        if (v >= 2) v -= 1;                  // -> 1: 64x64, 2: + 128x128, 3: + 128x64
+        else v = 0;
+    }
+    return v;
+}
+
 // gwd_conv_desc.ln_mean != NULL: convolution with the ConvLn epilogue (dma_tile<..., LN>).  0 = launched, -4 = no fused kernel for the shape.
 static int launch_convln(const gwd_conv_desc *d, hipStream_t s) {
     const int M = d->B * d->Ho * d->Wo, N = d->Cout;
@@ -1664,18 +1836,21 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
         // register-staged kernel below: the 160-wide tiles stay gate-free, the gated variants lean
         if (dma_enabled() && d->zero_page && (d->Cin % 32) == 0 && (N % 8) == 0 && !(d->gate && (N % 160 == 0 || !lean))) {
             const int gmk = d->gather == GWD_GATHER_CONV ? 0 : ((d->gather == GWD_GATHER_TRANSPOSED && d->stride == 1) ? 1 : 2);
-#define DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, G_, L_)                                                    \
+#define DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, G_, L_, KPB_)                                              \
     switch (gmk) {                                                                                              \
-        case 0: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 0, false, false, G_, L_><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;   \
-        case 1: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 1, false, false, G_, L_><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;   \
-        default: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 2, false, false, G_, L_><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;  \
+        case 0: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 0, false, false, G_, L_, false, KPB_><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;   \
+        case 1: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 1, false, false, G_, L_, false, KPB_><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;   \
+        default: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 2, false, false, G_, L_, false, KPB_><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;  \
     }
-#define DMA_LAUNCH(BM_, BN_, WM_, WN_, ST_, GRID)                                                              \
-    if (BN_ % 160 != 0 && d->gate) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, (BN_ % 160 != 0), 0) }         \
-    else if (actk == 0) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, 0) }                               \
-    else if (actk == 1 && BN_ % 160 != 0) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, (BN_ % 160 != 0 ? 1 : -1)) } \
-    else if (actk == 2 && BN_ % 160 != 0) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, (BN_ % 160 != 0 ? 2 : -1)) } \
-    else { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, -1) }
+#define DMA_LAUNCH_K(BM_, BN_, WM_, WN_, ST_, GRID, KPB_)                                                      \
+    if (BN_ % 160 != 0 && d->gate) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, (BN_ % 160 != 0), 0, KPB_) }   \
+    else if (actk == 0) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, 0, KPB_) }                         \
+    else if (actk == 1 && BN_ % 160 != 0) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, (BN_ % 160 != 0 ? 1 : -1), KPB_) } \
+    else if (actk == 2 && BN_ % 160 != 0) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, (BN_ % 160 != 0 ? 2 : -1), KPB_) } \
+    else { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, -1, KPB_) }
+#define DMA_LAUNCH(BM_, BN_, WM_, WN_, ST_, GRID) DMA_LAUNCH_K(BM_, BN_, WM_, WN_, ST_, GRID, 1)
+            // two K tiles per barrier for the latency-bound small tiles (even number of K tiles; GWD_IGEMM_KPB=1: one, as in round 2)
+            const bool kpb2 = kpb_enabled() && ((d->KH * d->KW * (d->Cin / 32)) % 2) == 0;
             const bool big = big_tiles_enabled() && M >= 256 * 512;      // >= 2 workgroups per CU with 256-row tiles
             const unsigned gm2 = (M + 255) / 256;
             if (N % 160 == 0) {
@@ -1689,14 +1864,18 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
                 if (big) { DMA_LAUNCH(256, 128, 4, 2, 3, dim3(gm2 * ((N + 127) / 128))) }
                 else if ((int)t128 < small_thr) {
                     // fewer 128x128 tiles than CUs: quarter tiles put four times as many workgroups on the chip
-                    DMA_LAUNCH(64, 64, 2, 2, 4, dim3(((M + 63) / 64) * ((N + 63) / 64)))
-                } else { DMA_LAUNCH(128, 128, 2, 2, 3, dim3(t128)) }
+                    if (kpb2) { DMA_LAUNCH_K(64, 64, 2, 2, 6, dim3(((M + 63) / 64) * ((N + 63) / 64)), 2) }
+                    else { DMA_LAUNCH(64, 64, 2, 2, 4, dim3(((M + 63) / 64) * ((N + 63) / 64))) }
+                } else if (kpb2 && kpb_enabled() >= 2) { DMA_LAUNCH_K(128, 128, 2, 2, 4, dim3(t128), 2) }
+                else { DMA_LAUNCH(128, 128, 2, 2, 3, dim3(t128)) }
             } else if (N > 32) {
-                DMA_LAUNCH(128, 64, 2, 2, 4, dim3(gm))
+                if (kpb2 && kpb_enabled() >= 3) { DMA_LAUNCH_K(128, 64, 2, 2, 4, dim3(gm), 2) }
+                else { DMA_LAUNCH(128, 64, 2, 2, 4, dim3(gm)) }
             } else {
                 DMA_LAUNCH(128, 32, 4, 1, 4, dim3(gm))
             }
 #undef DMA_LAUNCH
+#undef DMA_LAUNCH_K
 #undef DMA_LAUNCH_G
             GWD_CHECK_LAUNCH();
             return 0;
@@ -1791,6 +1970,44 @@ struct WgradCollector {
     }
 };
 
+static int wgrad_taps_enabled() {            // A/B switch (GWD_WGRAD_TAPS=0: igemm_wgrad_dma_kernel<160,128> as in round 2)
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GWD_WGRAD_TAPS");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v;
+}
+// 1 = launched wgrad_taps_kernel
+static int launch_wgrad_taps(const gwd_conv_desc *d, float *dw, hipStream_t s) {
+    if (!wgrad_taps_enabled() || d->dtype != GWD_BF16 || !d->zero_page) return 0;
+    if (d->gather != GWD_GATHER_CONV || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->Hi || d->Wo != d->Wi) return 0;
+    if ((d->Cout % 160) || (d->Cin % 8) || d->Cin < 32) return 0;
+    const long M = (long)d->B * d->Ho * d->Wo;
+    if (M < 32768) return 0;                             // small maps: too few steps per workgroup to pay for the nine-tap flush
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    static bool attr = false;
+    constexpr int LDS = WT_STAGES * WT_STAGE;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)wgrad_taps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr = true;
+    }
+    const int tiles = ((d->Cin + 31) / 32) * (d->Cout / 160);
+    const int total = d->B * d->Ho * ((d->Wo + 31) / 32);
+    int splits = cus / tiles;
+    if (splits < 1) splits = 1;
+    int cps = (total + splits - 1) / splits;
+    if (cps < 8) cps = 8;
+    splits = (total + cps - 1) / cps;
+    const int wgs = tiles * splits;
+    wgrad_taps_kernel<<<wgs, 576, LDS, s>>>(*d, dw, cps, wgs);
+    return 1;
+}
+
 template <typename T>
 int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s, WgradCollector *coll = nullptr) {
     constexpr int RM = Cfg<T>::BK;
@@ -1814,6 +2031,10 @@ int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s, WgradCollecto
         else if (fast == 1) igemm_wgrad_dma_kernel<BN_, BK_, WN_, WK_, ST_, 1><<<grid, 256, 0, s>>>(*d, dw, m_per_block); \
         else igemm_wgrad_dma_kernel<BN_, BK_, WN_, WK_, ST_, 0><<<grid, 256, 0, s>>>(*d, dw, m_per_block);   \
     }
+            if (launch_wgrad_taps(d, dw, s)) {
+                GWD_CHECK_LAUNCH();
+                return 0;
+            }
             const int var = wgrad_variant();
             int fast = 0;
             if (d->gather == GWD_GATHER_CONV && d->stride == 1) {
