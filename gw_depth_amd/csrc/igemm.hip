@@ -976,6 +976,19 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const gwd_conv_desc d,
         __syncthreads();
     }
 
+    // the per-row multiplier first, in a pass of its own: a load between two atomics makes the compiler wait for vmcnt(0) - i.e. for
+    // every atomic issued so far - in front of each multiply, and the flush runs at one atomic per memory round trip
+    if (d.scale) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * (BNW / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const float sc = n < N ? d.scale[n] : 0.f;
+#pragma unroll
+                for (int j = 0; j < TK; ++j) acc[i][j][r] *= sc;
+            }
+    }
 #pragma unroll
     for (int j = 0; j < TK; ++j) {
         const int k = kb0 + wk * (BKW / 2) + j * 32 + fr;
@@ -985,7 +998,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const gwd_conv_desc d,
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * (BNW / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (n < N) unsafeAtomicAdd(dw + (size_t)n * K + k, d.scale ? acc[i][j][r] * d.scale[n] : acc[i][j][r]);
+                if (n < N) unsafeAtomicAdd(dw + (size_t)n * K + k, acc[i][j][r]);
             }
     }
 }
@@ -1191,6 +1204,20 @@ __device__ __forceinline__ void wgrad_dma_body(const gwd_conv_desc &d, float *__
     }
 
     const int fr = lane & 31, fh = lane >> 5;
+    // the per-row multiplier (folded FrozenBN) in a pass of its own, BEFORE the first atomic: a load between two atomics puts an
+    // s_waitcnt vmcnt(0) - a wait for every atomic issued so far - in front of each multiply, and the flush runs at one atomic per
+    // memory round trip (seen in the ISA in round 3; every BN-folded ResNet layer paid it)
+    if (d.scale) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * (BNW / WN) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const float sc = n < N ? d.scale[n] : 0.f;
+#pragma unroll
+                for (int j = 0; j < TK; ++j) acc[i][j][r] *= sc;
+            }
+    }
 #pragma unroll
     for (int j = 0; j < TK; ++j) {
         const int kcol = kb0 + wk * (BKW / WK) + j * 32 + fr;
@@ -1200,7 +1227,7 @@ __device__ __forceinline__ void wgrad_dma_body(const gwd_conv_desc &d, float *__
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * (BNW / WN) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (n < N) unsafeAtomicAdd(dw + (size_t)n * K + kcol, d.scale ? acc[i][j][r] * d.scale[n] : acc[i][j][r]);
+                if (n < N) unsafeAtomicAdd(dw + (size_t)n * K + kcol, acc[i][j][r]);
             }
     }
 }
@@ -1248,9 +1275,13 @@ __global__ __launch_bounds__(256) void igemm_wgrad_group_kernel(const WgradGroup
 // waves hold 80 accumulator registers each), a ring of WT_STAGES steps in dynamic LDS, counted vmcnt + one barrier per step.
 // The reduction over pixels is split over workgroups (tiles x splits ~ one per CU), fp32 atomics into the flat gradient.
 constexpr int WT_STAGES = 8, WT_YB = 10240, WT_XB = 7168, WT_STAGE = WT_YB + WT_XB;
-__global__ __launch_bounds__(576) void wgrad_taps_kernel(const gwd_conv_desc d, float *__restrict__ dw, const int chunks_per_split, const int wg_count) {
+// NB the body is a function of its own with a __restrict__ parameter ON PURPOSE: inlining it gives every memory access of the body
+// alias-scope metadata, and only with that does the compiler's wait-count pass accept that the transposed LDS reads do not alias the
+// LDS-DMA writes still in flight.  Without it an `s_waitcnt vmcnt(0)` lands in front of the first ds_read_b64_tr_b16 of every step and
+// the ring degenerates to ONE step in flight (read off the ISA after the first version ran at 1.35 us per step; wgrad_dma_body has
+// had this shape all along, by accident - plain LDS loads, as in dma_tile, are not affected).
+__device__ __forceinline__ void wgrad_taps_body(const gwd_conv_desc &d, float *__restrict__ dw, char *wt_smem, const int chunks_per_split, const int wg_count) {
     typedef __bf16 T;
-    extern __shared__ __attribute__((aligned(1024))) char wt_smem[];
     const int N = d.Cout, Cin = d.Cin, H = d.Ho, W = d.Wo, K = 9 * Cin;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;          // wave = tap
     const int tiles_c = (Cin + 31) / 32, tiles = tiles_c * (N / 160);
@@ -1266,46 +1297,62 @@ __global__ __launch_bounds__(576) void wgrad_taps_kernel(const gwd_conv_desc d, 
     const char *zero = (const char *)d.zero_page;
 
     // ---- this lane's part of the 17 DMA instructions of a step: wave w issues instructions w and w + 9 (wave 8: one only)
-    // j < 10: dY, 16-byte piece q = j * 64 + lane of the [32 pixels][160 channels] block; j >= 10: x patch, piece q of [102][4]
-    int y_p[2], y_off[2], x_kr[2], x_px[2], x_co[2];
-    bool is_y[2], x_ok[2];
+    // j < 10: dY, 16-byte piece q = j * 64 + lane of the [32 pixels][160 channels] block; j >= 10: x patch, piece q of [102][4].
+    // Everything that does not depend on the step is folded into per-lane element offsets here; the step's own coordinates
+    // (image, row, first column) live in scalar registers and advance by additions - the first version recomputed them with two
+    // integer divisions per wave and step, ~0.5 us of address arithmetic in front of every barrier (ablation: DMA + barrier alone
+    // 0.62 us per step, reads + MFMAs alone 0.62 us, together 1.05).
+    int l_off[2], l_dh[2], l_dw[2];
+    bool is_y[2], l_ok[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int j = wave + 9 * i;
         is_y[i] = j < 10;
         const int q = (is_y[i] ? j : j - 10) * 64 + lane;
-        y_p[i] = q / 20;
-        y_off[i] = n0 + (q - y_p[i] * 20) * 8;
-        const int pr = q >> 2;
-        x_kr[i] = pr / 34;
-        x_px[i] = pr - x_kr[i] * 34;
-        x_co[i] = c0 + (q & 3) * 8;
-        x_ok[i] = q < 408 && x_co[i] < Cin;
+        if (is_y[i]) {
+            const int p = q / 20;
+            l_dh[i] = 0;
+            l_dw[i] = p;                                                  // valid while ow0 + p < W
+            l_off[i] = p * N + n0 + (q - p * 20) * 8;
+            l_ok[i] = true;
+        } else {
+            const int pr = q >> 2, kr = pr / 34, px = pr - kr * 34, co = c0 + (q & 3) * 8;
+            l_dh[i] = kr - 1;
+            l_dw[i] = px - 1;
+            l_off[i] = ((kr - 1) * W + (px - 1)) * Cin + co;
+            l_ok[i] = q < 408 && co < Cin;
+        }
     }
     const int my_loads = wave < 8 ? 2 : 1;
     int issued = 0;
+    // coordinates of the next step to request (workgroup-uniform -> scalar registers)
+    int n_b = __builtin_amdgcn_readfirstlane(s0 / (H * cpr));
+    int n_oh = __builtin_amdgcn_readfirstlane((s0 - n_b * (H * cpr)) / cpr);
+    int n_ow = __builtin_amdgcn_readfirstlane((s0 - n_b * (H * cpr) - n_oh * cpr) * 32);
     auto issue = [&](int stage) {
         char *sb = wt_smem + stage * WT_STAGE;
-        const int ci = s0 + issued;
-        const int b = ci / (H * cpr);
-        const int rem = ci - b * (H * cpr);
-        const int oh = rem / cpr, ow0 = (rem - oh * cpr) * 32;
+        const size_t pix = (size_t)(n_b * H + n_oh) * W + n_ow;           // scalar
+        const T *y_row = gy + pix * N;
+        const T *x_row = x + pix * Cin;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (i >= my_loads) break;                                     // wave-uniform
             const int j = wave + 9 * i;
-            const char *src = zero;
-            if (is_y[i]) {                                                // wave-uniform
-                if (ow0 + y_p[i] < W) src = (const char *)(gy + ((size_t)(b * H + oh) * W + ow0 + y_p[i]) * N + y_off[i]);
-            } else {
-                const int ih = oh + x_kr[i] - 1, iw = ow0 + x_px[i] - 1;
-                if (x_ok[i] & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W))
-                    src = (const char *)(x + ((size_t)(b * H + ih) * W + iw) * Cin + x_co[i]);
-            }
+            const int ih = n_oh + l_dh[i], iw = n_ow + l_dw[i];
+            const bool ok = l_ok[i] & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
+            const char *src = ok ? (const char *)((is_y[i] ? y_row : x_row) + l_off[i]) : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(sb + j * 1024), 16, 0, 0);
         }
         ++issued;
+        n_ow += 32;
+        if (n_ow >= W) {
+            n_ow = 0;
+            if (++n_oh == H) {
+                n_oh = 0;
+                ++n_b;
+            }
+        }
     };
 
     f32x16 acc[5];
@@ -1320,39 +1367,60 @@ __global__ __launch_bounds__(576) void wgrad_taps_kernel(const gwd_conv_desc d, 
     const int x_base = ((kh * 34 + kw + r_lo) * 64) + cw * 2;             // byte offset of this lane's first transposed read in the patch
     const int y_base = r_lo * 320 + cw * 2;
 
+    // Software pipeline over the two 16-pixel halves of a step: while the MFMAs of one half run, the transposed reads of the next
+    // half (the second half of this step, or the first half of the NEXT step) are in flight - with 2-3 waves per SIMD nothing else
+    // covers the ds_read -> MFMA latency.  The barrier that certifies step s + 1 therefore sits in the MIDDLE of iteration s; the
+    // ring slot refilled behind it is the one of step s - 1, whose reads every wave finished before it got here.
+    typedef union { s16x4 h[2]; bf16x8 v; } Frag;
+    auto read_half = [&](int slot, int ks, Frag &bx, Frag (&ay)[5]) {
+        const char *Yb = wt_smem + slot * WT_STAGE;
+        const char *Xb = Yb + WT_YB;
+        bx.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(Xb + x_base + ks * 16 * 64));
+        bx.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(Xb + x_base + (ks * 16 + 4) * 64));
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            ay[i].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(Yb + y_base + ks * 16 * 320 + i * 64));
+            ay[i].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(Yb + y_base + (ks * 16 + 4) * 320 + i * 64));
+        }
+    };
+    auto certify = [&](int c) {                         // every wave's part of step c has landed (then: barrier)
+        // loads of steps c + 1 .. (last issued) may stay in flight; `issued` steps have been requested so far
+        const int younger = issued - 1 - c;
+        if (younger >= WT_STAGES - 3 && my_loads == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WT_STAGES - 3)) : "memory");
+        else if (younger >= WT_STAGES - 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WT_STAGES - 3) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
 #pragma unroll 1
-    for (int s = 0; s < WT_STAGES - 1; ++s)
+    for (int s = 0; s < WT_STAGES - 2; ++s)
         if (s < steps) issue(s);
+    certify(0);
+    if (WT_STAGES - 2 < steps) issue(WT_STAGES - 2);
+    Frag bx0, ay0[5], bx1, ay1[5];
+    read_half(0, 0, bx0, ay0);
 #pragma unroll 1
     for (int s = 0; s < steps; ++s) {
-        if (s + WT_STAGES - 2 < steps) {
-            if (my_loads == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WT_STAGES - 2)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WT_STAGES - 2) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        if (s + WT_STAGES - 1 < steps) issue((s + WT_STAGES - 1) % WT_STAGES);
-        const char *Yb = wt_smem + (s % WT_STAGES) * WT_STAGE;
-        const char *Xb = Yb + WT_YB;
+        read_half(s % WT_STAGES, 1, bx1, ay1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            union { s16x4 h[2]; bf16x8 v; } bx;
-            bx.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(Xb + x_base + ks * 16 * 64));
-            bx.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(Xb + x_base + (ks * 16 + 4) * 64));
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                union { s16x4 h[2]; bf16x8 v; } ay;
-                ay.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(Yb + y_base + ks * 16 * 320 + i * 64));
-                ay.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(Yb + y_base + (ks * 16 + 4) * 320 + i * 64));
-                acc[i] = mma(ay.v, bx.v, acc[i]);
-            }
+        for (int i = 0; i < 5; ++i) acc[i] = mma(ay0[i].v, bx0.v, acc[i]);
+        if (s + 1 < steps) {
+            certify(s + 1);
+            if (s + WT_STAGES - 1 < steps) issue((s + WT_STAGES - 1) % WT_STAGES);
+            read_half((s + 1) % WT_STAGES, 0, bx0, ay0);
         }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) acc[i] = mma(ay1[i].v, bx1.v, acc[i]);
     }
 
     // ---- flush: D[row = n][col = c]; one register of a tile = two 128-byte row segments per wave instruction (full atomic rate)
     const int fr = lane & 31, fh = lane >> 5;
     const int c = c0 + fr;
+    if (d.scale) {                                                        // before the first atomic: see wgrad_dma_body
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] *= d.scale[n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh];
+    }
     if (c < Cin) {
         const size_t kcol = (size_t)wave * Cin + c;
 #pragma unroll
@@ -1360,9 +1428,13 @@ __global__ __launch_bounds__(576) void wgrad_taps_kernel(const gwd_conv_desc d, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                unsafeAtomicAdd(dw + (size_t)n * K + kcol, d.scale ? acc[i][r] * d.scale[n] : acc[i][r]);
+                unsafeAtomicAdd(dw + (size_t)n * K + kcol, acc[i][r]);
             }
     }
+}
+__global__ __launch_bounds__(576) void wgrad_taps_kernel(const gwd_conv_desc d, float *__restrict__ dw, const int chunks_per_split, const int wg_count) {
+    extern __shared__ __attribute__((aligned(1024))) char wt_dyn_smem[];
+    wgrad_taps_body(d, dw, wt_dyn_smem, chunks_per_split, wg_count);
 }
 
 template <typename T>
@@ -1982,9 +2054,12 @@ static int wgrad_taps_enabled() {            // A/B switch (GWD_WGRAD_TAPS=0: ig
 static int launch_wgrad_taps(const gwd_conv_desc *d, float *dw, hipStream_t s) {
     if (!wgrad_taps_enabled() || d->dtype != GWD_BF16 || !d->zero_page) return 0;
     if (d->gather != GWD_GATHER_CONV || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->Hi || d->Wo != d->Wi) return 0;
-    if ((d->Cout % 160) || (d->Cin % 8) || d->Cin < 32) return 0;
+    // measured against igemm_wgrad_dma_kernel<160,128>, same box (tools/convbench.py): 800 -> 320 at 8x120x160 1.17 -> 0.81 ms, 160 -> 160
+    // 0.133 -> 0.114 ms; 80 -> 160 0.081 -> 0.085 and 160 -> 160 on a pooled 8x60x80 map 0.057 -> 0.070 (the nine-tap flush of a
+    // workgroup - 184 KB of atomics - needs enough steps to pay for itself): those stay where they were
+    if ((d->Cout % 160) || (d->Cin % 8) || d->Cin < 160) return 0;
     const long M = (long)d->B * d->Ho * d->Wo;
-    if (M < 32768) return 0;                             // small maps: too few steps per workgroup to pay for the nine-tap flush
+    if (M < 131072) return 0;
     static int cus = 0;
     if (!cus) {
         int dev = 0;

@@ -31,7 +31,7 @@ def timeit(fn, n=30):
 
 lib = hip.library()
 dt = torch.bfloat16
-tot = [0.0, 0.0]
+tot = [0.0, 0.0, 0.0, 0.0]
 print("GWD_IGEMM_KPB", os.environ.get("GWD_IGEMM_KPB", "default"))
 for (B, H, W, Ci, Co, K) in SHAPES:
     p = K // 2
@@ -44,7 +44,14 @@ for (B, H, W, Ci, Co, K) in SHAPES:
     fl = 2.0 * B * H * W * Co * K * K * Ci
     tf = timeit(lambda: lib.conv_forward(x, w, y, dims, stride=1, pad=p, act=hip.ACT_RELU))
     td = timeit(lambda: lib.conv_forward(y, wt, gx, (B, H, W, Co, H, W, Ci, K, K), stride=1, pad=p, gather=hip.GATHER_TRANSPOSED))
+    dw = torch.zeros(Co, K, K, Ci, device="cuda")
+    sc = torch.rand(Co, device="cuda") + 0.5
+    tw = timeit(lambda: lib.conv_wgrad(x, y, dw, dims, stride=1, pad=p))
+    tws = timeit(lambda: lib.conv_wgrad(x, y, dw, dims, stride=1, pad=p, scale=sc))
     tot[0] += tf
     tot[1] += td
-    print("%-30s fwd %6.1f us %6.1f TF/s | dgrad %6.1f us %6.1f TF/s" % (str((B, H, W, Ci, Co, K)), tf, fl / tf / 1e6, td, fl / td / 1e6), flush=True)
-print("sum fwd %.1f us, dgrad %.1f us" % tuple(tot))
+    tot[2] += tw
+    tot[3] += tws
+    print("%-30s fwd %6.1f us %6.1f TF/s | dgrad %6.1f us %6.1f TF/s | wgrad %6.1f us, with a FrozenBN scale %6.1f us" %
+          (str((B, H, W, Ci, Co, K)), tf, fl / tf / 1e6, td, fl / td / 1e6, tw, tws), flush=True)
+print("sum fwd %.1f us, dgrad %.1f us, wgrad %.1f us, wgrad (scale) %.1f us" % tuple(tot))
