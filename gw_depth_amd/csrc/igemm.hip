@@ -1828,9 +1828,9 @@ static int launch_convln(const gwd_conv_desc *d, hipStream_t s) {
             if (tail) LN_LAUNCH(256, 160, 8, 1, 3, true, (M + 255) / 256) else LN_LAUNCH(256, 160, 8, 1, 3, false, (M + 255) / 256)
             return 0;
         }
-        if (tail) return -4;
-        LN_LAUNCH(128, 160, 4, 1, 3, false, (M + 127) / 128)
-        return 0;
+        // smaller maps (the PSP branches on pooled maps) run 128 x 160 tiles at two waves per SIMD: the longer epilogue costs more than
+        // the separate LayerNorm launch there (8x30x40: 45.3 us as two launches, 49.5 us fused) - not fused
+        return -4;
     }
     if (tail) return -4;
     if (N <= 32) LN_LAUNCH(128, 32, 4, 1, 4, false, (M + 127) / 128)

@@ -198,9 +198,7 @@ LN_CASES = [
     ("pyr2_160_160_gelu", (8, 120, 160), 160, 160, 160, True, False, "<256,160,8,1,3,0,..,2,LN>: PyrBlock conv1 at 1/4 resolution"),
     ("pyr2_160_160_skip", (8, 120, 160), 160, 160, 160, False, True, "<256,160,..,0,LN> + residual after the normalisation: PyrBlock conv2"),
     ("pyr2_80_160_gelu_tail", (8, 120, 160), 80, 160, 160, True, False, "<256,160,..,TAIL,2,LN>: firstconv[2], Cin = 80"),
-    ("pyr2_ragged_rows", (3, 119, 161), 160, 160, 160, True, True, "M = 57 477: <128,160,4,1,3> with a ragged last tile, GELU and skip together"),
-    ("branch_160_160_pooled", (8, 30, 40), 160, 160, 160, True, False, "<128,160,4,1,3,0,..,LN>: PSP branch on a pooled map"),
-    ("branch_tiny_map", (8, 7, 10), 160, 160, 160, True, False, "M = 560: five tiles"),
+    ("pyr2_ragged_rows", (9, 119, 161), 160, 160, 160, True, True, "M = 172 431: <256,160,8,1,3> with a ragged last tile, GELU and skip together"),
     ("pyr1_64_64_padded_60", (8, 60, 80), 64, 64, 60, True, False, "<128,64,4,1,4,0,..,LN>: 60 real channels in 64-wide rows, padding written as zeros"),
     ("pyr1_64_64_padded_skip", (8, 60, 80), 64, 64, 60, False, True, "the same with the skip"),
     ("pyr1_32_32_padded_30", (8, 60, 80), 32, 32, 30, True, False, "<128,32,4,1,4,0,..,LN>: 30 real channels"),
