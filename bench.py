@@ -276,10 +276,13 @@ def main():
     roofline = None
     if rank == 0:
         roofline = dominant_kernel_roofline(lib, dtype)
-        try:                        # the same kernel INSIDE the step (cold operands, neighbours on the chip): one eager step under the tracer
-            roofline.update(in_step_kernel_time(step, batch, roofline["algorithmic_gflop_per_launch"], roofline["peak"]))
-        except Exception as exc:
-            roofline["in_step_error"] = repr(exc)
+        if world == 1:
+            try:                    # the same kernel INSIDE the step (cold operands, neighbours on the chip): one eager step with events
+                roofline.update(in_step_kernel_time(step, batch, roofline["algorithmic_gflop_per_launch"], roofline["peak"]))
+            except Exception as exc:
+                roofline["in_step_error"] = repr(exc)
+        # (N > 1: an extra step on rank 0 alone would issue the step's collectives with no partner - the other ranks are waiting at the
+        # final barrier - so the in-step figure is a one-GPU measurement only)
     out = {
         "metric": "images/sec (train fwd+bwd) %dx%d bs=%d/GPU" % (a.height, a.width, a.batch),     # BASELINE.json's metric at the defaults
         "value": round(ips, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

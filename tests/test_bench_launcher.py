@@ -21,7 +21,7 @@ def test_bench_gpus_2_over_gloo_prints_one_line_with_a_comm_block():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "1",
-                        "--height", "96", "--width", "128", "--no-cpu-baseline"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+                        "--height", "96", "--width", "128", "--no-cpu-baseline"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
