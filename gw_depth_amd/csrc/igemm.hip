@@ -394,12 +394,13 @@ __device__ __forceinline__ int xcd_band(int id, int total) {
 // layer runs 0.122 -> 0.108 ms (same-box, 3 runs each).  Gated launches are always lean (the dispatcher sends the rest elsewhere).
 // (ACTK: -1 = any activation, decided at run time, + the pre-activation copy; 0 = none = "lean"; 1 = ReLU, a single v_max - the
 // Bottleneck convolutions.)
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, int BK = 32>
 struct DmaTileCfg {
     static constexpr int NW = WM * WN;
-    static constexpr int B_INSTR = (BN + 15) / 16;
-    static constexpr int BROWS = B_INSTR * 16;
-    static constexpr int STAGE_BYTES = (BM + BROWS) * 64;
+    static constexpr int RPI = 1024 / (BK * 2);          // rows one 1 KiB DMA wave-instruction moves: 16 rows of 64 B, or 8 of 128 B
+    static constexpr int B_INSTR = (BN + RPI - 1) / RPI;
+    static constexpr int BROWS = B_INSTR * RPI;
+    static constexpr int STAGE_BYTES = (BM + BROWS) * BK * 2;
     static constexpr int EPI_BYTES = NW * 32 * 36 * 4 + NW * (BM / WM / 32) * 64 * 4;      // transposition patches + the ConvLn row statistics
     static constexpr int SMEM = STAGES * STAGE_BYTES > EPI_BYTES ? STAGES * STAGE_BYTES : EPI_BYTES;
 };
@@ -409,17 +410,24 @@ struct DmaTileCfg {
 // mostly empty last round dealt out 44 per workgroup as a tile in which only two wave rows compute.  0.112 -> 0.122 ms on the
 // 160 -> 160 layer, with or without the idle waves' tile traffic: a K step of such a tail costs ~1.1 us whatever it computes, 45
 // of them are more than the 0.035 ms the half-empty round costs.  DESIGN.md section 4.)
-template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT, bool TAIL, bool GATE, int ACTK, bool LN = false, int KPB = 1>
+// BK = 64 (round 3): a K tile of 64 channels makes every staged row piece a whole 128-byte line.  tools/ubench/piecerate.hip, L2-resident
+// source, 512 workgroups: 64-byte pieces fill LDS at 17.6 TB/s chip-wide, 128-byte pieces at 33.4 TB/s - and the small tiles of the mid-
+// size GEMMs (64 x 64: 32 FLOP per staged byte) are bound by exactly that rate (340 TF/s = 10.5 TB/s of fill on ResNet layer3).  Needs
+// Cin % 64 == 0; half as many barriers per reduction as a bonus.  Swizzle: 16-byte chunk c of row r sits at position c ^ ((r >> 1) & 7)
+// (the 16 lanes one ds_read_b128 cycle serves then hit 16 different 4-bank groups); BK = 32 keeps c ^ ((r >> 2) & 3).
+template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT, bool TAIL, bool GATE, int ACTK, bool LN = false, int KPB = 1, int BK = 32>
 __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, const int m0, const int n0) {
     typedef __bf16 T;
-    constexpr int BK = 32, NW = WM * WN;                 // 4 or 8 waves
+    constexpr int NW = WM * WN;                          // 4 or 8 waves
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int A_IT = (BM / 16) / NW;                 // one wave-instruction moves 16 rows x 64 B
-    constexpr int B_INSTR = (BN + 15) / 16;              // wave w issues B instructions w, w+NW, ...
+    constexpr int RPI = 1024 / (BK * 2), CPR = BK / 8;   // rows per 1 KiB DMA wave-instruction (16 | 8), 16-byte chunks per row (4 | 8)
+    constexpr int A_IT = (BM / RPI) / NW;
+    constexpr int B_INSTR = (BN + RPI - 1) / RPI;        // wave w issues B instructions w, w+NW, ...
     constexpr int B_IT = (B_INSTR + NW - 1) / NW;
     constexpr int B_FULL = B_INSTR % NW;                 // waves below this index issue B_IT, the others B_IT-1 (0: all B_IT)
-    constexpr int STAGE_BYTES = DmaTileCfg<BM, BN, WM, WN, STAGES>::STAGE_BYTES;
-    static_assert((BM / 16) % NW == 0 && TM >= 1 && TN >= 1, "tile / wave layout");
+    constexpr int STAGE_BYTES = DmaTileCfg<BM, BN, WM, WN, STAGES, BK>::STAGE_BYTES;
+    static_assert((BM / RPI) % NW == 0 && TM >= 1 && TN >= 1 && (BK == 32 || (BK == 64 && !TAIL && KPB == 1)), "tile / wave layout");
+    auto swz = [](int row) { return BK == 32 ? (row >> 2) & 3 : (row >> 1) & 7; };
 
     const int M = d.B * d.Ho * d.Wo, N = d.Cout, K = d.KH * d.KW * d.Cin;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -438,8 +446,8 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
     const int gstride = GM == 1 ? 1 : d.stride;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int row = 16 * (wave * A_IT + i) + (lane >> 2);
-        a_ck[i] = ((lane & 3) ^ ((row >> 2) & 3)) * 8;
+        const int row = RPI * (wave * A_IT + i) + lane / CPR;
+        a_ck[i] = ((lane % CPR) ^ swz(row)) * 8;
         const int m = m0 + row;
         a_ok[i] = m < M;
         const int mm = a_ok[i] ? m : 0;
@@ -465,8 +473,8 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
     const int my_b_loads = (B_FULL == 0 || wave < B_FULL) ? B_IT : B_IT - 1;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-        const int row = 16 * (wave + i * NW) + (lane >> 2);
-        const int ck = ((lane & 3) ^ ((row >> 2) & 3)) * 8;
+        const int row = RPI * (wave + i * NW) + lane / CPR;
+        const int ck = ((lane % CPR) ^ swz(row)) * 8;
         b_ck[i] = ck;
         const int n = n0 + row;
         b_ok[i] = row < BN && n < N;
@@ -486,7 +494,7 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
     // 32-channel halves of the group - a pixel's line is re-read for the next tap / half one or two tiles later, while
     // it is still in L2 (tap-outermost order has a reuse distance of Cin/32 tiles x every resident workgroup).
     int u_kh = 0, u_kw = 0, u_cb = 0, u_sub = 0, u_c0 = 0;  // workgroup-uniform state of the next tile to issue
-    int u_grp = d.Cin > 32 ? 2 : 1;                      // 32-channel tiles in the current group (the last one may be a partial tile: TAIL)
+    int u_grp = (BK == 64) ? 1 : (d.Cin > 32 ? 2 : 1);   // K tiles in the current 64-channel group (BK 32: two halves, the last may be a partial tile: TAIL)
     auto issue = [&](int stage) {
         char *sb = smem + stage * STAGE_BYTES;
 #pragma unroll
@@ -529,7 +537,7 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
                 if constexpr (TAIL) bok = bok & (u_c0 + b_ck[i] < d.Cin);
                 const char *src = bok ? b_src[i] + (size_t)((u_kh * d.KW + u_kw) * d.Cin + u_c0) * 2 : zero;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(sb + BM * 64 + (wave + i * NW) * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(sb + BM * BK * 2 + (wave + i * NW) * 1024), 16, 0, 0);
             }
         }
         if (++u_sub == u_grp) {
@@ -539,7 +547,7 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
                 if (++u_kh == d.KH) {
                     u_kh = 0;
                     u_cb += 64;
-                    u_grp = d.Cin - u_cb > 32 ? 2 : 1;
+                    u_grp = (BK == 64) ? 1 : (d.Cin - u_cb > 32 ? 2 : 1);
                 }
             }
         }
@@ -548,19 +556,19 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
     const int fr = lane & 31, fh = lane >> 5;
     auto compute = [&](int stage) {
         const T *As = (const T *)(smem + stage * STAGE_BYTES);
-        const T *Bs = (const T *)(smem + stage * STAGE_BYTES + BM * 64);
+        const T *Bs = (const T *)(smem + stage * STAGE_BYTES + BM * BK * 2);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8 af[TM], bfr[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int row = wm * (BM / WM) + i * 32 + fr;
-                af[i] = *(const bf16x8 *)(As + row * 32 + (((ks * 2 + fh) ^ ((row >> 2) & 3)) * 8));
+                af[i] = *(const bf16x8 *)(As + row * BK + (((ks * 2 + fh) ^ swz(row)) * 8));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int row = wn * (BN / WN) + j * 32 + fr;
-                bfr[j] = *(const bf16x8 *)(Bs + row * 32 + (((ks * 2 + fh) ^ ((row >> 2) & 3)) * 8));
+                bfr[j] = *(const bf16x8 *)(Bs + row * BK + (((ks * 2 + fh) ^ swz(row)) * 8));
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -795,15 +803,15 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
     }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false, bool TAIL = false, bool GATE = false, int ACTK = -1, bool LN = false, int KPB = 1>
+template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false, bool TAIL = false, bool GATE = false, int ACTK = -1, bool LN = false, int KPB = 1, int BK = 32>
 __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_desc d, const int tile_base, const int tile_count) {
-    __shared__ __attribute__((aligned(1024))) char smem[DmaTileCfg<BM, BN, WM, WN, STAGES>::SMEM];
+    __shared__ __attribute__((aligned(1024))) char smem[DmaTileCfg<BM, BN, WM, WN, STAGES, BK>::SMEM];
     const int n_tiles = (d.Cout + BN - 1) / BN;
     // this launch covers tiles tile_base .. tile_base + tile_count - 1 of the logical order.  (Cutting a big problem into a body of
     // whole rounds of 256-row tiles and a tail of 128-row tiles was measured in round 2: 0.125 -> 0.134 ms on the 160 -> 160
     // layer, the second launch and the lone waves of the tail cost more than the half-empty round they replace.)
     const int tile = tile_base + xcd_band(blockIdx.x, tile_count);             // column tiles of a row tile are adjacent
-    dma_tile<BM, BN, WM, WN, STAGES, GM, MULT, TAIL, GATE, ACTK, LN, KPB>(d, smem, (tile / n_tiles) * BM, (tile % n_tiles) * BN);
+    dma_tile<BM, BN, WM, WN, STAGES, GM, MULT, TAIL, GATE, ACTK, LN, KPB, BK>(d, smem, (tile / n_tiles) * BM, (tile % n_tiles) * BN);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1797,6 +1805,14 @@ static bool dma_enabled() {
     return v == 1;
 }
 
+static int bk64_level() {                    // experiment switch GWD_IGEMM_BK64: 0 = 32-channel K tiles everywhere; 1 = 64 for the 64x64 tiles; 2 = + 128x64; 3 = + 128x128
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GWD_IGEMM_BK64");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
 static int kpb_enabled() {                   // experiment switch GWD_IGEMM_KPB: 0/1 = one K tile per barrier; 2 = two, 64x64 tiles; 3 = + 128x128; 4 = + 128x64
     static int v = -1;
     if (v < 0) {
@@ -1921,6 +1937,20 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
     else if (actk == 2 && BN_ % 160 != 0) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, (BN_ % 160 != 0 ? 2 : -1), KPB_) } \
     else { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, -1, KPB_) }
 #define DMA_LAUNCH(BM_, BN_, WM_, WN_, ST_, GRID) DMA_LAUNCH_K(BM_, BN_, WM_, WN_, ST_, GRID, 1)
+#define DMA_LAUNCH_G64(BM_, BN_, WM_, WN_, ST_, GRID, G_, L_)                                                   \
+    switch (gmk) {                                                                                              \
+        case 0: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 0, false, false, G_, L_, false, 1, 64><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;   \
+        case 1: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 1, false, false, G_, L_, false, 1, 64><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;   \
+        default: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 2, false, false, G_, L_, false, 1, 64><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;  \
+    }
+#define DMA_LAUNCH_64(BM_, BN_, WM_, WN_, ST_, GRID)                                                           \
+    if (d->gate) { DMA_LAUNCH_G64(BM_, BN_, WM_, WN_, ST_, GRID, true, 0) }                                     \
+    else if (actk == 0) { DMA_LAUNCH_G64(BM_, BN_, WM_, WN_, ST_, GRID, false, 0) }                             \
+    else if (actk == 1) { DMA_LAUNCH_G64(BM_, BN_, WM_, WN_, ST_, GRID, false, 1) }                             \
+    else if (actk == 2) { DMA_LAUNCH_G64(BM_, BN_, WM_, WN_, ST_, GRID, false, 2) }                             \
+    else { DMA_LAUNCH_G64(BM_, BN_, WM_, WN_, ST_, GRID, false, -1) }
+            // 64-channel K tiles (whole 128-byte lines per staged row piece) where every tap is a whole number of them
+            const int bk64 = (d->Cin % 64) == 0 ? bk64_level() : 0;
             // two K tiles per barrier for the latency-bound small tiles (even number of K tiles; GWD_IGEMM_KPB=1: one, as in round 2)
             const bool kpb2 = kpb_enabled() && ((d->KH * d->KW * (d->Cin / 32)) % 2) == 0;
             const bool big = big_tiles_enabled() && M >= 256 * 512;      // >= 2 workgroups per CU with 256-row tiles
@@ -1936,17 +1966,22 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
                 if (big) { DMA_LAUNCH(256, 128, 4, 2, 3, dim3(gm2 * ((N + 127) / 128))) }
                 else if ((int)t128 < small_thr) {
                     // fewer 128x128 tiles than CUs: quarter tiles put four times as many workgroups on the chip
-                    if (kpb2) { DMA_LAUNCH_K(64, 64, 2, 2, 6, dim3(((M + 63) / 64) * ((N + 63) / 64)), 2) }
+                    if (bk64 >= 1) { DMA_LAUNCH_64(64, 64, 2, 2, 3, dim3(((M + 63) / 64) * ((N + 63) / 64))) }
+                    else if (kpb2) { DMA_LAUNCH_K(64, 64, 2, 2, 6, dim3(((M + 63) / 64) * ((N + 63) / 64)), 2) }
                     else { DMA_LAUNCH(64, 64, 2, 2, 4, dim3(((M + 63) / 64) * ((N + 63) / 64))) }
-                } else if (kpb2 && kpb_enabled() >= 2) { DMA_LAUNCH_K(128, 128, 2, 2, 4, dim3(t128), 2) }
+                } else if (bk64 >= 3) { DMA_LAUNCH_64(128, 128, 2, 2, 2, dim3(t128)) }
+                else if (kpb2 && kpb_enabled() >= 2) { DMA_LAUNCH_K(128, 128, 2, 2, 4, dim3(t128), 2) }
                 else { DMA_LAUNCH(128, 128, 2, 2, 3, dim3(t128)) }
             } else if (N > 32) {
-                if (kpb2 && kpb_enabled() >= 3) { DMA_LAUNCH_K(128, 64, 2, 2, 4, dim3(gm), 2) }
+                if (bk64 >= 2) { DMA_LAUNCH_64(128, 64, 2, 2, 2, dim3(gm)) }
+                else if (kpb2 && kpb_enabled() >= 3) { DMA_LAUNCH_K(128, 64, 2, 2, 4, dim3(gm), 2) }
                 else { DMA_LAUNCH(128, 64, 2, 2, 4, dim3(gm)) }
             } else {
                 DMA_LAUNCH(128, 32, 4, 1, 4, dim3(gm))
             }
 #undef DMA_LAUNCH
+#undef DMA_LAUNCH_64
+#undef DMA_LAUNCH_G64
 #undef DMA_LAUNCH_K
 #undef DMA_LAUNCH_G
             GWD_CHECK_LAUNCH();
