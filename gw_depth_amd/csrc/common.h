@@ -30,6 +30,38 @@ __device__ __forceinline__ float gelu_grad_f(float v) {
     return cdf + v * pdf;
 }
 
+// GELU for the bf16 kernels: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, four orders below bf16's rounding) - one exp, one
+// reciprocal and a degree-5 polynomial instead of erff's ~40 instructions; the exponential is shared with the density in the
+// gradient.  The activation-backward + bias-gradient pass and the GELU LayerNorm kernels were VALU-bound on erff + expf (DESIGN.md
+// section 5).  The fp32 parity mode keeps erff (gelu_f / gelu_grad_f): gelu_t<T> picks.
+__device__ __forceinline__ void gelu_parts_fast(float v, float &cdf, float &pdf_e) {
+    const float x = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);
+    const float e = __expf(-0.5f * v * v);                // = exp(-x^2)
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * e;
+    cdf = 0.5f + (v < 0.f ? -0.5f : 0.5f) * erf_abs;
+    pdf_e = e;
+}
+__device__ __forceinline__ float gelu_fast(float v) {
+    float cdf, e;
+    gelu_parts_fast(v, cdf, e);
+    return v * cdf;
+}
+__device__ __forceinline__ float gelu_grad_fast(float v) {
+    float cdf, e;
+    gelu_parts_fast(v, cdf, e);
+    return cdf + v * 0.39894228040143267794f * e;
+}
+template <typename T> __device__ __forceinline__ float gelu_t(float v) {
+    if constexpr (std::is_same<T, float>::value) return gelu_f(v);
+    else return gelu_fast(v);
+}
+template <typename T> __device__ __forceinline__ float gelu_grad_t(float v) {
+    if constexpr (std::is_same<T, float>::value) return gelu_grad_f(v);
+    else return gelu_grad_fast(v);
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case GWD_ACT_RELU: return v > 0.f ? v : 0.f;

@@ -711,7 +711,7 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             t[e] = (v[e] - m_) * rs * sc[e] + sh[e];
-                            if (ACTK == 2) t[e] = gelu_f(t[e]);
+                            if (ACTK == 2) t[e] = gelu_fast(t[e]);
                         }
                         if (res) {
                             const bf16x8 rv = *(const bf16x8 *)(res + o);
@@ -794,7 +794,7 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
                         }
 #pragma unroll
                         for (int e = 0; e < 8; ++e)
-                            out[e] = (__bf16)((ACTK == 0 ? v[e] : (ACTK == 1 ? (v[e] > 0.f ? v[e] : 0.f) : (ACTK == 2 ? gelu_f(v[e]) : apply_act(v[e], d.act)))) * gm[e]);
+                            out[e] = (__bf16)((ACTK == 0 ? v[e] : (ACTK == 1 ? (v[e] > 0.f ? v[e] : 0.f) : (ACTK == 2 ? gelu_fast(v[e]) : apply_act(v[e], d.act)))) * gm[e]);
                     }
                     *(bf16x8 *)(y + o) = out;
                 }

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(NT) void inorm_gelu_fwd_kernel(const T *__restrict_
         load_vec(a + off + l * C, av);
         load_vec(u + off + l * C, uv);
 #pragma unroll
-        for (int i = 0; i < VN; ++i) av[i] += gelu_f((uv[i] - mean[i]) * rstd[i]);
+        for (int i = 0; i < VN; ++i) av[i] += gelu_t<T>((uv[i] - mean[i]) * rstd[i]);
         store_vec(y + off + l * C, av);
     }
 }
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(NT) void inorm_gelu_bwd_sums_kernel(const T *__rest
         load_vec(u + off + l * C, uv);
 #pragma unroll
         for (int i = 0; i < VN; ++i) {
-            const float n = (uv[i] - mean[i]) * rstd[i], gn = gv[i] * gelu_grad_f(n);
+            const float n = (uv[i] - mean[i]) * rstd[i], gn = gv[i] * gelu_grad_t<T>(n);
             s1[i] += gn;
             s2[i] += gn * n;
         }
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(NT) void inorm_gelu_bwd_kernel(const T *__restrict_
         load_vec(u + off + l * C, uv);
 #pragma unroll
         for (int i = 0; i < VN; ++i) {
-            const float n = (uv[i] - mean[i]) * rstd[i], gn = gv[i] * gelu_grad_f(n);
+            const float n = (uv[i] - mean[i]) * rstd[i], gn = gv[i] * gelu_grad_t<T>(n);
             gv[i] = rstd[i] * (gn - m1[i] - n * m2[i]);
         }
         store_vec(du + off + l * C, gv);

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T *__restrict_
             if (i < per && c < C) {
                 float o = (v[i] - mu) * rs;
                 if (gamma) o = o * gamma[c] + beta[c];
-                if (gelu) o = gelu_f(o);
+                if (gelu) o = gelu_t<T>(o);
                 if (res) o += to_f32(res[r * C + c]);
                 yr[c] = from_f32<T>(o);
             }
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T *__restrict_
             const bool ok = i < per && c < C;
             xh[i] = ok ? (to_f32(xr[c]) - mu) * rs : 0.f;
             float g = ok ? to_f32(gr[c]) : 0.f;
-            if (gelu) g *= gelu_grad_f(xh[i] * gm[i] + bt[i]);
+            if (gelu) g *= gelu_grad_t<T>(xh[i] * gm[i] + bt[i]);
             ag[i] += g * xh[i];
             ab[i] += g;
             gw[i] = g * gm[i];
@@ -254,7 +254,7 @@ __global__ void act_bwd_kernel(const T *__restrict__ gy, const T *__restrict__ r
         const float rv = ref ? to_f32(ref[i]) : 0.f;
         switch (act) {
             case GWD_ACT_RELU: g = rv > 0.f ? g : 0.f; break;
-            case GWD_ACT_GELU: g *= gelu_grad_f(rv); break;
+            case GWD_ACT_GELU: g *= gelu_grad_t<T>(rv); break;
             case GWD_ACT_ELU: g *= (rv > 0.f ? 1.0f : rv / act_scale + 1.0f); break;
             case GWD_ACT_SIGMOID: {
                 const float sg = rv / act_scale;
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T *__restr
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 float o = (v[c][e] - mu) * rs * g[c][e] + b[c][e];
-                if (GELU) o = gelu_f(o);         // compile-time: the erf code is not in the plain kernels
+                if (GELU) o = gelu_t<T>(o);         // compile-time: the erf code is not in the plain kernels
                 if (res) o += to_f32(pr[e]);
                 if (PAD && (sub + c * LPR) * VEC + e >= C) o = 0.f;
                 outv[e] = from_f32<T>(o);
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(NWV * 64) void layernorm_bwd_vec_kernel(const T *__
                 const bool ok = okv && (!PAD || (sub + c * LPR) * VEC + e < C);
                 xh[c][e] = ok ? (to_f32(px[e]) - mu) * rs : 0.f;
                 float gg = ok ? to_f32(pg[e]) : 0.f;
-                if (GELU) gg *= gelu_grad_f(xh[c][e] * g[c][e] + b[c][e]);     // compile-time (bit 0 of the flags): no erf / exp code in the plain kernels
+                if (GELU) gg *= gelu_grad_t<T>(xh[c][e] * g[c][e] + b[c][e]);     // compile-time (bit 0 of the flags): no erf / exp code in the plain kernels
                 ag[c][e] += gg * xh[c][e];
                 ab[c][e] += gg;
                 gw[c][e] = gg * g[c][e];
@@ -581,7 +581,7 @@ __global__ void act_bwd_vec_kernel(const T *__restrict__ gy, const T *__restrict
             const float rv = to_f32(pr[e]);
             switch (act) {
                 case GWD_ACT_RELU: g = rv > 0.f ? g : 0.f; break;
-                case GWD_ACT_GELU: g *= gelu_grad_f(rv); break;
+                case GWD_ACT_GELU: g *= gelu_grad_t<T>(rv); break;
                 case GWD_ACT_ELU: g *= (rv > 0.f ? 1.0f : rv / act_scale + 1.0f); break;
                 case GWD_ACT_SIGMOID: {
                     const float sg = rv / act_scale;
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const T *__restrict
                 const float rv = to_f32(pr[e]);
                 switch (act) {
                     case GWD_ACT_RELU: g = rv > 0.f ? g : 0.f; break;
-                    case GWD_ACT_GELU: g *= gelu_grad_f(rv); break;
+                    case GWD_ACT_GELU: g *= gelu_grad_t<T>(rv); break;
                     case GWD_ACT_ELU: g *= (rv > 0.f ? 1.0f : rv / act_scale + 1.0f); break;
                     case GWD_ACT_SIGMOID: {
                         const float sg = rv / act_scale;

