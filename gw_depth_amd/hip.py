@@ -32,7 +32,7 @@ ENTRY_POINTS = [
     "gwd_plane_loss_forward", "gwd_plane_loss_backward", "gwd_collate",
     "gwd_anchor_depth_forward", "gwd_anchor_depth_backward", "gwd_mha_flash_forward", "gwd_mha_flash_backward",
     "gwd_ref_scores_forward", "gwd_ref_scores_backward", "gwd_ref_mix_forward", "gwd_ref_mix_backward", "gwd_unpad_add_batch", "gwd_stem_pack", "gwd_stem_forward", "gwd_pos_sine", "gwd_silog_finalize", "gwd_psp_pool_forward", "gwd_psp_pool_backward",
-    "gwd_match_cost", "gwd_set_losses_forward", "gwd_set_losses_backward", "gwd_resample_u8_pass", "gwd_gather2d", "gwd_point_sample_backward_gather", "gwd_stride_place", "gwd_color_adjust",
+    "gwd_match_cost", "gwd_set_losses_forward", "gwd_set_losses_backward", "gwd_resample_u8_pass", "gwd_gather2d", "gwd_point_sample_backward_gather", "gwd_stride_place", "gwd_color_adjust", "gwd_bmm",
 ]
 
 
@@ -48,6 +48,14 @@ class ConvDesc(ctypes.Structure):
                                               "gather", "Hv", "Wv", "act")] + \
                [("act_scale", ctypes.c_float), ("dtype", ctypes.c_int32), ("gate_act", ctypes.c_int32),
                 ("ln_mean", ctypes.c_void_p), ("ln_rstd", ctypes.c_void_p), ("ln_C", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class BmmDesc(ctypes.Structure):
+    """gwd_bmm_desc (include/gwdepth.h)."""
+    _fields_ = [("a", ctypes.c_void_p), ("b", ctypes.c_void_p), ("c", ctypes.c_void_p)] + \
+               [(n, ctypes.c_int64) for n in ("a_sb0", "a_sb1", "a_ld", "b_sb0", "b_sb1", "b_ld", "c_sb0", "c_sb1", "c_ld")] + \
+               [(n, ctypes.c_int32) for n in ("M", "N", "K", "nb0", "nb1", "a_kmajor", "b_kmajor", "c_is_f32_accumulate", "splits")] + \
+               [("alpha", ctypes.c_float), ("dtype", ctypes.c_int32)]
 
 
 class PrepJob(ctypes.Structure):
@@ -175,6 +183,7 @@ class HipLibrary:
         L.gwd_set_losses_forward.argtypes = [vp] * 9 + [f32] + [vp] * 4 + [i32] * 6 + [vp]
         L.gwd_set_losses_backward.argtypes = [vp] * 8 + [f32] + [vp] * 6 + [i32] * 6 + [vp]
         L.gwd_color_adjust.argtypes = [vp, vp, vp, i64, i32, f32, vp]
+        L.gwd_bmm.argtypes = [ctypes.POINTER(BmmDesc), vp]
         L.gwd_stride_place.argtypes = [vp, vp, vp] + [i32] * 8 + [vp]
         L.gwd_psp_pool_forward.argtypes = [vp] * 5 + [i32] * 5 + [vp]
         L.gwd_psp_pool_backward.argtypes = [vp] * 6 + [i32] * 6 + [vp]
@@ -628,6 +637,27 @@ class HipLibrary:
         self._check(self.lib.gwd_certain_sample(_ptr(small), _ptr(large), _ptr(coords), B, hs, ws, H, W, _ptr(edges),
                                                 edges.numel() - 1, sample_num, self._stream(small, large, coords)),
                     "gwd_certain_sample")
+
+    def bmm(self, a, b, c, M, N, K, a_kmajor=False, b_kmajor=False, alpha=1.0, accumulate=False, splits=1):
+        """c[b0][b1] (M x N) = alpha * A (M x K) @ B (N x K)^T over two batch dims (gwd_bmm).  a, b, c: 4-D tensors / views with unit
+        inner stride, dims (b0, b1, outer, inner); an operand is (rows, K) - or (K, rows) when *_kmajor.  A batch dim of size 1 in a
+        or b broadcasts.  accumulate: c is fp32 and is ADDED to (required for splits > 1)."""
+        for t in (a, b, c):
+            if t.dim() != 4 or t.stride(3) != 1:
+                raise ValueError("bmm: 4-D operands with unit inner stride expected")
+        nb0, nb1 = c.shape[0], c.shape[1]
+        d = BmmDesc()
+        d.a, d.b, d.c = a.data_ptr(), b.data_ptr(), c.data_ptr()
+        bs = lambda t, i: 0 if t.shape[i] == 1 else t.stride(i)
+        d.a_sb0, d.a_sb1, d.a_ld = bs(a, 0), bs(a, 1), a.stride(2)
+        d.b_sb0, d.b_sb1, d.b_ld = bs(b, 0), bs(b, 1), b.stride(2)
+        d.c_sb0, d.c_sb1, d.c_ld = c.stride(0), c.stride(1), c.stride(2)
+        d.M, d.N, d.K, d.nb0, d.nb1 = M, N, K, nb0, nb1
+        d.a_kmajor, d.b_kmajor, d.c_is_f32_accumulate, d.splits = int(a_kmajor), int(b_kmajor), int(accumulate), int(splits)
+        if accumulate and c.dtype != torch.float32:
+            raise ValueError("bmm: an accumulated result is fp32")
+        d.alpha, d.dtype = float(alpha), dtype_code(a)
+        self._check(self.lib.gwd_bmm(ctypes.byref(d), self._stream(a, b, c)), "gwd_bmm")
 
     COLOR_MODES = {"brightness": 0, "contrast": 1, "saturation": 2, "hue": 3}
 

@@ -259,9 +259,10 @@ class MultiheadAttention(nn.Module):
             k = k.reshape(B, S, H, hd).transpose(1, 2)
             v = v.reshape(B, S, H, hd).transpose(1, 2)
             # q * scaling and masked_fill(-inf) (multi_head_attention.py:329-352) are folded into the softmax kernel
-            att = ops.attention_softmax(q @ k.transpose(-2, -1), key_padding_mask, scale)
+            own = q.is_cuda                   # gwd_bmm on the strided head views (exact fp32 MFMA); the CPU stand-in of the tests uses torch
+            att = ops.attention_softmax(ops.matmul_nt(q, k) if own else q @ k.transpose(-2, -1), key_padding_mask, scale)
             att = att * amult if amult is not None else F.dropout(att, self.dropout, self.training)
-            fused = (att @ v).transpose(1, 2).reshape(B, L, E)
+            fused = (ops.matmul_nn(att, v) if own else att @ v).transpose(1, 2).reshape(B, L, E)
         # bf16: one matrix-core kernel each way, no L x S tensor, no head split / merge copies
         return self.out_proj(fused, residual=residual, mult=out_mult)
 
@@ -699,7 +700,10 @@ class PointBasedPred(nn.Module):
         Sp = self.pyramid.padded_width(xg)                   # S, or S rounded up to 32: zero rows in `refer` = zero channels of the map
         if Sp != S:
             refer = F.pad(refer, (0, 0, 0, Sp - S))
-        rg = torch.bmm(xg, refer.transpose(1, 2).to(xg.dtype)) * (self.dim ** -2)       # (B, HW, S) = pixel-major map
+        if xg.is_cuda:                                       # own batched GEMM (gwd_bmm): no vendor library on the path
+            rg = ops.matmul_nt(xg, refer.to(xg.dtype), alpha=self.dim ** -2)            # (B, HW, S) = pixel-major map
+        else:
+            rg = torch.bmm(xg, refer.transpose(1, 2).to(xg.dtype)) * (self.dim ** -2)
         # NB: when H or W < 16 the pyramid zero-pads its map and the reference keeps the padded size (:94-125)
         logits = self.pyramid(rg.view(B, H, W, -1))
         att = ops.softmax_lastdim(logits if Sp == S else logits[..., :S])
@@ -707,7 +711,7 @@ class PointBasedPred(nn.Module):
         if R <= 256 and os.environ.get("GWD_ANCHOR_FUSED", "1") != "0":
             pred = ops.anchor_depth(att.view(B, Ho * Wo, R), anchor.view(B, R))          # sum_r att * anchor depth, one pass
         else:
-            pred = torch.bmm(att.float().view(B, Ho * Wo, R), anchor.view(B, R, 1))
+            pred = (ops.matmul_nn if att.is_cuda else torch.bmm)(att.float().view(B, Ho * Wo, R), anchor.view(B, R, 1))
         return pred.view(B, 1, Ho, Wo)                                                  # (B,1,H',W') fp32
 
 

@@ -830,6 +830,84 @@ def conv_ln_fused_enabled():
     return os.environ.get("GWD_CONVLN", "1") != "0"
 
 
+def _as4(t):
+    """(..., rows, cols) tensor -> a 4-D (b0, b1, rows, cols) view with unit inner stride (a copy only when the inner stride is not 1)."""
+    if t.stride(-1) != 1:
+        t = t.contiguous()
+    while t.dim() < 4:
+        t = t.unsqueeze(0)
+    if t.dim() > 4:
+        t = t.reshape(-1, *t.shape[-3:])
+    return t
+
+
+def _bmm_raw(a, a_km, b, b_km, M, N, K, alpha=1.0, out_dtype=None, splits=1):
+    """alpha * A @ B^T with A (M x K), B (N x K) given as 4-D views, either possibly k-major; batch dims broadcast from size 1."""
+    nb0, nb1 = max(a.shape[0], b.shape[0]), max(a.shape[1], b.shape[1])
+    acc = splits > 1
+    c = (torch.zeros if acc else torch.empty)((nb0, nb1, M, N), dtype=torch.float32 if acc else a.dtype, device=a.device)
+    _lib().bmm(a, b, c, M, N, K, a_kmajor=a_km, b_kmajor=b_km, alpha=alpha, accumulate=acc, splits=splits)
+    return c if (out_dtype is None or c.dtype == out_dtype) else c.to(out_dtype)
+
+
+def _bmm_splits(M, N, K, batches):
+    """Workgroups along the reduction when the tiles alone leave the chip idle (d refer = d rg^T @ xg: 19 200 pixels onto 80 x 64)."""
+    tiles = ((M + 63) // 64) * ((N + 63) // 64) * batches
+    if tiles >= 256 or K < 2048:
+        return 1
+    return max(1, min(K // 512, 512 // tiles))
+
+
+class _MatmulFn(torch.autograd.Function):
+    """alpha * a @ b^T (trans_b) or alpha * a @ b over leading batch dims, forward and both gradients on gwd_bmm - strided operands,
+    no transposed copies.  a (..., M, K); b (..., N, K) when trans_b else (..., K, N); batch dims of a and b equal (or 1: broadcast)."""
+
+    @staticmethod
+    def forward(ctx, a, b, trans_b, alpha):
+        a4, b4 = _as4(a), _as4(b)
+        M, K = a4.shape[-2:]
+        N = b4.shape[-2] if trans_b else b4.shape[-1]
+        c = _bmm_raw(a4, False, b4, not trans_b, M, N, K, alpha)
+        ctx.save_for_backward(a4, b4)
+        ctx.cfg = (trans_b, alpha, a.shape, b.shape, M, N, K)
+        lead = torch.broadcast_shapes(a.shape[:-2], b.shape[:-2])
+        return c.reshape(*lead, M, N)
+
+    @staticmethod
+    def backward(ctx, gc):
+        a4, b4 = ctx.saved_tensors
+        trans_b, alpha, ashape, bshape, M, N, K = ctx.cfg
+        g4 = _as4(gc)
+        ga = gb = None
+        batches = g4.shape[0] * g4.shape[1]
+        if ctx.needs_input_grad[0]:
+            # d a (M x K) = alpha * gc (M x N) @ B'^T, B' (K x N): b (N x K) is k-major for it, b (K x N) is not
+            ga = _bmm_raw(g4, False, b4, trans_b, M, K, N, alpha)
+            if a4.shape[0] != g4.shape[0] or a4.shape[1] != g4.shape[1]:
+                ga = ga.sum(dim=[i for i in (0, 1) if a4.shape[i] != g4.shape[i]], keepdim=True)
+            ga = ga.reshape(ashape)
+        if ctx.needs_input_grad[1]:
+            sp = _bmm_splits(N if trans_b else K, K if trans_b else N, M, batches)
+            if trans_b:       # d b (N x K) = alpha * gc^T (N x M) @ a'^T with a' (K x M): both k-major (the reduction runs over M)
+                gb = _bmm_raw(g4, True, a4, True, N, K, M, alpha, out_dtype=b4.dtype, splits=sp)
+            else:             # d b (K x N) = alpha * a^T (K x M) @ gc'^T with gc' (N x M): both k-major
+                gb = _bmm_raw(a4, True, g4, True, K, N, M, alpha, out_dtype=b4.dtype, splits=sp)
+            if b4.shape[0] != g4.shape[0] or b4.shape[1] != g4.shape[1]:
+                gb = gb.sum(dim=[i for i in (0, 1) if b4.shape[i] != g4.shape[i]], keepdim=True)
+            gb = gb.reshape(bshape)
+        return ga, gb, None, None
+
+
+def matmul_nt(a, b, alpha=1.0):
+    """alpha * a @ b.transpose(-1, -2) on the library's own batched GEMM (gwd_bmm)."""
+    return _MatmulFn.apply(a, b, True, float(alpha))
+
+
+def matmul_nn(a, b, alpha=1.0):
+    """alpha * a @ b on the library's own batched GEMM (gwd_bmm)."""
+    return _MatmulFn.apply(a, b, False, float(alpha))
+
+
 class _SoftmaxFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

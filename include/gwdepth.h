@@ -518,6 +518,25 @@ int gwd_gather2d(const void *src, void *dst, const int32_t *ytab, const int32_t 
  * entry point: not meant for HIP-graph capture (mode 1 clears its scratch with a memset node).                                     */
 int gwd_color_adjust(const uint8_t *rgb, uint8_t *out, uint64_t *scratch, int64_t npix, int32_t mode, float factor, void *stream);
 
+/* Strided batched GEMM  C[b0][b1] (M x N) = alpha * A[b0][b1] (M x K) * B[b0][b1] (N x K)^T  (csrc/bmm.hip).
+ * Every operand has inner stride 1; a_ld / b_ld / c_ld are the element strides of the outer matrix dimension, *_sb0 / *_sb1 those of
+ * the two batch dimensions (0 broadcasts an operand over a batch dimension).  a_kmajor / b_kmajor: the operand is stored [k][row]
+ * (k is the outer dimension) instead of [row][k] - with these the gradients of a product need no transposed copies.
+ * c_is_f32_accumulate: C is fp32 whatever `dtype` says and the result is ADDED to it (fp32 atomics; the caller zeroes it); required
+ * for splits > 1, which cuts the reduction over K into `splits` workgroups per tile (long reductions onto a small result).
+ * Replaces torch.bmm of the point heads (src/models/points/points_sample.py:271-279) and, in the fp32 parity mode, the two attention
+ * products of src/models/multi_head_attention.py:347-371 (exact fp32: v_mfma_f32_32x32x2_f32).                                   */
+typedef struct {
+    const void *a, *b;
+    void *c;
+    int64_t a_sb0, a_sb1, a_ld, b_sb0, b_sb1, b_ld, c_sb0, c_sb1, c_ld;
+    int32_t M, N, K, nb0, nb1;
+    int32_t a_kmajor, b_kmajor, c_is_f32_accumulate, splits;
+    float alpha;
+    int32_t dtype;        /* GWD_F32 / GWD_BF16 of a, b (and of c unless c_is_f32_accumulate) */
+} gwd_bmm_desc;
+int gwd_bmm(const gwd_bmm_desc *d, void *stream);
+
 #define GWD_COLLATE_BATCH 16
 typedef struct {
     const void *rgb, *depth_mm, *labels;

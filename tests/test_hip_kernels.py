@@ -1249,3 +1249,58 @@ def test_compile_time_activation_variants_of_every_tile_family(dev, tile, act):
         assert rel(got, want) < TOL[dt], gather
         if zg is not None:
             assert rel(zg, zw) < TOL[dt], gather
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# gwd_bmm: the library's own strided batched GEMM (point-head affinity maps, fp32-mode attention products) against torch.matmul
+BMM_CASES = [
+    # name, a shape, b shape, trans_b, dtype, tol
+    ("affinity_1/4", (8, 19200, 64), (8, 80, 64), True, torch.bfloat16, 1.5e-2),
+    ("affinity_1/8_padded", (8, 4800, 128), (8, 32, 128), True, torch.bfloat16, 1.5e-2),
+    ("attention_scores_fp32", (8, 8, 300, 32), (8, 8, 300, 32), True, torch.float32, 2e-5),
+    ("attention_mix_fp32", (8, 8, 100, 300), (8, 8, 300, 32), False, torch.float32, 2e-5),
+    ("ragged_unaligned_fp32", (3, 77, 30), (3, 45, 30), True, torch.float32, 2e-5),
+    ("ragged_unaligned_bf16", (2, 3, 131, 27), (2, 3, 27, 19), False, torch.bfloat16, 1.5e-2),
+    ("broadcast_b", (4, 2, 70, 64), (1, 2, 64, 40), False, torch.float32, 2e-5),
+    ("anchor_column", (8, 4800, 300), (8, 300, 1), False, torch.float32, 2e-5),
+]
+
+
+@pytest.mark.parametrize("case", BMM_CASES, ids=[c[0] for c in BMM_CASES])
+def test_own_batched_gemm_forward_and_gradients(case):
+    from gw_depth_amd import ops
+    name, ash, bsh, trans_b, dt, tol = case
+    g = torch.Generator().manual_seed(7)
+    a0 = (torch.randn(*ash, generator=g) * 0.5).to(dt)
+    b0 = (torch.randn(*bsh, generator=g) * 0.5).to(dt)
+    alpha = 0.37
+    ar, br = a0.double().requires_grad_(True), b0.double().requires_grad_(True)
+    ref = alpha * (ar @ (br.transpose(-1, -2) if trans_b else br))
+    gy = torch.randn(ref.shape, generator=g).to(dt)
+    ref.backward(gy.double())
+    a, b = a0.cuda().requires_grad_(True), b0.cuda().requires_grad_(True)
+    y = (ops.matmul_nt if trans_b else ops.matmul_nn)(a, b, alpha=alpha)
+    assert y.shape == ref.shape and y.dtype == dt
+    y.backward(gy.cuda())
+    torch.cuda.synchronize()
+
+    def err(got, want):
+        return float((got.double().cpu() - want).norm() / (want.norm() + 1e-30))
+    assert err(y.detach(), ref.detach()) < tol, (name, "forward", err(y.detach(), ref.detach()))
+    assert err(a.grad, ar.grad) < tol, (name, "d a", err(a.grad, ar.grad))
+    assert err(b.grad, br.grad) < tol, (name, "d b", err(b.grad, br.grad))
+
+
+def test_own_batched_gemm_on_strided_head_views():
+    """The fp32 attention path hands over (B, H, L, hd) views of packed (B, L, 2E) projections: no copies, unit inner stride only."""
+    from gw_depth_amd import ops
+    B, L, S, H, hd = 2, 50, 70, 8, 32
+    E = H * hd
+    g = torch.Generator().manual_seed(9)
+    qk = torch.randn(B, L, 2 * E, generator=g).cuda()
+    kk = torch.randn(B, S, 2 * E, generator=g).cuda()
+    q = qk[..., :E].reshape(B, L, H, hd).transpose(1, 2)
+    k = kk[..., E:].reshape(B, S, H, hd).transpose(1, 2)
+    got = ops.matmul_nt(q, k)
+    want = q.double() @ k.double().transpose(-1, -2)
+    assert float((got.double() - want).norm() / want.norm()) < 2e-5
