@@ -16,6 +16,10 @@ def _dist_ready():
     return torch.distributed.is_available() and torch.distributed.is_initialized()
 
 
+# gwd_match_cost + gwd_lsap + gwd_set_losses_* as ONE autograd node (five launches); False keeps forward_packed's torch formulation of the
+# same arithmetic - the unit test of the fused node compares the two (tests/test_hip_kernels.py), nothing else clears it
+FUSED_SETLOSS = True
+
 class HungarianMatcherLine(nn.Module):
     """cost = cost_line * L1 cdist - cost_class * prob[target class]; scipy LSAP per image (matcher.py:28-82)."""
 
@@ -151,7 +155,7 @@ class SetCriterion(nn.Module):
         cap = packed["lines"].shape[0]
         meta = packed["meta"]                                                          # int32: col_off (B+1) | image of column (cap) | valid (cap)
         col_off, bidx, valid = meta[:B + 1], meta[B + 1:B + 1 + cap].long(), meta[B + 1 + cap:].float()
-        if os.environ.get("GWD_FUSED_SETLOSS", "1") != "0":
+        if FUSED_SETLOSS:
             ce, l1, qi = _SetLossFn.apply(logits.contiguous(), lines.contiguous(), packed["lines"], packed["labels"], meta, self.empty_weight,
                                           packed["num_items"], float(world), float(self.matcher.cost_line), float(self.matcher.cost_class))
             self.last_query_of_target = qi.long()

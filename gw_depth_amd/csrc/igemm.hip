@@ -1543,41 +1543,10 @@ int check_desc(const gwd_conv_desc *d) {
     return 0;
 }
 
-static bool big_tiles_enabled() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GWD_IGEMM_BIG");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v == 1;
-}
-
-static bool tail_enabled() {                 // A/B switch (GWD_IGEMM_TAILK=0: the register-staged kernel for Cin % 32 != 0, as before)
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GWD_IGEMM_TAILK");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v == 1;
-}
-
-static int small_tile_threshold() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GWD_SMALL_TILES");
-        v = e ? atoi(e) : 320;
-    }
-    return v;
-}
-
-static int fwd_variant() {                   // experiment switch (tools/convbench.py); 0 = the shipped selection
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GWD_IGEMM_VARIANT");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
+// Fixed choices (each was an A/B switch while it was being measured; the measurements are in DESIGN.md section 4):
+constexpr bool big_tiles_enabled() { return true; }      // 256-row tiles from M >= 131 072 on
+constexpr bool tail_enabled() { return true; }           // zero-page channel tail for Cin % 32 != 0 (the 80-channel layers)
+constexpr int small_tile_threshold() { return 320; }     // fewer 128 x 128 tiles than this: 64 x 64 tiles
 
 
 // ----------------------------------------------------------------------------------------------
@@ -1759,14 +1728,7 @@ __global__ __launch_bounds__(256) void gemm_ksplit_kernel(const gwd_conv_desc d,
     }
 }
 
-static int ksplit_min_k() {                  // A/B switch: GWD_IGEMM_KSPLIT=0 keeps these GEMMs on igemm_dma_kernel
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GWD_IGEMM_KSPLIT");
-        v = e ? atoi(e) : 1024;
-    }
-    return v;
-}
+constexpr int ksplit_min_k() { return 1024; }
 
 // 1 = launched
 static int launch_ksplit(const gwd_conv_desc *d, hipStream_t s) {
@@ -1803,25 +1765,6 @@ static bool dma_enabled() {
         v = (e && e[0] == '0') ? 0 : 1;
     }
     return v == 1;
-}
-
-static int bk64_level() {                    // experiment switch GWD_IGEMM_BK64: 0 = 32-channel K tiles everywhere; 1 = 64 for the 64x64 tiles; 2 = + 128x64; 3 = + 128x128
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GWD_IGEMM_BK64");
-        v = e ? atoi(e) : 1;
-    }
-    return v;
-}
-static int kpb_enabled() {                   // experiment switch GWD_IGEMM_KPB: 0/1 = one K tile per barrier; 2 = two, 64x64 tiles; 3 = + 128x128; 4 = + 128x64
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GWD_IGEMM_KPB");
-        v = e ? atoi(e) : 2;
-        if (v >= 2) v -= 1;                  // -> 1: 64x64, 2: + 128x128, 3: + 128x64
-        else v = 0;
-    }
-    return v;
 }
 
 // gwd_conv_desc.ln_mean != NULL: convolution with the ConvLn epilogue (dma_tile<..., LN>).  0 = launched, -4 = no fused kernel for the shape.
@@ -1949,33 +1892,27 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
     else if (actk == 1) { DMA_LAUNCH_G64(BM_, BN_, WM_, WN_, ST_, GRID, false, 1) }                             \
     else if (actk == 2) { DMA_LAUNCH_G64(BM_, BN_, WM_, WN_, ST_, GRID, false, 2) }                             \
     else { DMA_LAUNCH_G64(BM_, BN_, WM_, WN_, ST_, GRID, false, -1) }
-            // 64-channel K tiles (whole 128-byte lines per staged row piece) where every tap is a whole number of them
-            const int bk64 = (d->Cin % 64) == 0 ? bk64_level() : 0;
-            // two K tiles per barrier for the latency-bound small tiles (even number of K tiles; GWD_IGEMM_KPB=1: one, as in round 2)
-            const bool kpb2 = kpb_enabled() && ((d->KH * d->KW * (d->Cin / 32)) % 2) == 0;
+            // 64-channel K tiles (whole 128-byte lines per staged row piece) where every tap is a whole number of them; for the 64 x 64
+            // tiles only (128 x 64 and 128 x 128 with two stages: no gain, measured)
+            const bool bk64 = (d->Cin % 64) == 0;
+            // otherwise two 32-channel K tiles per barrier for them (needs an even number of K tiles)
+            const bool kpb2 = ((d->KH * d->KW * (d->Cin / 32)) % 2) == 0;
             const bool big = big_tiles_enabled() && M >= 256 * 512;      // >= 2 workgroups per CU with 256-row tiles
             const unsigned gm2 = (M + 255) / 256;
             if (N % 160 == 0) {
-                const int var = fwd_variant();
-                if (var == 1) { DMA_LAUNCH(128, 160, 4, 1, 3, dim3(gm * (N / 160))) }
-                else if (var == 2) { DMA_LAUNCH(128, 160, 4, 1, 2, dim3(gm * (N / 160))) }
-                else if (big) { DMA_LAUNCH(256, 160, 8, 1, 3, dim3(gm2 * (N / 160))) } else { DMA_LAUNCH(128, 160, 4, 1, 3, dim3(gm * (N / 160))) }
+                if (big) { DMA_LAUNCH(256, 160, 8, 1, 3, dim3(gm2 * (N / 160))) } else { DMA_LAUNCH(128, 160, 4, 1, 3, dim3(gm * (N / 160))) }
             } else if (N > 64) {
                 const unsigned t128 = gm * ((N + 127) / 128);
                 const int small_thr = small_tile_threshold();
                 if (big) { DMA_LAUNCH(256, 128, 4, 2, 3, dim3(gm2 * ((N + 127) / 128))) }
                 else if ((int)t128 < small_thr) {
                     // fewer 128x128 tiles than CUs: quarter tiles put four times as many workgroups on the chip
-                    if (bk64 >= 1) { DMA_LAUNCH_64(64, 64, 2, 2, 3, dim3(((M + 63) / 64) * ((N + 63) / 64))) }
+                    if (bk64) { DMA_LAUNCH_64(64, 64, 2, 2, 3, dim3(((M + 63) / 64) * ((N + 63) / 64))) }
                     else if (kpb2) { DMA_LAUNCH_K(64, 64, 2, 2, 6, dim3(((M + 63) / 64) * ((N + 63) / 64)), 2) }
                     else { DMA_LAUNCH(64, 64, 2, 2, 4, dim3(((M + 63) / 64) * ((N + 63) / 64))) }
-                } else if (bk64 >= 3) { DMA_LAUNCH_64(128, 128, 2, 2, 2, dim3(t128)) }
-                else if (kpb2 && kpb_enabled() >= 2) { DMA_LAUNCH_K(128, 128, 2, 2, 4, dim3(t128), 2) }
-                else { DMA_LAUNCH(128, 128, 2, 2, 3, dim3(t128)) }
+                } else { DMA_LAUNCH(128, 128, 2, 2, 3, dim3(t128)) }
             } else if (N > 32) {
-                if (bk64 >= 2) { DMA_LAUNCH_64(128, 64, 2, 2, 2, dim3(gm)) }
-                else if (kpb2 && kpb_enabled() >= 3) { DMA_LAUNCH_K(128, 64, 2, 2, 4, dim3(gm), 2) }
-                else { DMA_LAUNCH(128, 64, 2, 2, 4, dim3(gm)) }
+                DMA_LAUNCH(128, 64, 2, 2, 4, dim3(gm))
             } else {
                 DMA_LAUNCH(128, 32, 4, 1, 4, dim3(gm))
             }
@@ -1990,7 +1927,7 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
     }
     // fewer than two tiles per CU (the 60/120-channel pyramid at 1/8 resolution: 300 tiles of 128 rows = one full round plus
     // a tail round of 44): quarter tiles give four times as many workgroups
-    const bool quarter = fwd_variant() != 7 && N > 32 && gm * ((N + 127) / 128) < 512;
+    const bool quarter = N > 32 && gm * ((N + 127) / 128) < 512;
     if (N % 160 == 0) {                       // 160 / 320 channel pyramids: exact tiles, no padded columns
         igemm_fwd_kernel<T, 128, 160, 4, 1, BK><<<dim3(gm, N / 160), 256, 0, s>>>(*d);
     } else if (quarter) {
@@ -2006,30 +1943,8 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
     return 0;
 }
 
-static int wgrad_target_blocks(int resident) {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GWD_WGRAD_BLOCKS");
-        v = e ? atoi(e) : 0;
-    }
-    return v > 0 ? v : resident;     // default: exactly one full round of resident workgroups (no tail round)
-}
-static int wgrad_per_cu_128() {              // resident 128 x 128 weight-gradient workgroups per CU the split count aims at (A/B: GWD_WGRAD_PER_CU128)
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GWD_WGRAD_PER_CU128");
-        v = e ? atoi(e) : 2;
-    }
-    return v;
-}
-static int wgrad_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GWD_WGRAD_VARIANT");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
+constexpr int wgrad_target_blocks(int resident) { return resident; }     // exactly one full round of resident workgroups (no tail round)
+constexpr int wgrad_per_cu_128() { return 2; }                            // resident 128 x 128 weight-gradient workgroups per CU the split count aims at
 
 static void wgrad_split(int M, int tiles, int rm, int &splits, int &m_per_block, int resident = 768, double balance = 0.0) {
     // M-splits so that tiles x splits fills the chip's resident workgroup slots once; >= 8 reduction steps each
@@ -2077,17 +1992,9 @@ struct WgradCollector {
     }
 };
 
-static int wgrad_taps_enabled() {            // A/B switch (GWD_WGRAD_TAPS=0: igemm_wgrad_dma_kernel<160,128> as in round 2)
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GWD_WGRAD_TAPS");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v;
-}
 // 1 = launched wgrad_taps_kernel
 static int launch_wgrad_taps(const gwd_conv_desc *d, float *dw, hipStream_t s) {
-    if (!wgrad_taps_enabled() || d->dtype != GWD_BF16 || !d->zero_page) return 0;
+    if (d->dtype != GWD_BF16 || !d->zero_page) return 0;
     if (d->gather != GWD_GATHER_CONV || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->Hi || d->Wo != d->Wi) return 0;
     // measured against igemm_wgrad_dma_kernel<160,128>, same box (tools/convbench.py): 800 -> 320 at 8x120x160 1.17 -> 0.81 ms, 160 -> 160
     // 0.133 -> 0.114 ms; 80 -> 160 0.081 -> 0.085 and 160 -> 160 on a pooled 8x60x80 map 0.057 -> 0.070 (the nine-tap flush of a
@@ -2133,7 +2040,7 @@ int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s, WgradCollecto
         if (BN_ * BK_ > 128 * 128 && per_cu > 2) per_cu = 2;   /* -> 2 waves per SIMD = 2 workgroups per CU */          \
         if (BN_ * BK_ == 128 * 128 && per_cu > wgrad_per_cu_128()) per_cu = wgrad_per_cu_128();  /* 138 registers: 3 fit */      \
         /* plain GEMMs: a step costs ~0.45 us, one split's flush tiles * BN * BK * 4 bytes at ~1.3 TB/s */                \
-        const double bal = (fast == 2 && wgrad_variant() != 9) ? 0.45e-6 * 1.3e12 / ((double)tiles * BN_ * BK_ * 4) : 0.0;  \
+        const double bal = fast == 2 ? 0.45e-6 * 1.3e12 / ((double)tiles * BN_ * BK_ * 4) : 0.0;                         \
         wgrad_split(M, tiles, 32, splits, m_per_block, 256 * (per_cu > 4 ? 4 : per_cu), bal);                \
         dim3 grid((unsigned)tiles * splits);                                                                 \
         if (coll && coll->take(BN_, BK_, fast, *d, dw, m_per_block, tiles * splits)) { /* runs at flush() */ }             \
@@ -2145,18 +2052,16 @@ int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s, WgradCollecto
                 GWD_CHECK_LAUNCH();
                 return 0;
             }
-            const int var = wgrad_variant();
             int fast = 0;
             if (d->gather == GWD_GATHER_CONV && d->stride == 1) {
                 if (d->KH == 1 && d->KW == 1 && d->pad == 0) fast = 2;
                 else if (d->Ho == d->Hi && d->Wo == d->Wi && d->Wo >= 11) fast = 1;
             }
-            if (N % 160 == 0 && K >= 256 && (var == 1 || var == 2)) WG_LAUNCH(160, 256, 1, 4, 3)      // var 2: the wide tile for the 160-wide pyramids only
-            else if (N % 160 == 0 && K >= 128 && var == 4) WG_LAUNCH(160, 128, 1, 4, 3)      // the 3-stage ring (default until round 2)
-            else if (N % 160 == 0 && K >= 128 && var != 3) WG_LAUNCH(160, 128, 1, 4, 4)      // 4 stages = 72 KB, still 2 per CU: +3-4 %
-            else if (N > 64 && K >= 256 && var == 1) WG_LAUNCH(128, 256, 2, 2, 3)
+            // tile shapes measured and dropped: 160 x 256 / 128 x 256 (one workgroup per CU: -1 ms per step in all), the 3-stage ring for
+            // 160 x 128 (+3-4 %), 64 x 64 for the narrow layers
+            if (N % 160 == 0 && K >= 128) WG_LAUNCH(160, 128, 1, 4, 4)      // 4 stages = 72 KB, still 2 per CU
             else if (N > 64 && K > 64) WG_LAUNCH(128, 128, 2, 2, 3)
-            else if (N <= 32 && K >= 128 && wgrad_variant() != 5) WG_LAUNCH(32, 128, 1, 4, 4)      // narrow layers: no half-empty 64-row tile
+            else if (N <= 32 && K >= 128) WG_LAUNCH(32, 128, 1, 4, 4)      // narrow layers: no half-empty 64-row tile
             else WG_LAUNCH(64, 64, 2, 2, 4)
 #undef WG_LAUNCH
             GWD_CHECK_LAUNCH();

@@ -789,13 +789,7 @@ int gwd_mfattn_token(bool backward, const gwd_strided *const *ops, long n_proble
     // 90 / 20 / ~12 here; backward 224 / 77 / 43 -> 269 / 52 / 20: at E = 12 the 48 wave reductions of the VALU form are cheaper than this
     // kernel's 8-24-byte-per-lane row traffic, so that one case stays there
     // (with a window's head groups on one XCD - xcd_grouped_block - the E = 12 backward is the faster one here as well: same-box
-    //  A/B -0.1 ... -0.25 ms per step; GWD_TOK_BWD12=0 = the lane-per-token kernel for that case)
-    static int bwd12 = -1;
-    if (bwd12 < 0) {
-        const char *ev = getenv("GWD_TOK_BWD12");
-        bwd12 = (ev && ev[0] == '0') ? 0 : 1;
-    }
-    if (backward && e == 12 && !bwd12) return 1;
+    //  A/B -0.1 ... -0.25 ms per step)
     switch (e) {
         case 12: return tok::run<12>(backward, ops, n_problems, heads, scale, s);
         case 16: return tok::run<16>(backward, ops, n_problems, heads, scale, s);

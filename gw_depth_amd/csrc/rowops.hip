@@ -183,11 +183,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T *__restrict__ 
     }
 }
 
-inline bool softmax_generic() {              // A/B switch: the one-size kernel (NPL = 16) for every row length
-    static int v = -1;
-    if (v < 0) v = getenv("GWD_SOFTMAX_GENERIC") ? 1 : 0;
-    return v == 1;
-}
+inline bool softmax_generic() { return false; }      // (the one-size kernel, NPL = 16, for every row length: -0.56 ms per step against it)
 template <typename T>
 void launch_softmax_fwd(int grid, hipStream_t s, const T *x, T *y, int64_t rows, int L, float scale, const unsigned char *mask, int64_t rpm) {
     const int per = softmax_generic() ? SM_PER_LANE : (L + 63) / 64;

@@ -212,11 +212,7 @@ int gwd_thin_conv_forward(const gwd_conv_desc *d, hipStream_t s) {
 int gwd_thin_conv_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s) {
     if (!thin_common(d) || d->gather != GWD_GATHER_CONV || d->Cin != C || (d->Cout != 1 && d->Cout != 2) || d->scale) return 0;   // scaled gradients: igemm
     const int tiles = d->B * ((d->Hi + TILE - 1) / TILE) * ((d->Wi + TILE - 1) / TILE);
-    static int cap = -2;                                               // every workgroup flushes its 288 / 576 sums with atomics onto the same addresses
-    if (cap == -2) {
-        const char *e = getenv("GWD_THIN_WGRAD_GRID");
-        cap = e ? atoi(e) : 1024;
-    }
+    constexpr int cap = 1024;                                          // every workgroup flushes its 288 / 576 sums with atomics onto the same addresses
     const int grid = tiles < cap ? tiles : cap;                        // <= 4 workgroups (34 KiB LDS each) per CU, one round
     if (d->Cout == 1) thin_wgrad_kernel<1><<<grid, 320, 0, s>>>(*d, dw, tiles);
     else thin_wgrad_kernel<2><<<grid, 320, 0, s>>>(*d, dw, tiles);

@@ -177,14 +177,7 @@ __global__ __launch_bounds__(64 * TH / RPW) void tconv_fwd_kernel(const gwd_conv
 template <int CIN, int COUT, int TH>
 size_t fwd_lds() { return (size_t)(Halo<CIN, TH>::HPIX * Halo<CIN, TH>::PS + 9 * ((COUT + 31) / 32 * 32) * Halo<CIN, TH>::PS) * 2; }
 
-static bool enabled() {                      // A/B switch (GWD_TILE_CONV=0: the tap-by-tap implicit GEMM for these layers as well)
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GWD_TILE_CONV");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v == 1;
-}
+static bool enabled() { return true; }       // (against the tap-by-tap implicit GEMM for these layers: -0.5 ms per step, round 2)
 
 template <int CIN, int COUT, bool UP, bool FLIP>
 int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
@@ -198,11 +191,7 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
     const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
     long grid = 256L * per_cu;
     if (grid > ntiles) grid = ntiles;
-    static int rpw1 = -1;                                       // GWD_TCONV_RPW1: bit mask of the layers that run one row per wave (A/B)
-    if (rpw1 < 0) {                                             //   1: 64 -> 64, 2: 64 -> 32, 4: 32 -> 64, 8: 32 -> 32
-        const char *e = getenv("GWD_TCONV_RPW1");
-        rpw1 = e ? atoi(e) : 1;
-    }
+    constexpr int rpw1 = 1;                                     // bit mask of the layers that run one row per wave: 1: 64 -> 64 (measured), 2: 64 -> 32, 4: 32 -> 64, 8: 32 -> 32
     constexpr int bit = (CIN == 64 && COUT == 64) ? 1 : (CIN == 64 && COUT == 32) ? 2 : (CIN == 32 && COUT == 64) ? 4 : (CIN == 32 && COUT == 32) ? 8 : 0;
 #define TC_GO(RPW_, ACTK_)                                                                                                       \
     {                                                                                                                            \
@@ -358,24 +347,14 @@ int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s) {
     long grid = 256L * per_cu;
     // every workgroup ends with CG x 9 x CX fp32 atomics onto the SAME few thousand addresses: with 768 workgroups that flush
     // (768-way contention per address) outweighs the tile loop for the small weights; cap the workgroup count by the weight size
-    static int cap_env = -2;
-    if (cap_env == -2) {
-        const char *e = getenv("GWD_TCONV_WGRAD_GRID");
-        cap_env = e ? atoi(e) : -1;
-    }
-    // measured (tools/convbench.py, GWD_TCONV_WGRAD_GRID sweep): 32 x 32 at 480 x 640: 154 us with 768 workgroups, 116 with 512;
+    // measured (tools/convbench.py, grid sweep): 32 x 32 at 480 x 640: 154 us with 768 workgroups, 116 with 512;
     // 64 x 32 at 240 x 320: 125 -> 86 us with 256
-    const long cap = cap_env > 0 ? cap_env : (CX * CG <= 1024 ? 512 : 256);
+    const long cap = CX * CG <= 1024 ? 512 : 256;
     if (grid > cap) grid = cap;
     if (grid > ntiles) grid = ntiles;
     // nine waves with one filter tap each instead of three with three: 64 x 32 at 240 x 320 85 -> 52 us (more waves per CU for the
-    // same LDS), 32 x 32 at 480 x 640 120 -> 126 us - so only the 64-channel input runs that way (GWD_TCONV_WGRAD_TPW1=0 / 1 forces)
-    static int tpw1 = -1;
-    if (tpw1 < 0) {
-        const char *e = getenv("GWD_TCONV_WGRAD_TPW1");
-        tpw1 = e ? (e[0] == '1' ? 1 : 0) : 2;
-    }
-    if (tpw1 == 1 || (tpw1 == 2 && CX == 64)) {
+    // same LDS), 32 x 32 at 480 x 640 120 -> 126 us - so only the 64-channel input runs that way
+    if (CX == 64) {
         static bool attr1 = false;
         if (!attr1) {
             (void)hipFuncSetAttribute((const void *)tconv_wgrad_kernel<CX, CG, UP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -200,14 +200,7 @@ int by_e(int e, bool bwd, const gwd_strided *const *s, long np, int heads, float
 // mfattn.hip: the same problem on the matrix cores (bf16); 0 = launched, 1 = not covered
 int gwd_mfattn_token(bool backward, const gwd_strided *const *ops, long n_problems, int heads, int e, float scale, hipStream_t s);
 
-static bool mfma_token_enabled() {            // A/B switch (GWD_MFMA_TOKATTN=0: the lane-per-token kernels for bf16 as well)
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GWD_MFMA_TOKATTN");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v == 1;
-}
+static bool mfma_token_enabled() { return true; }       // bf16: csrc/mfattn.hip; the lane-per-token kernels below are the fp32 (parity) path
 
 extern "C" int gwd_tokattn_forward(const gwd_strided *q, const gwd_strided *k, const gwd_strided *v, const gwd_strided *o,
                                    int64_t n_windows, int32_t heads, int32_t e, float scale, int32_t dtype, void *stream) {

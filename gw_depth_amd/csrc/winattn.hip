@@ -334,14 +334,7 @@ int gwd_mfattn_window(bool backward, const gwd_strided *q, const gwd_strided *k,
                       const int32_t *rel_index, int32_t n_rel, const int32_t *region, int64_t n_windows, int32_t wpi, int32_t heads,
                       int32_t head_dim, float scale, hipStream_t s);
 
-static bool mfma_window_enabled() {          // A/B switch (GWD_MFMA_WINATTN=0: the lane-per-row VALU kernels for bf16 as well)
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GWD_MFMA_WINATTN");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v == 1;
-}
+static bool mfma_window_enabled() { return true; }      // bf16 with aligned operands: csrc/mfattn.hip; the lane-per-row kernels below are the fp32 (parity) path
 
 extern "C" int gwd_winattn_forward(const gwd_strided *q, const gwd_strided *k, const gwd_strided *v, const gwd_strided *o,
                                    const float *bias, const int32_t *rel_index, int32_t n_rel, const int32_t *region,

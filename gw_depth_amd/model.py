@@ -132,7 +132,7 @@ class ResNetBody(nn.Module):
     def forward(self, x):
         s, b = self.bn1.folded()
         if x.is_cuda and x.dtype == torch.bfloat16 and not (self.conv1.weight.requires_grad and torch.is_grad_enabled()) \
-                and not x.requires_grad and os.environ.get("GWD_FUSED_STEM", "1") != "0":
+                and not x.requires_grad:
             x = ops.stem(x, self.conv1.weight, s, b)             # conv1 + bn1 + relu + maxpool, one forward-only kernel
         else:
             x = ops.conv2d(x, self.conv1.weight, stride=2, pad=3, row_scale=s, shift=b, act=ACT_RELU)
@@ -140,7 +140,7 @@ class ResNetBody(nn.Module):
         feats = []
         # a block whose output feeds only the next block of its layer defers its last ReLU backward to that block's first conv
         # (which, with the fan-out, is the single consumer of the map); the last block's output also leaves as a feature level
-        chain = ops.act_gate_enabled() and os.environ.get("GWD_FANOUT", "1") != "0"
+        chain = ops.act_gate_enabled()
         for li in range(1, 5):
             blocks = getattr(self, f"layer{li}")
             for bi, blk in enumerate(blocks):
@@ -178,7 +178,7 @@ class Joiner(nn.Module):
 
     def forward(self, images_pm, pad_mask):
         feats = self._modules["0"].body(images_pm)
-        if pad_mask.is_cuda and os.environ.get("GWD_FUSED_POS", "1") != "0":
+        if pad_mask.is_cuda:
             masks = ops.mask_levels(pad_mask, [tuple(f.shape[1:3]) for f in feats])      # + the counts pos_sine() builds on
         else:
             masks = [F.interpolate(pad_mask[None].float(), size=f.shape[1:3]).to(torch.bool)[0] for f in feats]
@@ -590,7 +590,7 @@ class ConvLn(nn.Module):
 
     def forward(self, x, gelu=False, residual=None, geom=None, fan=False):
         """fan: also return the input again for its second consumer (the block's skip): ops._ConvFn fan-out."""
-        if x.is_cuda and x.dtype == torch.bfloat16 and ops.conv_ln_fused_enabled():
+        if x.is_cuda and x.dtype == torch.bfloat16:
             # one launch: the LayerNorm (+ GELU / + skip) runs in the convolution's epilogue (ops._ConvLnFn)
             return ops.conv_ln(x, self.conv.weight, self.layer_norm.weight, self.layer_norm.bias, self.pad, gelu=gelu, residual=residual,
                                geom=geom, fanout=fan)
@@ -708,7 +708,7 @@ class PointBasedPred(nn.Module):
         logits = self.pyramid(rg.view(B, H, W, -1))
         att = ops.softmax_lastdim(logits if Sp == S else logits[..., :S])
         Ho, Wo, R = att.shape[1], att.shape[2], att.shape[3]
-        if R <= 256 and os.environ.get("GWD_ANCHOR_FUSED", "1") != "0":
+        if R <= 256:
             pred = ops.anchor_depth(att.view(B, Ho * Wo, R), anchor.view(B, R))          # sum_r att * anchor depth, one pass
         else:
             pred = (ops.matmul_nn if att.is_cuda else torch.bmm)(att.float().view(B, Ho * Wo, R), anchor.view(B, R, 1))

@@ -414,8 +414,6 @@ class _PadConvFn(torch.autograd.Function):
 
 def conv2d_padded(x, w, pad, geom, fanout=False):
     """See _PadConvFn.  x (B, H, W, G*Cgp) zero-padded, w (Cout, KH, KW, G*Cg) fp32 master, geom = (Np, Cg, Cgp)."""
-    if fanout and os.environ.get("GWD_FANOUT", "1") == "0":
-        return _PadConvFn.apply(x, w, int(pad), tuple(int(v) for v in geom), _sink(w), False), x
     return _PadConvFn.apply(x, w, int(pad), tuple(int(v) for v in geom), _sink(w), bool(fanout))
 
 
@@ -533,7 +531,7 @@ class _ConvFn(torch.autograd.Function):
             else:
                 gx = torch.empty_like(x)
                 done = False
-                if KH == 1 and KW == 1 and stride > 1 and pad == 0 and not gate and os.environ.get("GWD_STRIDE_PLACE", "1") != "0":
+                if KH == 1 and KW == 1 and stride > 1 and pad == 0 and not gate:
                     # 1x1 / stride s: only the pixels (s i, s j) get a gradient - a plain GEMM over the OUTPUT pixels, then placement
                     # (+ the skip gradient) in one pass; the transposed gather spent 3/4 of its work on zero-page products
                     q = torch.empty((B, Ho, Wo, Cin), dtype=x.dtype, device=x.device)
@@ -595,16 +593,13 @@ def conv2d(x, w, bias=None, *, stride=1, pad=0, act=ACT_NONE, act_scale=1.0, res
     with it) is called with defer=True and that consumer with in_gate=<the producer's activation>: the activation's backward then
     runs in the consumer's data-gradient epilogue instead of as a pass of its own (act_gate_enabled(): both or neither)."""
     sinks = (_sink(w), _sink(bias) if bias is not None else None)
-    if fanout and os.environ.get("GWD_FANOUT", "1") == "0":         # A/B: autograd's own accumulation of the two gradients
-        return _ConvFn.apply(x, w, bias, residual, row_scale, shift, stride, pad, act, float(act_scale), upsample_to,
-                             getattr(w, "_gwd_bf16", None), sinks if (sinks[0] or sinks[1]) else None, mult, False, in_gate, defer), x
     return _ConvFn.apply(x, w, bias, residual, row_scale, shift, stride, pad, act, float(act_scale), upsample_to,
                          getattr(w, "_gwd_bf16", None), sinks if (sinks[0] or sinks[1]) else None, mult, bool(fanout), in_gate, defer)
 
 
 def act_gate_enabled():
-    """A/B switch (GWD_ACT_GATE=0: every activation layer runs its own backward pass)."""
-    return os.environ.get("GWD_ACT_GATE", "1") != "0"
+    """ReLU / ELU layers with a single consumer run their backward in that consumer's data-gradient epilogue (conv2d defer / in_gate)."""
+    return True
 
 
 def linear(x, w, bias=None, act=ACT_NONE, rows=None, residual=None, mult=None, fanout=False):
@@ -630,7 +625,7 @@ def linear(x, w, bias=None, act=ACT_NONE, rows=None, residual=None, mult=None, f
     sinks = (None if ws is None else (ws[0].view(n, 1, 1, K), ws[1]), bs)
     res = None if residual is None else residual.reshape(-1, 1, 1, n)
     mul = None if mult is None else mult.reshape(-1, 1, 1, n)
-    fan = bool(fanout) and os.environ.get("GWD_FANOUT", "1") != "0"
+    fan = bool(fanout)
     y = _ConvFn.apply(x2, w.view(n, 1, 1, K), bias, res, None, None, 1, 0, act, 1.0, None,
                       None if shadow is None else shadow.view(n, 1, 1, K),
                       sinks if (sinks[0] or sinks[1]) else None, mul, fan)
@@ -709,8 +704,6 @@ def layer_norm(x, gamma, beta, gelu=False, residual=None, fanout=False, in_gate=
     if gamma is not None:
         sg, sb = _sink(gamma), _sink(beta)
         sinks = (sg, sb) if (sg is not None and sb is not None) else None
-    if fanout and os.environ.get("GWD_LN_FANOUT", "1") == "0":
-        return _LayerNormFn.apply(x, gamma, beta, bool(gelu), sinks, residual, False, in_gate), x
     return _LayerNormFn.apply(x, gamma, beta, bool(gelu), sinks, residual, bool(fanout), in_gate)
 
 
@@ -823,11 +816,6 @@ def conv_ln(x, w, gamma, beta, pad, gelu=False, residual=None, geom=None, fanout
     ln_sinks = (sg, sb) if (sg is not None and sb is not None) else None
     return _ConvLnFn.apply(x, w, gamma, beta, residual, int(pad), bool(gelu), None if geom is None else tuple(int(v) for v in geom),
                            _sink(w), ln_sinks, bool(fanout))
-
-
-def conv_ln_fused_enabled():
-    """A/B switch (GWD_CONVLN=0: convolution and LayerNorm as two launches, the round-2 path)."""
-    return os.environ.get("GWD_CONVLN", "1") != "0"
 
 
 def _as4(t):
@@ -1013,7 +1001,7 @@ def mha_core(qk, k, v, heads, key_padding_mask, dropout_p, training, scale, mult
     or None when the kernels do not cover the call (not bf16 on a HIP device, head_dim != 32): the caller keeps the unfused
     path (the fp32 parity mode)."""
     E = v.shape[-1]
-    if not v.is_cuda or v.dtype != torch.bfloat16 or E // heads != 32 or os.environ.get("GWD_FLASH_MHA", "1") == "0":
+    if not v.is_cuda or v.dtype != torch.bfloat16 or E // heads != 32:
         return None
     B, L = qk.shape[0], qk.shape[1]
     S = v.shape[1]
@@ -1138,8 +1126,7 @@ def psp_pools(x, pools):
     """(x, [avg_pool(x, k) for k in pools]); fused into one pass each way for the reference's pools (16, 8, 4, 2)."""
     B, H, W, C = x.shape
     vec = 8 if x.dtype == torch.bfloat16 else 4
-    if tuple(pools) == (16, 8, 4, 2) and H >= 16 and W >= 16 and C % vec == 0 and x.is_contiguous() \
-            and os.environ.get("GWD_PSP_POOL", "1") != "0":
+    if tuple(pools) == (16, 8, 4, 2) and H >= 16 and W >= 16 and C % vec == 0 and x.is_contiguous():
         outs = _PspPoolFn.apply(x)
         return outs[0], list(outs[1:])
     return x, [avg_pool(x, k) for k in pools]
@@ -1188,7 +1175,7 @@ class _PyramidCatFn(torch.autograd.Function):
 def pyramid_concat(x, ys):
     """x (B,H,W,C) and low-resolution maps ys[k] (B,h_k,w_k,C) -> (B,H,W,(1+len(ys)) C) = [x | bilinear_ac(ys[k] -> H,W) ...]."""
     C = x.shape[-1]
-    if C % 8 or not ys or os.environ.get("GWD_PYRAMID_CAT", "1") == "0":
+    if C % 8 or not ys:
         return torch.cat([x] + [upsample_bilinear_ac(y, x.shape[1:3]) for y in ys], dim=-1)
     return _PyramidCatFn.apply(x, *ys)
 

@@ -282,36 +282,10 @@ def test_flat_adamw_on_device_matches_torch_adamw():
     assert worst < 1e-6, worst
 
 
-def test_bf16_attention_kernels_match_the_unfused_path():
-    """The bf16 step runs the DETR attention and every 7x7 window attention on the matrix cores (csrc/mfattn.hip); switching
-    them off (GWD_FLASH_MHA=0: unfused batched GEMMs; GWD_MFMA_WINATTN=0: lane-per-row kernels) must give the same step to
-    bf16 rounding: same loss terms, same flat gradient."""
-    import os
-    import subprocess
-    import sys
-    code = (
-        "import sys, torch; sys.path.insert(0, %r)\n"
-        "from tests.golden_check import build, to_device\n"
-        "from gw_depth_amd.engine import TrainStep\n"
-        "from gw_depth_amd.synth import synth_batch\n"
-        "b = to_device(synth_batch(2, 224, 288, seed=71, n_lines=[4, 6], sizes=[(224, 288), (200, 260)]), 'cuda')\n"
-        "cfg, model, crits = build(device='cuda')\n"
-        "step = TrainStep(model, crits, cfg, compute_dtype=torch.bfloat16)\n"
-        "out, total, terms = step(b)\n"
-        "torch.cuda.synchronize()\n"
-        "torch.save({'g': step.flat_g.cpu(), 'terms': {k: float(v) for k, v in terms.items()}, 'lines': out['pred_lines'].float().cpu(),\n"
-        "            'depth': out['pred_depth'][-1].float().cpu()}, sys.argv[1])\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = {}
-    for tag, env in (("mfma", {}), ("plain", {"GWD_FLASH_MHA": "0", "GWD_MFMA_WINATTN": "0"})):
-        path = "/tmp/gwd_attn_%s_%d.pt" % (tag, os.getpid())
-        subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, **env))      # the switches are read once per process
-        res[tag] = torch.load(path)
-        os.remove(path)
-    a, b = res["mfma"], res["plain"]
-    assert rel(a["lines"], b["lines"]) < 2e-2 and rel(a["depth"], b["depth"]) < 3e-2
-    for k in a["terms"]:
-        assert abs(a["terms"][k] - b["terms"][k]) <= 3e-2 * max(1.0, abs(b["terms"][k])), k
-    assert rel(a["g"], b["g"]) < 0.15                                   # bf16 gradients of a random-init net: noise-level agreement
+# (test_bf16_attention_kernels_match_the_unfused_path lived here until round 3: it compared the matrix-core attention kernels with the
+# library's OWN lane-per-row kernels through two environment switches.  tests/test_bf16_pinning.py compares the whole bf16 step - those
+# kernels included - with the fp32 parity mode, which runs different code (VALU window attention, gwd_bmm + softmax for the DETR
+# attention) and is itself pinned to the reference's fixtures; the switches are gone.)
 
 
 def test_hip_graph_step_with_plane_loss_equals_eager_step(golden_dir):

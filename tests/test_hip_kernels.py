@@ -995,7 +995,7 @@ def test_psp_pools_equal_four_average_pools(dev, shape, dtype):
 
 @pytest.mark.parametrize("sizes", [[7] * 8, [1, 12, 0, 5], [64, 3]])
 def test_fused_set_criterion_equals_the_torch_formulation(dev, sizes, monkeypatch):
-    """gwd_match_cost + gwd_lsap + gwd_set_losses_* (one autograd node) against forward_packed's torch formulation (GWD_FUSED_SETLOSS=0):
+    """gwd_match_cost + gwd_lsap + gwd_set_losses_* (one autograd node) against forward_packed's torch formulation (criteria.FUSED_SETLOSS = False):
     same assignment, same 2 x layers loss terms, same gradients w.r.t. logits and lines - ragged target counts incl. an empty image."""
     from gw_depth_amd.criteria import HungarianMatcherLine as HungarianMatcher, SetCriterion, pack_targets
     torch.manual_seed(11)
@@ -1006,7 +1006,7 @@ def test_fused_set_criterion_equals_the_torch_formulation(dev, sizes, monkeypatc
     logits0, lines0 = torch.randn(L_, B, Q, 2, device="cuda"), torch.rand(L_, B, Q, 6, device="cuda")
     res = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("GWD_FUSED_SETLOSS", mode)
+        monkeypatch.setattr("gw_depth_amd.criteria.FUSED_SETLOSS", mode == "1")
         lg, ln = logits0.clone().requires_grad_(True), lines0.clone().requires_grad_(True)
         outs = {"pred_logits": lg[0], "pred_lines": ln[0], "aux_outputs": [{"pred_logits": lg[i], "pred_lines": ln[i]} for i in range(1, L_)]}
         losses = crit.forward_packed(outs, packed)
@@ -1187,8 +1187,7 @@ KSPLIT_CASES = [
 
 @pytest.mark.parametrize("case", KSPLIT_CASES, ids=["%dx%dx%d_%s" % (c[0], c[1], c[2], "_".join(sorted(c[3]))) for c in KSPLIT_CASES])
 def test_long_reduction_gemm_split_over_waves(dev, case, monkeypatch):
-    """gemm_ksplit_kernel (1x1 layers with K >= 1024 on few rows) against fp32 math and against the ordinary kernel (GWD_IGEMM_KSPLIT=0
-    is read once per process, so the second comparison is with FakeDevice only when the switch cannot be flipped)."""
+    """gemm_ksplit_kernel (1x1 layers with K >= 1024 on few rows) against fp32 math."""
     M, K, N, ex = case
     dt = torch.bfloat16
     x, w = rnd(M, 1, 1, K, dtype=dt, seed=1), rnd(N, 1, 1, K, dtype=dt, seed=2, scale=K ** -0.5)

@@ -35,7 +35,6 @@ def timeit(fn, n=20):
 def main():
     lib = hip.library()
     dt = torch.bfloat16
-    print("variant", os.environ.get("GWD_IGEMM_VARIANT", "0"))
     for (B, H, W, Ci, Co, K) in SHAPES:
         p = K // 2
         x = torch.randn(B, H, W, Ci, device="cuda").to(dt)

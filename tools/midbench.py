@@ -32,7 +32,6 @@ def timeit(fn, n=30):
 lib = hip.library()
 dt = torch.bfloat16
 tot = [0.0, 0.0, 0.0, 0.0]
-print("GWD_IGEMM_KPB", os.environ.get("GWD_IGEMM_KPB", "default"))
 for (B, H, W, Ci, Co, K) in SHAPES:
     p = K // 2
     x = torch.randn(B, H, W, Ci, device="cuda").to(dt)
