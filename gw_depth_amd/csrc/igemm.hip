@@ -2106,12 +2106,14 @@ extern "C" int gwd_conv_forward(const gwd_conv_desc *d, void *stream) {
     if (rc) return rc;
     if (!d->w) return -1;
     if ((int64_t)d->B * d->Ho * d->Wo * d->Cout >= (1LL << 40)) return -7;
-    if (trace_conv()) trace_line("fwd", d);
     if (!d->ln_mean && (gwd_thin_conv_forward(d, (hipStream_t)stream) || gwd_tile_conv_forward(d, (hipStream_t)stream))) {
+        if (trace_conv()) trace_line("fwd", d);
         GWD_CHECK_LAUNCH();
         return 0;
     }
-    return d->dtype == GWD_BF16 ? launch_fwd<__bf16>(d, (hipStream_t)stream) : launch_fwd<float>(d, (hipStream_t)stream);
+    rc = d->dtype == GWD_BF16 ? launch_fwd<__bf16>(d, (hipStream_t)stream) : launch_fwd<float>(d, (hipStream_t)stream);
+    if (rc == 0 && trace_conv()) trace_line("fwd", d);     // one line per LAUNCH (a refused ConvLn request, -4, launched nothing): tools/conv_instep.py
+    return rc;
 }
 
 extern "C" int gwd_conv_wgrad(const gwd_conv_desc *d, float *dw, void *stream) {

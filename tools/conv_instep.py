@@ -33,21 +33,29 @@ def main():
             calls.append(tuple(int(v) for v in m.groups()))
     if len(ks) != len(calls):
         raise SystemExit("trace has %d forward-family kernels, the log %d gwd_conv_forward calls: the 1:1 mapping does not hold" % (len(ks), len(calls)))
-    passes = sum(1 for r in rows if "adamw_kernel" in r["Kernel_Name"]) // 2 or 1
+    # forward passes in the trace: the fused stem runs once per forward (bench.py adds one forward/backward without an optimizer step)
+    passes = sum(1 for r in rows if "stem_kernel" in r["Kernel_Name"]) or (sum(1 for r in rows if "adamw_kernel" in r["Kernel_Name"]) // 2) or 1
     agg = collections.defaultdict(lambda: [0, 0.0])
     for c, us in zip(calls, ks):
         agg[c][0] += 1
         agg[c][1] += us
-    planes = {64, 128, 256, 512}
+    size_of = {64: 120, 128: 60, 256: 30, 512: 15}           # planes -> rows of the layer's output map at 480 x 640
 
     def is_backbone(c):
+        """torchvision ResNet-50 v1.5 Bottleneck shapes (stride on the 3x3): conv1 1x1 cin -> p, conv2 3x3 p -> p (stride 1 | 2), conv3 1x1
+        p -> 4p, downsample 1x1 cin -> 4p; a data-gradient launch has the same numbers with Cin / Cout and the map sizes swapped.  One
+        known collision: dense_input_proj (2048 -> 512 at 15 x 20) has the shape of layer4's conv1 (one of three launches of that row)."""
         B, Hi, Wi, Cin, Ho, Wo, Cout, k, s, g, dt = c
-        lo, hi = min(Cin, Cout), max(Cin, Cout)
+        if Hi * Wi == 1 or B != 8:
+            return False
+        lo, hi, small = min(Cin, Cout), max(Cin, Cout), min(Hi, Ho)
         if k == 3:
-            return Cin == Cout and Cin in planes and (Hi, Wi) != (441, 40)
-        if k == 1 and Hi * Wi > 1:
-            return lo in planes | {1024} and hi in {256, 512, 1024, 2048} and (hi == 4 * lo or hi == 2 * lo or (lo, hi) in ((64, 256),))
-        return False
+            return Cin == Cout and Cin in size_of and small == size_of[Cin]
+        if k != 1 or max(Hi, Ho) not in (120, 60, 30, 15):
+            return False
+        if (lo, hi) == (64, 64):
+            return small == 120
+        return lo in (64, 128, 256, 512, 1024) and hi in (256, 512, 1024, 2048) and hi // lo in (2, 4) and hi % lo == 0
 
     out = []
     for c, (n, us) in agg.items():
