@@ -65,17 +65,23 @@ def main():
         M = B * (Ho * Wo if g != 1 else Hi * Wi)          # a data-gradient launch (g = 1) is described by its INPUT gradient's pixels = Ho x Wo of the desc
         M = B * Ho * Wo
         gflop = 2.0 * M * k * k * Cin * Cout / 1e9
-        out.append((us / passes, n / passes, us / n, gflop, c))
+        # algorithmic bytes of the launch: input map + output map + weights (bf16); skip / gate / pre-activation operands of the epilogue
+        # are NOT counted (unknown here), so the HBM floor below is a lower bound of what the launch really moves
+        mbytes = 2.0 * (B * Hi * Wi * Cin + B * Ho * Wo * Cout + k * k * Cin * Cout) / 1e6
+        out.append((us / passes, n / passes, us / n, gflop, c, mbytes))
     out.sort(reverse=True)
     tot_us = sum(o[0] for o in out)
     tot_gf = sum(o[3] * o[1] for o in out)
     print("%s forward + data-gradient launches inside one step (%d passes averaged): %.0f launches, %.2f ms, %.0f GFLOP, %.0f TFLOP/s = %.1f %% of the dense bf16 MFMA peak" %
           ("ResNet-50 Bottleneck" if only_backbone else "all conv / linear", passes, sum(o[1] for o in out), tot_us / 1e3, tot_gf,
            tot_gf / tot_us * 1e3, 100 * tot_gf / tot_us * 1e3 / PEAK))
-    print("%9s %5s %9s %7s %6s  %s" % ("us/step", "n", "us each", "TF/s", "%peak", "(B, Hi, Wi, Cin, Ho, Wo, Cout, k, stride, gather[1 = data gradient])"))
-    for us, n, each, gf, c in out[:120]:
+    floor_us = sum(o[1] * max(o[3] / PEAK * 1e3, o[5] / 6.3) for o in out)      # per launch: max(MFMA time at peak, bytes at 6.3 TB/s)
+    print("roofline floor of these launches (per launch max of FLOP / 2500 TFLOP/s and algorithmic bytes / 6.3 TB/s, the copy rate MI355X_MICROARCH.md "
+          "measures): %.2f ms -> the measured %.2f ms are %.0f %% of it" % (floor_us / 1e3, tot_us / 1e3, 100 * floor_us / tot_us))
+    print("%9s %5s %9s %7s %6s %8s %9s  %s" % ("us/step", "n", "us each", "TF/s", "%MFMA", "MB", "floor us", "(B, Hi, Wi, Cin, Ho, Wo, Cout, k, stride, gather[1 = data gradient])"))
+    for us, n, each, gf, c, mb in out[:120]:
         tf = gf / each * 1e3
-        print("%9.1f %5.1f %9.1f %7.1f %6.1f  %s" % (us, n, each, tf, 100 * tf / PEAK, c[:10]))
+        print("%9.1f %5.1f %9.1f %7.1f %6.1f %8.1f %9.1f  %s" % (us, n, each, tf, 100 * tf / PEAK, mb, max(gf / PEAK * 1e3, mb / 6.3), c[:10]))
     if not only_backbone:
         wg = collections.defaultdict(lambda: [0, 0.0])
         for r in rows:
