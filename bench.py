@@ -343,7 +343,9 @@ def in_step_kernel_time(step, batch, gflop, peak):
     rec = []
 
     def spy(x, w, y, dims, **kw):
-        hit = tuple(dims) == (8, 120, 160, 160, 120, 160, 160, 3, 3)
+        # the plain launches of the shape: since round 3 the ten FORWARD launches carry the LayerNorm epilogue (another kernel variant,
+        # +40 us of epilogue), the ten data-gradient launches are the kernel the roofline leg times
+        hit = tuple(dims) == (8, 120, 160, 160, 120, 160, 160, 3, 3) and kw.get("ln") is None
         if hit:
             a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(torch.cuda.current_stream())
@@ -369,6 +371,11 @@ def in_step_kernel_time(step, batch, gflop, peak):
     return {"in_step_launch_ms": round(ms, 4), "in_step_launches": len(d), "in_step_achieved": round(ach, 2), "in_step_frac": round(ach / peak, 4)}
 
 
+def hip_gather_transposed():
+    from gw_depth_amd import hip
+    return hip.GATHER_TRANSPOSED
+
+
 def dominant_kernel_roofline(lib, dtype):
     """Times the dominant kernel of the step — the 3x3 160->160 ConvLn convolution of
     point_based_pred2.pyramid at 1/4 resolution (B=8: M = 8*120*160 = 153600 output pixels; 10 forward
@@ -379,14 +386,17 @@ def dominant_kernel_roofline(lib, dtype):
     w = (torch.randn(C, 3, 3, C, device="cuda") * (9 * C) ** -0.5).to(dtype)
     y = torch.empty(B, H, W, C, device="cuda", dtype=dtype)
     dims = (B, H, W, C, H, W, C, 3, 3)
+    # the launch as the step makes it: the DATA GRADIENT of the layer (transposed gather, weights [Cin][3][3][Cout]) - same FLOPs and
+    # bytes as the forward product; the step's forward launches of this shape carry the ConvLn epilogue since round 3
+    kw = dict(stride=1, pad=1, gather=hip_gather_transposed())
     for _ in range(3):
-        lib.conv_forward(x, w, y, dims, stride=1, pad=1)
+        lib.conv_forward(x, w, y, dims, **kw)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = 20
     torch.cuda.synchronize()
     s.record()
     for _ in range(n):
-        lib.conv_forward(x, w, y, dims, stride=1, pad=1)
+        lib.conv_forward(x, w, y, dims, **kw)
     e.record()
     torch.cuda.synchronize()
     ms = s.elapsed_time(e) / n
@@ -403,7 +413,7 @@ def dominant_kernel_roofline(lib, dtype):
     except (OSError, KeyError, ValueError):
         pass
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "traffic": traffic, "traffic_measured": stamp, "kernel": "igemm_dma_kernel<256,160,8,1,3,0,false,false,false,0> (%s) conv3x3 160->160 @ 8x120x160" % ("bf16" if dtype == torch.bfloat16 else "f32"),
+            "traffic": traffic, "traffic_measured": stamp, "kernel": "igemm_dma_kernel<256,160,8,1,3,1,...> (%s) conv3x3 160->160 @ 8x120x160, data-gradient launch" % ("bf16" if dtype == torch.bfloat16 else "f32"),
             "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(flops / 1e9, 2)}
 
 

@@ -15,6 +15,6 @@ x = torch.randn(B, H, W, C, device="cuda").to(torch.bfloat16)
 w = (torch.randn(C, 3, 3, C, device="cuda") * (9 * C) ** -0.5).to(torch.bfloat16)
 y = torch.empty(B, H, W, C, device="cuda", dtype=torch.bfloat16)
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 20):
-    lib.conv_forward(x, w, y, (B, H, W, C, H, W, C, 3, 3), stride=1, pad=1)
+    lib.conv_forward(x, w, y, (B, H, W, C, H, W, C, 3, 3), stride=1, pad=1, gather=hip.GATHER_TRANSPOSED)    # the step's data-gradient launch
 torch.cuda.synchronize()
 print("algorithmic bytes per launch: in %d + w %d + out %d" % (x.numel() * 2, w.numel() * 2, y.numel() * 2))
