@@ -31,7 +31,7 @@ PEAK_MFMA_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-
 PEAK_HBM_GBPS = 8000.0
 STEP_GFLOP_PER_IMAGE = 1049.5      # fwd + losses + bwd, conv/mm/addmm/bmm only
 BACKBONE_GFLOP_PER_IMAGE = 128.4   # 50.05 fwd + 78.33 bwd
-HBM_STEP_FILE = "r02_hbm_step.json"
+HBM_STEP_FILE = "r03_hbm_step.json"
 
 
 def parse():

@@ -77,7 +77,7 @@ def main():
            tot_gf / tot_us * 1e3, 100 * tot_gf / tot_us * 1e3 / PEAK))
     floor_us = sum(o[1] * max(o[3] / PEAK * 1e3, o[5] / 6.3) for o in out)      # per launch: max(MFMA time at peak, bytes at 6.3 TB/s)
     print("roofline floor of these launches (per launch max of FLOP / 2500 TFLOP/s and algorithmic bytes / 6.3 TB/s, the copy rate MI355X_MICROARCH.md "
-          "measures): %.2f ms -> the measured %.2f ms are %.0f %% of it" % (floor_us / 1e3, tot_us / 1e3, 100 * floor_us / tot_us))
+          "measures): %.2f ms = %.0f %% of the measured %.2f ms" % (floor_us / 1e3, 100 * floor_us / tot_us, tot_us / 1e3))
     print("%9s %5s %9s %7s %6s %8s %9s  %s" % ("us/step", "n", "us each", "TF/s", "%MFMA", "MB", "floor us", "(B, Hi, Wi, Cin, Ho, Wo, Cout, k, stride, gather[1 = data gradient])"))
     for us, n, each, gf, c, mb in out[:120]:
         tf = gf / each * 1e3
