@@ -394,6 +394,9 @@ __device__ __forceinline__ int xcd_band(int id, int total) {
 // layer runs 0.122 -> 0.108 ms (same-box, 3 runs each).  Gated launches are always lean (the dispatcher sends the rest elsewhere).
 // (ACTK: -1 = any activation, decided at run time, + the pre-activation copy; 0 = none = "lean"; 1 = ReLU, a single v_max - the
 // Bottleneck convolutions.)
+#ifndef GWD_DBG_ZERO
+#define GWD_DBG_ZERO 0      // development ablation builds only (tools/ab_build.sh): bit 0 / 1 = stage the A / B tile from the zero page
+#endif
 template <int BM, int BN, int WM, int WN, int STAGES, int BK = 32>
 struct DmaTileCfg {
     static constexpr int NW = WM * WN;
@@ -415,9 +418,23 @@ struct DmaTileCfg {
 // size GEMMs (64 x 64: 32 FLOP per staged byte) are bound by exactly that rate (340 TF/s = 10.5 TB/s of fill on ResNet layer3).  Needs
 // Cin % 64 == 0; half as many barriers per reduction as a bonus.  Swizzle: 16-byte chunk c of row r sits at position c ^ ((r >> 1) & 7)
 // (the 16 lanes one ds_read_b128 cycle serves then hit 16 different 4-bank groups); BK = 32 keeps c ^ ((r >> 2) & 3).
-template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT, bool TAIL, bool GATE, int ACTK, bool LN = false, int KPB = 1, int BK = 32>
+// HALO (round 3): 3x3 / stride 1 / pad 1 layers on maps that tile exactly into 8 x 32 pixel patches.  The row tile is such a patch
+// (wave w = patch row w, accumulator row = x), and the activations are staged ONCE per 32-channel block as the 10 x 34 pixel halo
+// patch (21.25 KB) instead of once per tap: a K step then stages the 10 KB weight tile of its (channel block, tap) and a ninth of a
+// halo patch - 12.4 KB and ~200 distinct 128-byte lines instead of 26.6 KB and 416 lines.  The lines are what the fill costs
+// (tools/ubench/piecerate.hip: ~0.4 lines per clock and CU whatever the piece size; ablation with the A or B tile staged from the
+// zero page, 160 -> 160 forward: 0.113 ms -> A 0.084, B 0.094, both 0.075; profiles/r03_ablations.txt 11).  The nine taps read
+// their A fragments from the same patch at a pixel offset; the transposed gather (stride-1 data gradient) is the same walk with the
+// taps mirrored.  Ring: 2 halo patches (22 KB each: channel block cb + 1 lands while the nine taps of cb compute) + 3 weight tiles.
+struct HaloCfg {
+    static constexpr int A_INSTR = 22, A_BYTES = A_INSTR * 1024, B_BYTES = 160 * 64, B_STAGES = 3;
+    static constexpr int RING = 2 * A_BYTES + B_STAGES * B_BYTES;
+};
+
+template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT, bool TAIL, bool GATE, int ACTK, bool LN = false, int KPB = 1, int BK = 32, bool HALO = false>
 __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, const int m0, const int n0) {
     typedef __bf16 T;
+    static_assert(!HALO || (BM == 256 && BN == 160 && WM == 8 && WN == 1 && BK == 32 && KPB == 1 && !TAIL && GM <= 1), "halo tiles: 8 x 32 pixel patches, 160 columns");
     constexpr int NW = WM * WN;                          // 4 or 8 waves
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int RPI = 1024 / (BK * 2), CPR = BK / 8;   // rows per 1 KiB DMA wave-instruction (16 | 8), 16-byte chunks per row (4 | 8)
@@ -526,7 +543,7 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
             ok = ok & a_ok[i];
             if constexpr (TAIL) ok = ok & (u_c0 + a_ck[i] < d.Cin);
             const size_t off = (a_pix[i] + (size_t)(ok ? ih : 0) * d.Wi + (ok ? iw : 0)) * d.Cin + u_c0 + a_ck[i];
-            const char *src = ok ? (const char *)(x + off) : zero;
+            const char *src = (ok && !(GWD_DBG_ZERO & 1)) ? (const char *)(x + off) : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(sb + (wave * A_IT + i) * 1024), 16, 0, 0);
         }
@@ -535,7 +552,7 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
             if (i < my_b_loads) {                                 // wave-uniform
                 bool bok = b_ok[i];
                 if constexpr (TAIL) bok = bok & (u_c0 + b_ck[i] < d.Cin);
-                const char *src = bok ? b_src[i] + (size_t)((u_kh * d.KW + u_kw) * d.Cin + u_c0) * 2 : zero;
+                const char *src = (bok && !(GWD_DBG_ZERO & 2)) ? b_src[i] + (size_t)((u_kh * d.KW + u_kw) * d.Cin + u_c0) * 2 : zero;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(sb + BM * BK * 2 + (wave + i * NW) * 1024), 16, 0, 0);
             }
@@ -577,7 +594,111 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
         }
     };
 
-    if constexpr (KPB == 1) {
+    // row -> output pixel of accumulator block i, row r (0..31) of this wave
+    int halo_m0 = 0;
+    if constexpr (HALO) {
+        const int txs = d.Wo >> 5, tys = d.Ho >> 3;
+        const int mt = m0 / BM;
+        const int tb = mt / (txs * tys), tr = mt - tb * (txs * tys);
+        const int ty = tr / txs, tx = tr - ty * txs;
+        halo_m0 = (tb * d.Ho + ty * 8 + wave) * d.Wo + tx * 32;
+        constexpr int A_IT_H = 3;                         // DMA instructions wave + 8 i (< 22) of a halo patch
+        const char *ha_src[A_IT_H];
+        bool ha_ok[A_IT_H];
+#pragma unroll
+        for (int i = 0; i < A_IT_H; ++i) {
+            const int p = 16 * (wave + 8 * i) + (lane >> 2);          // halo pixel (row-major in the 10 x 34 patch)
+            const int hy = p / 34, hx = p - hy * 34;
+            const int iy = ty * 8 + hy - 1, ix = tx * 32 + hx - 1;
+            ha_ok[i] = (p < 340) & ((unsigned)iy < (unsigned)d.Hi) & ((unsigned)ix < (unsigned)d.Wi);
+            const int ck = ((lane & 3) ^ ((p >> 2) & 3)) * 8;
+            ha_src[i] = (const char *)(x + ((size_t)(tb * d.Hi + (ha_ok[i] ? iy : 0)) * d.Wi + (ha_ok[i] ? ix : 0)) * d.Cin + ck);
+        }
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // scalar: the wait switch below is a chain of scalar branches
+        const int nA = wave_u < HaloCfg::A_INSTR - 16 ? 3 : 2, nB = (B_FULL == 0 || wave_u < B_FULL) ? B_IT : B_IT - 1;
+        const int NCB = d.Cin >> 5, S = NCB * 9;
+        auto issue_a = [&](int cb) {
+            char *ab = smem + (cb & 1) * HaloCfg::A_BYTES;
+#pragma unroll
+            for (int i = 0; i < A_IT_H; ++i) {
+                if (wave + 8 * i < HaloCfg::A_INSTR) {            // wave-uniform
+                    const char *src = (ha_ok[i] && !(GWD_DBG_ZERO & 1)) ? ha_src[i] + cb * 64 : zero;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(ab + (wave + 8 * i) * 1024), 16, 0, 0);
+                }
+            }
+        };
+        int i_cb = 0, i_tap = 0;                          // (channel block, tap) of the next weight tile to issue
+        auto issue_b = [&](int stage) {
+            char *sb = smem + 2 * HaloCfg::A_BYTES + stage * HaloCfg::B_BYTES;
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                if (i < my_b_loads) {
+                    const char *src = (b_ok[i] && !(GWD_DBG_ZERO & 2)) ? b_src[i] + (size_t)(i_tap * d.Cin + i_cb * 32) * 2 : zero;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(sb + (wave + i * NW) * 1024), 16, 0, 0);
+                }
+            }
+            if (++i_tap == 9) {
+                i_tap = 0;
+                ++i_cb;
+            }
+        };
+        const int fr_h = lane & 31, fh_h = lane >> 5;
+        const int hp0 = wave * 34 + fr_h;
+        auto compute_h = [&](int cb, int toff, int stage) {
+            const int hp = hp0 + toff;
+            const char *Ap = smem + (cb & 1) * HaloCfg::A_BYTES + hp * 64;
+            const int asw = (hp >> 2) & 3;
+            const T *Bs = (const T *)(smem + 2 * HaloCfg::A_BYTES + stage * HaloCfg::B_BYTES);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 bfr[TN];
+                const bf16x8 af = *(const bf16x8 *)(Ap + (((ks * 2 + fh_h) ^ asw) << 4));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int row = j * 32 + fr_h;
+                    bfr[j] = *(const bf16x8 *)(Bs + row * 32 + (((ks * 2 + fh_h) ^ swz(row)) * 8));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[0][j] = mma(af, bfr[j], acc[0][j]);
+            }
+        };
+        issue_a(0);
+        issue_b(0);
+        issue_b(1);
+        int cb = 0, kh = 0, kw = 0;
+        bool a_prev = false;
+        for (int st = 0; st < S; ++st) {
+            // the weight tile of this step has landed once only the next one (and a halo patch issued in the step before) is in flight
+            if (st + 1 < S) {
+                const int allow = nB + (a_prev ? nA : 0);         // wave-uniform: 1 .. 5
+                if (allow == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else if (allow == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else if (allow == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else if (allow == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            const int tap = kh * 3 + kw;
+            a_prev = false;
+            if (tap == 0 && cb + 1 < NCB) {
+                issue_a(cb + 1);
+                a_prev = true;
+            }
+            if (st + 2 < S) issue_b((st + 2) % 3);
+            compute_h(cb, GM == 1 ? (2 - kh) * 34 + (2 - kw) : kh * 34 + kw, st % 3);
+            if (++kw == 3) {
+                kw = 0;
+                if (++kh == 3) {
+                    kh = 0;
+                    ++cb;
+                }
+            }
+        }
+    } else if constexpr (KPB == 1) {
 #pragma unroll
         for (int t = 0; t < STAGES - 1; ++t)
             if (t < KT) issue(t);
@@ -625,6 +746,7 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
         }
     }
     __syncthreads();
+    const int wbase = HALO ? halo_m0 : m0 + wm * (BM / WM);      // output pixel of this wave's accumulator row 0
 
     if constexpr (LN) {
         // ---- ConvLn epilogue (points_sample.py:12-25): LayerNorm over the row's C = d.ln_C real channels (eps 1e-5, biased variance)
@@ -667,10 +789,10 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
                     stats[(i * 32 + row) * 2] = mu[r];
                     stats[(i * 32 + row) * 2 + 1] = rs;
-                    const int rt = wm * (BM / WM) + i * 32 + row;
-                    if (m0 + rt < M) {
-                        d.ln_mean[m0 + rt] = mu[r];
-                        d.ln_rstd[m0 + rt] = rs;
+                    const int mr = wbase + i * 32 + row;
+                    if (mr < M) {
+                        d.ln_mean[mr] = mu[r];
+                        d.ln_rstd[mr] = rs;
                     }
                 }
             }
@@ -694,13 +816,13 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
                         const int row = vr + 16 * half;
-                        const int rt = wm * (BM / WM) + i * 32 + row;
-                        if (m0 + rt >= M) continue;
+                        const int mr = wbase + i * 32 + row;
+                        if (mr >= M) continue;
                         const f32x4 lo = *(const f32x4 *)(stage + row * 36 + vc);
                         const f32x4 hi = *(const f32x4 *)(stage + row * 36 + vc + 4);
                         const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                         const float m_ = stats[(i * 32 + row) * 2], rs = stats[(i * 32 + row) * 2 + 1];
-                        const size_t o = (size_t)(m0 + rt) * N + nb;
+                        const size_t o = (size_t)mr * N + nb;
                         bf16x8 out;
                         if (z) {
 #pragma unroll
@@ -754,7 +876,7 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const int row = vr + 16 * half;
-                    const int m = m0 + wm * (BM / WM) + i * 32 + row;
+                    const int m = wbase + i * 32 + row;
                     if (m >= M) continue;
                     const f32x4 lo = *(const f32x4 *)(stage + row * 36 + vc);
                     const f32x4 hi = *(const f32x4 *)(stage + row * 36 + vc + 4);
@@ -803,15 +925,16 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
     }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false, bool TAIL = false, bool GATE = false, int ACTK = -1, bool LN = false, int KPB = 1, int BK = 32>
+template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false, bool TAIL = false, bool GATE = false, int ACTK = -1, bool LN = false, int KPB = 1, int BK = 32, bool HALO = false>
 __global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_desc d, const int tile_base, const int tile_count) {
-    __shared__ __attribute__((aligned(1024))) char smem[DmaTileCfg<BM, BN, WM, WN, STAGES, BK>::SMEM];
+    constexpr int SM_ = DmaTileCfg<BM, BN, WM, WN, STAGES, BK>::SMEM;
+    __shared__ __attribute__((aligned(1024))) char smem[HALO ? (HaloCfg::RING > DmaTileCfg<BM, BN, WM, WN, STAGES, BK>::EPI_BYTES ? HaloCfg::RING : DmaTileCfg<BM, BN, WM, WN, STAGES, BK>::EPI_BYTES) : SM_];
     const int n_tiles = (d.Cout + BN - 1) / BN;
     // this launch covers tiles tile_base .. tile_base + tile_count - 1 of the logical order.  (Cutting a big problem into a body of
     // whole rounds of 256-row tiles and a tail of 128-row tiles was measured in round 2: 0.125 -> 0.134 ms on the 160 -> 160
     // layer, the second launch and the lone waves of the tail cost more than the half-empty round they replace.)
     const int tile = tile_base + xcd_band(blockIdx.x, tile_count);             // column tiles of a row tile are adjacent
-    dma_tile<BM, BN, WM, WN, STAGES, GM, MULT, TAIL, GATE, ACTK, LN, KPB, BK>(d, smem, (tile / n_tiles) * BM, (tile % n_tiles) * BN);
+    dma_tile<BM, BN, WM, WN, STAGES, GM, MULT, TAIL, GATE, ACTK, LN, KPB, BK, HALO>(d, smem, (tile / n_tiles) * BM, (tile % n_tiles) * BN);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1768,6 +1891,15 @@ static bool dma_enabled() {
 }
 
 // gwd_conv_desc.ln_mean != NULL: convolution with the ConvLn epilogue (dma_tile<..., LN>).  0 = launched, -4 = no fused kernel for the shape.
+// 3x3 / stride 1 / pad 1 on a map of whole 8 x 32 pixel patches, whole 32-channel blocks: the halo-patch variant of the 256 x 160 tile
+static bool halo_ok(const gwd_conv_desc *d) {
+#ifdef GWD_NO_HALO
+    return false;
+#endif
+    return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Hi == d->Ho && d->Wi == d->Wo && (d->Wo % 32) == 0 && (d->Ho % 8) == 0 &&
+           (d->Cin % 32) == 0 && (d->Cout % 160) == 0 && (d->gather == GWD_GATHER_CONV || d->gather == GWD_GATHER_TRANSPOSED);
+}
+
 static int launch_convln(const gwd_conv_desc *d, hipStream_t s) {
     const int M = d->B * d->Ho * d->Wo, N = d->Cout;
     if (d->dtype != GWD_BF16 || !dma_enabled() || !d->zero_page || !d->ln_rstd || !d->scale || !d->shift || d->mult || d->gate) return -4;
@@ -1784,7 +1916,12 @@ static int launch_convln(const gwd_conv_desc *d, hipStream_t s) {
     }
     if (N == 160) {
         if (big_tiles_enabled() && M >= 256 * 512) {
-            if (tail) LN_LAUNCH(256, 160, 8, 1, 3, true, (M + 255) / 256) else LN_LAUNCH(256, 160, 8, 1, 3, false, (M + 255) / 256)
+            if (tail) LN_LAUNCH(256, 160, 8, 1, 3, true, (M + 255) / 256)
+            else if (halo_ok(d)) {
+                const dim3 g_((M + 255) / 256);
+                if (gelu) igemm_dma_kernel<256, 160, 8, 1, 3, 0, false, false, false, 2, true, 1, 32, true><<<g_, 512, 0, s>>>(*d, 0, (int)g_.x);
+                else igemm_dma_kernel<256, 160, 8, 1, 3, 0, false, false, false, 0, true, 1, 32, true><<<g_, 512, 0, s>>>(*d, 0, (int)g_.x);
+            } else LN_LAUNCH(256, 160, 8, 1, 3, false, (M + 255) / 256)
             return 0;
         }
         // smaller maps (the PSP branches on pooled maps) run 128 x 160 tiles at two waves per SIMD: the longer epilogue costs more than
@@ -1900,7 +2037,16 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
             const bool big = big_tiles_enabled() && M >= 256 * 512;      // >= 2 workgroups per CU with 256-row tiles
             const unsigned gm2 = (M + 255) / 256;
             if (N % 160 == 0) {
-                if (big) { DMA_LAUNCH(256, 160, 8, 1, 3, dim3(gm2 * (N / 160))) } else { DMA_LAUNCH(128, 160, 4, 1, 3, dim3(gm * (N / 160))) }
+                if (big && gmk <= 1 && halo_ok(d)) {
+                    const dim3 g(gm2 * (N / 160));
+                    if (actk == 0) {
+                        if (gmk == 0) igemm_dma_kernel<256, 160, 8, 1, 3, 0, false, false, false, 0, false, 1, 32, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
+                        else igemm_dma_kernel<256, 160, 8, 1, 3, 1, false, false, false, 0, false, 1, 32, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
+                    } else {
+                        if (gmk == 0) igemm_dma_kernel<256, 160, 8, 1, 3, 0, false, false, false, -1, false, 1, 32, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
+                        else igemm_dma_kernel<256, 160, 8, 1, 3, 1, false, false, false, -1, false, 1, 32, true><<<g, 512, 0, s>>>(*d, 0, (int)g.x);
+                    }
+                } else if (big) { DMA_LAUNCH(256, 160, 8, 1, 3, dim3(gm2 * (N / 160))) } else { DMA_LAUNCH(128, 160, 4, 1, 3, dim3(gm * (N / 160))) }
             } else if (N > 64) {
                 const unsigned t128 = gm * ((N + 127) / 128);
                 const int small_thr = small_tile_threshold();
