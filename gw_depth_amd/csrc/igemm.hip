@@ -427,8 +427,12 @@ struct DmaTileCfg {
 // their A fragments from the same patch at a pixel offset; the transposed gather (stride-1 data gradient) is the same walk with the
 // taps mirrored.  Ring: 2 halo patches (22 KB each: channel block cb + 1 lands while the nine taps of cb compute) + 3 weight tiles.
 struct HaloCfg {
-    static constexpr int A_INSTR = 22, A_BYTES = A_INSTR * 1024, B_BYTES = 160 * 64, B_STAGES = 3;
-    static constexpr int RING = 2 * A_BYTES + B_STAGES * B_BYTES;
+#if GWD_DBG_ZERO & 128          // timing experiment only (wrong results): ONE halo patch buffer, five weight tiles
+    static constexpr int A_INSTR = 22, A_BYTES = A_INSTR * 1024, B_BYTES = 160 * 64, B_STAGES = 5, A_BUFS = 1;
+#else
+    static constexpr int A_INSTR = 22, A_BYTES = A_INSTR * 1024, B_BYTES = 160 * 64, B_STAGES = 3, A_BUFS = 2;
+#endif
+    static constexpr int RING = A_BUFS * A_BYTES + B_STAGES * B_BYTES;
 };
 
 template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT, bool TAIL, bool GATE, int ACTK, bool LN = false, int KPB = 1, int BK = 32, bool HALO = false>
@@ -618,7 +622,7 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
         const int nA = wave_u < HaloCfg::A_INSTR - 16 ? 3 : 2, nB = (B_FULL == 0 || wave_u < B_FULL) ? B_IT : B_IT - 1;
         const int NCB = d.Cin >> 5, S = NCB * 9;
         auto issue_a = [&](int cb) {
-            char *ab = smem + (cb & 1) * HaloCfg::A_BYTES;
+            char *ab = smem + (cb & (HaloCfg::A_BUFS - 1)) * HaloCfg::A_BYTES;
 #pragma unroll
             for (int i = 0; i < A_IT_H; ++i) {
                 if (wave + 8 * i < HaloCfg::A_INSTR) {            // wave-uniform
@@ -630,7 +634,7 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
         };
         int i_cb = 0, i_tap = 0;                          // (channel block, tap) of the next weight tile to issue
         auto issue_b = [&](int stage) {
-            char *sb = smem + 2 * HaloCfg::A_BYTES + stage * HaloCfg::B_BYTES;
+            char *sb = smem + HaloCfg::A_BUFS * HaloCfg::A_BYTES + stage * HaloCfg::B_BYTES;
 #pragma unroll
             for (int i = 0; i < B_IT; ++i) {
                 if (i < my_b_loads) {
@@ -646,50 +650,93 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
         };
         const int fr_h = lane & 31, fh_h = lane >> 5;
         const int hp0 = wave * 34 + fr_h;
+        // Fragment reads and MFMAs of a step in a fixed issue order, the reads as inline assembly with counted lgkmcnt waits: six reads up
+        // front, then every MFMA of the first 16-channel half is followed by one read of the second half, so four or five reads stay in
+        // flight behind the matrix pipe.  (The compiler's own order was two reads, s_waitcnt lgkmcnt(0), one or two MFMAs - a full LDS
+        // round trip exposed five times per half - and with the reads it can see it drains the counter to zero in this loop whatever
+        // the order.)  7 fragment slots + 80 accumulator registers stay inside the 128 of four waves per SIMD.
+        typedef __attribute__((address_space(3))) const char *lds_cptr;
         auto compute_h = [&](int cb, int toff, int stage) {
             const int hp = hp0 + toff;
-            const char *Ap = smem + (cb & 1) * HaloCfg::A_BYTES + hp * 64;
+            const uint32_t ap = (uint32_t)(uintptr_t)(lds_cptr)(smem + (cb & (HaloCfg::A_BUFS - 1)) * HaloCfg::A_BYTES + hp * 64);
             const int asw = (hp >> 2) & 3;
-            const T *Bs = (const T *)(smem + 2 * HaloCfg::A_BYTES + stage * HaloCfg::B_BYTES);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 bfr[TN];
-                const bf16x8 af = *(const bf16x8 *)(Ap + (((ks * 2 + fh_h) ^ asw) << 4));
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int row = j * 32 + fr_h;
-                    bfr[j] = *(const bf16x8 *)(Bs + row * 32 + (((ks * 2 + fh_h) ^ swz(row)) * 8));
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[0][j] = mma(af, bfr[j], acc[0][j]);
-            }
+            const uint32_t a0 = ap + (((fh_h) ^ asw) << 4), a1 = ap + (((2 + fh_h) ^ asw) << 4);
+            const uint32_t bp = (uint32_t)(uintptr_t)(lds_cptr)(smem + HaloCfg::A_BUFS * HaloCfg::A_BYTES + stage * HaloCfg::B_BYTES) + fr_h * 64;
+            const uint32_t b0 = bp + (((fh_h) ^ swz(fr_h)) << 4), b1 = bp + (((2 + fh_h) ^ swz(fr_h)) << 4);     // swz(j * 32 + fr) == swz(fr)
+            bf16x8 fa0, fa1, f0[TN], f1[TN];
+            static_assert(TN == 5, "schedule written for five column blocks");
+#define HALO_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define HALO_WAIT(n, x, y) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(n))
+            HALO_RD(fa0, a0, 0);
+            HALO_RD(f0[0], b0, 0);
+            HALO_RD(f0[1], b0, 2048);
+            HALO_RD(f0[2], b0, 4096);
+            HALO_RD(f0[3], b0, 6144);
+            HALO_RD(f0[4], b0, 8192);
+            HALO_WAIT(4, fa0, f0[0]);
+            acc[0][0] = mma(fa0, f0[0], acc[0][0]);
+            HALO_RD(fa1, a1, 0);
+            HALO_WAIT(4, fa0, f0[1]);
+            acc[0][1] = mma(fa0, f0[1], acc[0][1]);
+            HALO_RD(f1[0], b1, 0);
+            HALO_WAIT(4, fa0, f0[2]);
+            acc[0][2] = mma(fa0, f0[2], acc[0][2]);
+            HALO_RD(f1[1], b1, 2048);
+            HALO_WAIT(4, fa0, f0[3]);
+            acc[0][3] = mma(fa0, f0[3], acc[0][3]);
+            HALO_RD(f1[2], b1, 4096);
+            HALO_WAIT(4, fa0, f0[4]);
+            acc[0][4] = mma(fa0, f0[4], acc[0][4]);
+            HALO_RD(f1[3], b1, 6144);
+            HALO_WAIT(3, fa1, f1[0]);
+            acc[0][0] = mma(fa1, f1[0], acc[0][0]);
+            HALO_RD(f1[4], b1, 8192);
+            HALO_WAIT(3, fa1, f1[1]);
+            acc[0][1] = mma(fa1, f1[1], acc[0][1]);
+            HALO_WAIT(2, fa1, f1[2]);
+            acc[0][2] = mma(fa1, f1[2], acc[0][2]);
+            HALO_WAIT(1, fa1, f1[3]);
+            acc[0][3] = mma(fa1, f1[3], acc[0][3]);
+            HALO_WAIT(0, fa1, f1[4]);
+            acc[0][4] = mma(fa1, f1[4], acc[0][4]);
+#undef HALO_RD
+#undef HALO_WAIT
         };
+        constexpr int NB = HaloCfg::B_STAGES;             // weight tiles st + 1 .. st + NB - 2 stay in flight behind the one step st waits for
         issue_a(0);
-        issue_b(0);
-        issue_b(1);
+#pragma unroll
+        for (int t = 0; t < NB - 1; ++t) issue_b(t);
         int cb = 0, kh = 0, kw = 0;
-        bool a_prev = false;
+        int a_age = NB;                                   // steps since a halo patch was issued (it is in flight behind tile st while a_age <= NB - 2)
         for (int st = 0; st < S; ++st) {
-            // the weight tile of this step has landed once only the next one (and a halo patch issued in the step before) is in flight
-            if (st + 1 < S) {
-                const int allow = nB + (a_prev ? nA : 0);         // wave-uniform: 1 .. 5
-                if (allow == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-                else if (allow == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else if (allow == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                else if (allow == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // the weight tile of this step has landed once only the newer tiles (and a halo patch issued after it) are in flight
+            const int newer = min(NB - 2, S - 1 - st);
+            const int allow = newer * nB + ((a_age <= NB - 2 && a_age <= newer) ? nA : 0);         // wave-uniform
+            switch (allow) {
+                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
             }
+#if !(GWD_DBG_ZERO & 64)
             __builtin_amdgcn_s_barrier();
+#endif
             const int tap = kh * 3 + kw;
-            a_prev = false;
+            ++a_age;
+#if !(GWD_DBG_ZERO & 32)
             if (tap == 0 && cb + 1 < NCB) {
                 issue_a(cb + 1);
-                a_prev = true;
+                a_age = 1;
             }
-            if (st + 2 < S) issue_b((st + 2) % 3);
-            compute_h(cb, GM == 1 ? (2 - kh) * 34 + (2 - kw) : kh * 34 + kw, st % 3);
+            if (st + NB - 1 < S) issue_b((st + NB - 1) % NB);
+#endif
+            compute_h(cb, GM == 1 ? (2 - kh) * 34 + (2 - kw) : kh * 34 + kw, st % NB);
             if (++kw == 3) {
                 kw = 0;
                 if (++kh == 3) {
@@ -926,7 +973,7 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false, bool TAIL = false, bool GATE = false, int ACTK = -1, bool LN = false, int KPB = 1, int BK = 32, bool HALO = false>
-__global__ __launch_bounds__(WM *WN * 64) void igemm_dma_kernel(const gwd_conv_desc d, const int tile_base, const int tile_count) {
+__global__ __launch_bounds__(WM *WN * 64) __attribute__((amdgpu_waves_per_eu(HALO ? 4 : 1, HALO ? 4 : 8))) void igemm_dma_kernel(const gwd_conv_desc d, const int tile_base, const int tile_count) {
     constexpr int SM_ = DmaTileCfg<BM, BN, WM, WN, STAGES, BK>::SMEM;
     __shared__ __attribute__((aligned(1024))) char smem[HALO ? (HaloCfg::RING > DmaTileCfg<BM, BN, WM, WN, STAGES, BK>::EPI_BYTES ? HaloCfg::RING : DmaTileCfg<BM, BN, WM, WN, STAGES, BK>::EPI_BYTES) : SM_];
     const int n_tiles = (d.Cout + BN - 1) / BN;

@@ -849,6 +849,23 @@ __device__ __forceinline__ void stage_tile(__bf16 *img, const __bf16 *slab, long
     *(uint4 *)(img + r * RSV + 16 * half + 8) = b;
 }
 
+// the two halves of stage_tile: global -> registers (issued one tile ahead of its use), registers -> LDS image
+__device__ __forceinline__ void load_tile_regs(uint4 &a, uint4 &b, const __bf16 *slab, long ts, int ntok, int tok0, int lane) {
+    const int r = lane & 31, half = lane >> 5, tok = tok0 + r;
+    a = make_uint4(0, 0, 0, 0);
+    b = a;
+    if (tok < ntok) {
+        const __bf16 *src = slab + (long)tok * ts + 16 * half;
+        a = *(const uint4 *)src;
+        b = *(const uint4 *)(src + 8);
+    }
+}
+__device__ __forceinline__ void store_tile_regs(__bf16 *img, const uint4 &a, const uint4 &b, int lane) {
+    const int r = lane & 31, half = lane >> 5;
+    *(uint4 *)(img + r * RSV + 16 * half) = a;
+    *(uint4 *)(img + r * RSV + 16 * half + 8) = b;
+}
+
 __device__ __forceinline__ bf16x8 rowfrag_l(const __bf16 *img, int s, int lane) {
     return *(const bf16x8 *)(img + (lane & 31) * RSV + 16 * s + 8 * (lane >> 5));
 }
@@ -861,6 +878,18 @@ __device__ __forceinline__ bf16x8 keymask_frag(const unsigned char *__restrict__
         const bool masked = key >= S || (kpm_b && kpm_b[key]);
         f[0] = masked ? (__bf16)-1e30f : (__bf16)0.0f;
     }
+    return f;
+}
+// the same in two halves: the mask byte (loaded a tile ahead), then the fragment
+__device__ __forceinline__ unsigned keymask_load(const unsigned char *__restrict__ kpm_b, int S, int key0, int lane) {
+    const int key = key0 + (lane & 31);
+    unsigned raw = 0;                                      // the raw byte: nothing here waits for it
+    if ((lane >> 5) == 0 && key < S && kpm_b) raw = kpm_b[key];
+    return raw;
+}
+__device__ __forceinline__ bf16x8 keymask_from(unsigned raw, int S, int key0, int lane) {
+    bf16x8 f = zero_frag();
+    if ((lane >> 5) == 0) f[0] = (key0 + (lane & 31) >= S || raw) ? (__bf16)-1e30f : (__bf16)0.0f;
     return f;
 }
 __device__ __forceinline__ bf16x8 one_frag(int lane) {
@@ -884,6 +913,26 @@ __device__ __forceinline__ void load_mult_keys(float (&mv)[16], const __bf16 *__
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) mv[4 * g + j] = (qok && kk + j < S) ? (float)mrow[kk + j] : 0.f;
+        }
+    }
+}
+
+// the raw multipliers of load_mult_keys, loaded a tile ahead and converted at the use
+union MultRaw {
+    uint2 u[4];
+    __bf16 e[16];
+};
+template <bool VEC4>
+__device__ __forceinline__ void load_mult_raw(MultRaw &r, const __bf16 *__restrict__ mrow, bool qok, int S, int key0, int h) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int kk = key0 + 8 * g + 4 * h;
+        if constexpr (VEC4) {
+            r.u[g] = make_uint2(0, 0);
+            if (qok && kk < S) r.u[g] = *(const uint2 *)(mrow + kk);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r.e[4 * g + j] = (qok && kk + j < S) ? mrow[kk + j] : (__bf16)0.0f;
         }
     }
 }
@@ -923,14 +972,34 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(Tok q, Tok k, Tok v, const 
     float m = -1e30f, l = 0.f;
     f32x16 ot = zero16();
     const int nkt = (S + 31) / 32;
+    // Every global load of key tile kt + 1 (V rows, K fragments, mask byte, dropout multipliers) is issued before the arithmetic of tile
+    // kt: a wave is alone on its SIMD here (B x H x L / 32 single-wave workgroups), so an un-prefetched tile exposed one L2 / HBM round
+    // trip per 32 keys - most of the launch (24 us for 300 keys).  Loads of a tile past the end are predicated off by their bounds.
+    uint4 va, vb;
+    bf16x8 kf0, kf1;
+    unsigned msk;
+    MultRaw mraw;
+    load_tile_regs(va, vb, vs, v.ts, S, 0, lane);
+    kf0 = rowfrag_g(ks, k.ts, S, 0, 0, lane);
+    kf1 = rowfrag_g(ks, k.ts, S, 0, 1, lane);
+    msk = keymask_load(kpm_b, S, 0, lane);
+    if (mult) load_mult_raw<VEC4>(mraw, mrow, qok, S, 0, h);
     for (int kt = 0; kt < nkt; ++kt) {
-        stage_tile(vimg, vs, v.ts, S, 32 * kt, lane);
+        store_tile_regs(vimg, va, vb, lane);
+        const bf16x8 ck0 = kf0, ck1 = kf1;
+        const unsigned cmsk = msk;
+        const MultRaw cm = mraw;
+        load_tile_regs(va, vb, vs, v.ts, S, 32 * (kt + 1), lane);
+        kf0 = rowfrag_g(ks, k.ts, S, 32 * (kt + 1), 0, lane);
+        kf1 = rowfrag_g(ks, k.ts, S, 32 * (kt + 1), 1, lane);
+        msk = keymask_load(kpm_b, S, 32 * (kt + 1), lane);
+        if (mult) load_mult_raw<VEC4>(mraw, mrow, qok, S, 32 * (kt + 1), h);
         f32x16 a = zero16();
-        a = mma(rowfrag_g(ks, k.ts, S, 32 * kt, 0, lane), qf[0], a);
-        a = mma(rowfrag_g(ks, k.ts, S, 32 * kt, 1, lane), qf[1], a);
+        a = mma(ck0, qf[0], a);
+        a = mma(ck1, qf[1], a);
 #pragma unroll
         for (int i = 0; i < 16; ++i) a[i] *= scale;
-        a = mma(keymask_frag(kpm_b, S, 32 * kt, lane), ones, a);
+        a = mma(keymask_from(cmsk, S, 32 * kt, lane), ones, a);
         float tm = a[0];
 #pragma unroll
         for (int i = 1; i < 16; ++i) tm = fmaxf(tm, a[i]);
@@ -946,10 +1015,8 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(Tok q, Tok k, Tok v, const 
         l = l * alpha + ts;
         m = mn;
         if (mult) {
-            float mv[16];
-            load_mult_keys<VEC4>(mv, mrow, qok, S, 32 * kt, h);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) a[i] *= mv[i];
+            for (int i = 0; i < 16; ++i) a[i] *= (float)cm.e[i];
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) ot[i] *= alpha;
@@ -1009,24 +1076,40 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(Tok q, Tok k, Tok v, Tok go
         const bf16x8 ones = one_frag(lane);
         f32x16 dq = zero16();
         const int nkt = (S + 31) / 32;
+        // loads of key tile kt + 1 in flight during the arithmetic of tile kt (see mha_fwd_kernel)
+        uint4 ka, kb;
+        bf16x8 vf0, vf1;
+        unsigned msk;
+        MultRaw mraw;
+        load_tile_regs(ka, kb, ks, k.ts, S, 0, lane);
+        vf0 = rowfrag_g(vs, v.ts, S, 0, 0, lane);
+        vf1 = rowfrag_g(vs, v.ts, S, 0, 1, lane);
+        msk = keymask_load(kpm_b, S, 0, lane);
+        if (mult) load_mult_raw<VEC4>(mraw, mrow, qok, S, 0, h);
         for (int kt = 0; kt < nkt; ++kt) {
-            stage_tile(img0, ks, k.ts, S, 32 * kt, lane);
+            store_tile_regs(img0, ka, kb, lane);
+            const bf16x8 cv0 = vf0, cv1 = vf1;
+            const unsigned cmsk = msk;
+            const MultRaw cm = mraw;
+            load_tile_regs(ka, kb, ks, k.ts, S, 32 * (kt + 1), lane);
+            vf0 = rowfrag_g(vs, v.ts, S, 32 * (kt + 1), 0, lane);
+            vf1 = rowfrag_g(vs, v.ts, S, 32 * (kt + 1), 1, lane);
+            msk = keymask_load(kpm_b, S, 32 * (kt + 1), lane);
+            if (mult) load_mult_raw<VEC4>(mraw, mrow, qok, S, 32 * (kt + 1), h);
             f32x16 dp = zero16();
-            dp = mma(rowfrag_g(vs, v.ts, S, 32 * kt, 0, lane), of[0], dp);          // dP^T[key][query] = V[key] . dO[query]
-            dp = mma(rowfrag_g(vs, v.ts, S, 32 * kt, 1, lane), of[1], dp);
+            dp = mma(cv0, of[0], dp);          // dP^T[key][query] = V[key] . dO[query]
+            dp = mma(cv1, of[1], dp);
             lds_settle();
             f32x16 a = zero16();
             a = mma(rowfrag_l(img0, 0, lane), qf[0], a);
             a = mma(rowfrag_l(img0, 1, lane), qf[1], a);
 #pragma unroll
             for (int i = 0; i < 16; ++i) a[i] *= scale;
-            a = mma(keymask_frag(kpm_b, S, 32 * kt, lane), ones, a);
-            float mv[16];
-            if (mult) load_mult_keys<VEC4>(mv, mrow, qok, S, 32 * kt, h);
+            a = mma(keymask_from(cmsk, S, 32 * kt, lane), ones, a);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const float p = __expf(a[i] - my_lse);
-                const float dpi = mult ? dp[i] * mv[i] : dp[i];
+                const float dpi = mult ? dp[i] * (float)cm.e[i] : dp[i];
                 a[i] = p * (dpi - my_dl);                                            // dS
             }
             dq = mma(gather_perm(img0, RSV, 0, 0, 0, true, lane), accfrag(a, 0), dq);   // dQ^T[d][q] += K[key][d] dS^T[key][q]
@@ -1047,9 +1130,34 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(Tok q, Tok k, Tok v, Tok go
         }
         f32x16 dk = zero16(), dv = zero16();
         const int nqt = (L + 31) / 32;
+        // loads of query tile qt + 1 (Q and dO rows, the 16 row statistics and multipliers of this lane) in flight during tile qt
+        uint4 qa, qb, ga, gb;
+        float ls[16], dl[16];
+        __bf16 mu[16];
+        auto load_q = [&](int qt) {
+            load_tile_regs(qa, qb, qs, q.ts, L, 32 * qt, lane);
+            load_tile_regs(ga, gb, gs, go.ts, L, 32 * qt, lane);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int qrow = 32 * qt + acc_row(i, h);
+                const bool qok = qrow < L;
+                ls[i] = qok ? lse_h[qrow] : 1e30f;
+                dl[i] = qok ? dl_h[qrow] : 0.f;
+                mu[i] = mult_h ? ((qok && kok) ? mult_h[(long)qrow * S + key] : (__bf16)0.0f) : (__bf16)1.0f;
+            }
+        };
+        load_q(0);
         for (int qt = 0; qt < nqt; ++qt) {
-            stage_tile(img0, qs, q.ts, L, 32 * qt, lane);
-            stage_tile(img1, gs, go.ts, L, 32 * qt, lane);
+            store_tile_regs(img0, qa, qb, lane);
+            store_tile_regs(img1, ga, gb, lane);
+            float cls[16], cdl[16], cmu[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                cls[i] = ls[i];
+                cdl[i] = dl[i];
+                cmu[i] = (float)mu[i];
+            }
+            load_q(qt + 1);
             lds_settle();
             f32x16 a = zero16(), dp = zero16();
 #pragma unroll
@@ -1059,13 +1167,9 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(Tok q, Tok k, Tok v, Tok go
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int qrow = 32 * qt + acc_row(i, h);
-                const bool qok = qrow < L;
-                const float ls = qok ? lse_h[qrow] : 1e30f, dl = qok ? dl_h[qrow] : 0.f;
-                const float mu = mult_h ? ((qok && kok) ? (float)mult_h[(long)qrow * S + key] : 0.f) : 1.f;
-                const float p = __expf(a[i] * scale + mk - ls);
-                a[i] = p * mu;                                                      // dropped probabilities -> dV
-                dp[i] = p * (dp[i] * mu - dl);                                      // dS -> dK
+                const float p = __expf(a[i] * scale + mk - cls[i]);
+                a[i] = p * cmu[i];                                                  // dropped probabilities -> dV
+                dp[i] = p * (dp[i] * cmu[i] - cdl[i]);                              // dS -> dK
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
