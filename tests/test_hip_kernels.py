@@ -534,7 +534,8 @@ def test_point_sample(dev, shape, nearest, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("rows,C,act", [(1000, 64, hip.ACT_GELU), (77, 256, hip.ACT_RELU), (513, 32, hip.ACT_ELU), (40, 1024, hip.ACT_GELU)])
+@pytest.mark.parametrize("rows,C,act", [(1000, 64, hip.ACT_GELU), (77, 256, hip.ACT_RELU), (513, 32, hip.ACT_ELU), (40, 1024, hip.ACT_GELU), (2403, 1024, hip.ACT_RELU),
+                                          (9999, 96, hip.ACT_GELU)])
 def test_act_backward_colsum(dev, rows, C, act, dtype):
     fake = FakeDevice()
     gy, ref = rnd(rows, C, dtype=dtype, seed=11), rnd(rows, C, dtype=dtype, seed=12)
