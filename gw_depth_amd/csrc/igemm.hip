@@ -2136,6 +2136,9 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
     return 0;
 }
 
+#ifndef GWD_WG_BAL1
+#define GWD_WG_BAL1 1.3e12     // nominal flush rate (bytes/s) behind the split count of grouped 3x3 / strided weight gradients (0 = fill the chip with each layer: +0.15 ms per step)
+#endif
 constexpr int wgrad_target_blocks(int resident) { return resident; }     // exactly one full round of resident workgroups (no tail round)
 constexpr int wgrad_per_cu_128() { return 2; }                            // resident 128 x 128 weight-gradient workgroups per CU the split count aims at
 
@@ -2158,30 +2161,55 @@ static void wgrad_split(int M, int tiles, int rm, int &splits, int &m_per_block,
     splits = (M + m_per_block - 1) / m_per_block;
 }
 
-// gwd_conv_wgrad_batch: plain-GEMM weight gradients on the two hot tile shapes are collected here instead of being
-// launched one by one; flush() runs each non-empty group as one igemm_wgrad_group_kernel launch.
+// gwd_conv_wgrad_batch: weight gradients on the two hot tile shapes (128 x 128, 64 x 64; every gather form) are collected here instead
+// of being launched one by one; a full group, and flush() at the end of the batch, runs as ONE igemm_wgrad_group_kernel launch: the
+// layers of a group fill the chip together, so each needs fewer, longer workgroups (fewer prologues and atomic flushes), and one
+// layer's flush runs beside another's reduction.
 struct WgradCollector {
-    WgradGroup g128, g64;
-    int total128 = 0, total64 = 0;
-    WgradCollector() { g128.n = g64.n = 0; }
+    static constexpr int NT_ = 3;
+    WgradGroup g[NT_][3];                                 // [128 x 128 | 64 x 64 | 32 x 128][gather form: 0 general, 1 same-size stride 1, 2 plain GEMM]
+    int total[NT_][3];
+    hipStream_t s;
+    explicit WgradCollector(hipStream_t st) : s(st) {
+        for (int t = 0; t < NT_; ++t)
+            for (int f = 0; f < 3; ++f) g[t][f].n = total[t][f] = 0;
+    }
+    void launch(int t, int f) {
+        WgradGroup &gr = g[t][f];
+        if (!gr.n) return;
+        const int tot = total[t][f];
+        if (t == 0) {
+            if (f == 2) igemm_wgrad_group_kernel<128, 128, 2, 2, 3, 2><<<tot, 256, 0, s>>>(gr);
+            else if (f == 1) igemm_wgrad_group_kernel<128, 128, 2, 2, 3, 1><<<tot, 256, 0, s>>>(gr);
+            else igemm_wgrad_group_kernel<128, 128, 2, 2, 3, 0><<<tot, 256, 0, s>>>(gr);
+        } else if (t == 1) {
+            if (f == 2) igemm_wgrad_group_kernel<64, 64, 2, 2, 4, 2><<<tot, 256, 0, s>>>(gr);
+            else if (f == 1) igemm_wgrad_group_kernel<64, 64, 2, 2, 4, 1><<<tot, 256, 0, s>>>(gr);
+            else igemm_wgrad_group_kernel<64, 64, 2, 2, 4, 0><<<tot, 256, 0, s>>>(gr);
+        } else {
+            if (f == 2) igemm_wgrad_group_kernel<32, 128, 1, 4, 4, 2><<<tot, 256, 0, s>>>(gr);
+            else if (f == 1) igemm_wgrad_group_kernel<32, 128, 1, 4, 4, 1><<<tot, 256, 0, s>>>(gr);
+            else igemm_wgrad_group_kernel<32, 128, 1, 4, 4, 0><<<tot, 256, 0, s>>>(gr);
+        }
+        gr.n = total[t][f] = 0;
+    }
     bool take(int bn, int bk, int fast, const gwd_conv_desc &d, float *dw, int m_per_block, int blocks) {
-        if (fast != 2 || !((bn == 128 && bk == 128) || (bn == 64 && bk == 64))) return false;
-        WgradGroup &g = bn == 128 ? g128 : g64;
-        int &total = bn == 128 ? total128 : total64;
-        if (g.n >= WG_GROUP) return false;
-        const int i = g.n++;
-        g.d[i] = d;
-        g.dw[i] = dw;
-        g.m_per_block[i] = m_per_block;
-        g.block0[i] = total;
-        g.blocks[i] = blocks;
-        total += (blocks + 7) & ~7;
+        if (fast < 0 || fast > 2 || !((bn == 128 && bk == 128) || (bn == 64 && bk == 64) || (bn == 32 && bk == 128))) return false;
+        const int t = bn == 128 ? 0 : (bn == 64 ? 1 : 2);
+        if (g[t][fast].n >= WG_GROUP) launch(t, fast);
+        WgradGroup &gr = g[t][fast];
+        const int i = gr.n++;
+        gr.d[i] = d;
+        gr.dw[i] = dw;
+        gr.m_per_block[i] = m_per_block;
+        gr.block0[i] = total[t][fast];
+        gr.blocks[i] = blocks;
+        total[t][fast] += (blocks + 7) & ~7;
         return true;
     }
-    void flush(hipStream_t s) {
-        if (g128.n) igemm_wgrad_group_kernel<128, 128, 2, 2, 3, 2><<<total128, 256, 0, s>>>(g128);
-        if (g64.n) igemm_wgrad_group_kernel<64, 64, 2, 2, 4, 2><<<total64, 256, 0, s>>>(g64);
-        g128.n = g64.n = total128 = total64 = 0;
+    void flush() {
+        for (int t = 0; t < NT_; ++t)
+            for (int f = 0; f < 3; ++f) launch(t, f);
     }
 };
 
@@ -2232,8 +2260,11 @@ int launch_wgrad(const gwd_conv_desc *d, float *dw, hipStream_t s, WgradCollecto
         int per_cu = (160 * 1024) / lds;                  /* LDS-limited; the >= 128-wide tiles hold ~200 VGPRs */      \
         if (BN_ * BK_ > 128 * 128 && per_cu > 2) per_cu = 2;   /* -> 2 waves per SIMD = 2 workgroups per CU */          \
         if (BN_ * BK_ == 128 * 128 && per_cu > wgrad_per_cu_128()) per_cu = wgrad_per_cu_128();  /* 138 registers: 3 fit */      \
-        /* plain GEMMs: a step costs ~0.45 us, one split's flush tiles * BN * BK * 4 bytes at ~1.3 TB/s */                \
-        const double bal = fast == 2 ? 0.45e-6 * 1.3e12 / ((double)tiles * BN_ * BK_ * 4) : 0.0;                         \
+        /* plain GEMMs: a step costs ~0.45 us, one split's flush tiles * BN * BK * 4 bytes at a NOMINAL 0.25 TB/s: the atomics themselves run */  \
+        /* at ~1.3 TB/s, but these layers run grouped (WgradCollector), the group fills the chip, and fewer, longer workgroups per layer */   \
+        /* pay fewer prologues and flushes - whole step, same box: rate 4e12 35.15 ms | 1.3e12 34.49 | 0.5e12 34.12 | 0.25e12 34.05 | 0.12e12 34.04; */ \
+        /* the same balance for the 3x3 layers (not grouped): +0.1 ... +0.4 ms, not applied */ \
+        const double bal = fast == 2 ? 0.45e-6 * 0.25e12 / ((double)tiles * BN_ * BK_ * 4) : (coll ? GWD_WG_BAL1 * 0.6e-6 / ((double)tiles * BN_ * BK_ * 4) : 0.0);                         \
         wgrad_split(M, tiles, 32, splits, m_per_block, 256 * (per_cu > 4 ? 4 : per_cu), bal);                \
         dim3 grid((unsigned)tiles * splits);                                                                 \
         if (coll && coll->take(BN_, BK_, fast, *d, dw, m_per_block, tiles * splits)) { /* runs at flush() */ }             \
@@ -2330,16 +2361,15 @@ extern "C" int gwd_conv_wgrad_batch(const gwd_conv_desc *descs, float *const *dw
         if (!dws[i]) return -1;
     }
     hipStream_t s = (hipStream_t)stream;
-    WgradCollector coll;
+    WgradCollector coll(s);
     for (int i = 0; i < n; ++i) {
         const gwd_conv_desc *d = descs + i;
-        if (coll.g128.n == WG_GROUP || coll.g64.n == WG_GROUP) coll.flush(s);
         if (trace_conv()) trace_line("wgrad", d);
         if (gwd_thin_conv_wgrad(d, dws[i], s) || gwd_tile_conv_wgrad(d, dws[i], s)) continue;
         const int rc = d->dtype == GWD_BF16 ? launch_wgrad<__bf16>(d, dws[i], s, &coll) : launch_wgrad<float>(d, dws[i], s);
         if (rc) return rc;
     }
-    coll.flush(s);
+    coll.flush();
     GWD_CHECK_LAUNCH();
     return 0;
 }

@@ -629,19 +629,23 @@ def test_colsum_batch(dev, dtype):
 
 
 def test_conv_wgrad_batch_equals_single_calls(dev):
-    """gwd_conv_wgrad_batch: 40 mixed jobs (plain GEMMs on both grouped tile shapes - more than one group's worth -, a
-    3x3 convolution, a narrow layer, a shared gradient buffer) give exactly what 40 gwd_conv_wgrad calls give up to the
-    order of the fp32 atomics."""
+    """gwd_conv_wgrad_batch: 52 mixed jobs (plain GEMMs, 3x3 and strided convolutions on all three grouped tile shapes - more than
+    one group's worth of the first -, a shared gradient buffer) give exactly what 52 gwd_conv_wgrad calls give up to the order of the
+    fp32 atomics."""
     dt = torch.bfloat16
+    # (B, H, W, Cin, Cout, k[, stride]): every grouped class - 128 x 128 / 64 x 64 / 32 x 128 tiles x plain GEMM / same-size 3x3 / strided
     specs = [(2400, 1, 1, 256, 256, 1), (800, 1, 1, 256, 2048, 1), (300, 1, 1, 2048, 256, 1), (19200, 1, 1, 64, 128, 1),
-             (2, 12, 16, 64, 64, 3), (4800, 1, 1, 128, 24, 1), (153600, 1, 1, 64, 64, 1), (1176, 1, 1, 64, 192, 1)]
+             (2, 12, 16, 64, 64, 3), (4800, 1, 1, 128, 24, 1), (153600, 1, 1, 64, 64, 1), (1176, 1, 1, 64, 192, 1),
+             (2, 30, 40, 128, 128, 3), (2, 30, 40, 256, 128, 3, 2), (2, 24, 32, 64, 64, 3, 2), (2, 30, 40, 128, 16, 3), (2, 30, 40, 256, 512, 1, 2)]
     jobs, refs = [], []
-    for i in range(40):
-        B, H, W, Ci, Co, K = specs[i % len(specs)]
+    for i in range(52):
+        B, H, W, Ci, Co, K = specs[i % len(specs)][:6]
+        st = specs[i % len(specs)][6] if len(specs[i % len(specs)]) > 6 else 1
+        Ho, Wo = conv_out(H, K, st, K // 2), conv_out(W, K, st, K // 2)
         x = rnd(B, H, W, Ci, dtype=dt, seed=i).cuda()
-        gy = rnd(B, H, W, Co, dtype=dt, seed=50 + i).cuda()
-        dims = (B, H, W, Ci, H, W, Co, K, K)
-        kw = dict(stride=1, pad=K // 2)
+        gy = rnd(B, Ho, Wo, Co, dtype=dt, seed=50 + i).cuda()
+        dims = (B, H, W, Ci, Ho, Wo, Co, K, K)
+        kw = dict(stride=st, pad=K // 2)
         dw = rnd(Co, K, K, Ci, seed=200 + i).cuda()
         ref = dw.clone()
         dev.conv_wgrad(x, gy, ref, dims, **kw)
