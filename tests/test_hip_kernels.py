@@ -651,12 +651,13 @@ def test_conv_wgrad_batch_equals_single_calls(dev):
         dev.conv_wgrad(x, gy, ref, dims, **kw)
         jobs.append((x, gy, dw, dims, kw))
         refs.append(ref)
-    jobs[8] = jobs[8][:2] + (jobs[0][2],) + jobs[8][3:]          # job 8 (same shape as job 0) accumulates into job 0's buffer
-    dev.conv_wgrad(jobs[8][0], jobs[8][1], refs[0], jobs[8][3], **jobs[8][4])
+    twin = len(specs)                                            # job `twin` (same shape as job 0) accumulates into job 0's buffer
+    jobs[twin] = jobs[twin][:2] + (jobs[0][2],) + jobs[twin][3:]
+    dev.conv_wgrad(jobs[twin][0], jobs[twin][1], refs[0], jobs[twin][3], **jobs[twin][4])
     dev.conv_wgrad_batch(jobs)
     torch.cuda.synchronize()
     for i, (j, r) in enumerate(zip(jobs, refs)):
-        if i == 8:
+        if i == twin:
             continue
         assert rel(j[2], r) < 1e-5, i
 
