@@ -45,7 +45,74 @@ __global__ void winmap_kernel(const uint4 *__restrict__ src, uint4 *__restrict__
     }
 }
 
+// up to GWD_WINMAP_JOBS maps of the same geometry (different channel counts) in ONE launch: job = blockIdx.y.  A Swin block with class
+// tokens partitions / reverses three maps (features, depth tokens, seg tokens) at every hand-over; as separate launches each of the
+// small ones cost a full dependent-launch slot (~6 us) for a few hundred KB.
+struct WinJobs {
+    const uint4 *src[GWD_WINMAP_JOBS];
+    uint4 *dst[GWD_WINMAP_JOBS];
+    const uint4 *res[GWD_WINMAP_JOBS];
+    int cv[GWD_WINMAP_JOBS];
+};
+template <bool GATHER, typename T>
+__global__ void winmap_multi_kernel(const WinJobs j, int B, int H, int W, int shift) {
+    const int job = blockIdx.y, CV = j.cv[job];
+    const uint4 *__restrict__ src = j.src[job];
+    uint4 *__restrict__ dst = j.dst[job];
+    const uint4 *__restrict__ res = j.res[job];
+    const int Hp = (H + 6) / 7 * 7, Wp = (W + 6) / 7 * 7, nwx = Wp / 7, nwy = Hp / 7;
+    const int64_t total = (int64_t)B * Hp * Wp * CV;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        int64_t r = i / CV;
+        const int t = (int)(r % 49);
+        r /= 49;
+        const int wx = (int)(r % nwx);
+        r /= nwx;
+        const int wy = (int)(r % nwy);
+        const int b = (int)(r / nwy);
+        int py = wy * 7 + t / 7 + shift, px = wx * 7 + t % 7 + shift;
+        if (py >= Hp) py -= Hp;
+        if (px >= Wp) px -= Wp;
+        const bool inside = py < H && px < W;
+        const int64_t map_idx = (((int64_t)b * H + py) * W + px) * CV + cv;
+        if (GATHER) {
+            dst[i] = inside ? src[map_idx] : make_uint4(0u, 0u, 0u, 0u);
+        } else if (inside) {
+            dst[map_idx] = res ? add_vec<T>(src[i], res[map_idx]) : src[i];
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int gwd_window_map_multi(const void *const *src, void *const *dst, const void *const *residual, const int32_t *C, int32_t n,
+                                    int32_t B, int32_t H, int32_t W, int32_t shift, int32_t gather, int32_t dtype, void *stream) {
+    if (!src || !dst || !C || n <= 0 || n > GWD_WINMAP_JOBS || B <= 0 || H <= 0 || W <= 0 || shift < 0 || shift >= 7) return -1;
+    const int esz = dtype == GWD_BF16 ? 2 : (dtype == GWD_F32 ? 4 : 0);
+    if (!esz) return -2;
+    const int Hp = (H + 6) / 7 * 7, Wp = (W + 6) / 7 * 7;
+    WinJobs j;
+    int64_t most = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!src[i] || !dst[i] || C[i] <= 0) return -1;
+        if (gather && residual && residual[i]) return -1;
+        if ((C[i] * esz) % 16) return -4;
+        j.src[i] = (const uint4 *)src[i];
+        j.dst[i] = (uint4 *)dst[i];
+        j.res[i] = residual ? (const uint4 *)residual[i] : nullptr;
+        j.cv[i] = C[i] * esz / 16;
+        const int64_t total = (int64_t)B * Hp * Wp * j.cv[i];
+        most = total > most ? total : most;
+    }
+    const int64_t nb = (most + 255) / 256;
+    const dim3 grid((unsigned)(nb > 8192 ? 8192 : nb), (unsigned)n);
+    if (gather) winmap_multi_kernel<true, float><<<grid, 256, 0, (hipStream_t)stream>>>(j, B, H, W, shift);
+    else if (dtype == GWD_BF16) winmap_multi_kernel<false, __bf16><<<grid, 256, 0, (hipStream_t)stream>>>(j, B, H, W, shift);
+    else winmap_multi_kernel<false, float><<<grid, 256, 0, (hipStream_t)stream>>>(j, B, H, W, shift);
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int gwd_window_map(const void *src, void *dst, const void *residual, int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift,
                               int32_t gather, int32_t dtype, void *stream) {

@@ -25,7 +25,7 @@ ENTRY_POINTS = [
     "gwd_softmax_backward", "gwd_silog_sums", "gwd_silog_backward", "gwd_seg_ce_sum", "gwd_seg_ce_backward",
     "gwd_sqnorm", "gwd_adamw_step", "gwd_resample_forward", "gwd_resample_backward", "gwd_avgpool_forward",
     "gwd_avgpool_backward", "gwd_winattn_forward", "gwd_winattn_backward", "gwd_tokattn_forward",
-    "gwd_tokattn_backward", "gwd_certain_sample", "gwd_lsap", "gwd_window_map",
+    "gwd_tokattn_backward", "gwd_certain_sample", "gwd_lsap", "gwd_window_map", "gwd_window_map_multi",
     "gwd_inorm_gelu_forward", "gwd_inorm_gelu_backward", "gwd_weight_prep_batch",
     "gwd_point_sample_forward", "gwd_point_sample_backward", "gwd_act_backward_colsum", "gwd_resample_backward_sep",
     "gwd_softmax_masked_forward", "gwd_softmax_scaled_backward", "gwd_query_workspace", "gwd_eval_accumulate", "gwd_colsum_batch", "gwd_conv_wgrad_batch",
@@ -225,6 +225,7 @@ class HipLibrary:
         L.gwd_point_sample_backward_gather.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_weight_prep_batch.argtypes = [vp, i32, i32, vp, vp]
         L.gwd_window_map.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+        L.gwd_window_map_multi.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_sqnorm.argtypes = [vp, vp, i64, vp]
         L.gwd_adamw_step.argtypes = [vp, vp, vp, vp, vp, vp, i64] + [f32] * 9 + [vp]
 
@@ -755,6 +756,16 @@ class HipLibrary:
     def window_map(self, src, dst, B, H, W, C, shift, gather, residual=None):
         self._check(self.lib.gwd_window_map(_ptr(src), _ptr(dst), _ptr(residual), B, H, W, C, shift, int(gather), dtype_code(src),
                                             self._stream(src, dst)), "gwd_window_map")
+
+    def window_map_multi(self, srcs, dsts, B, H, W, Cs, shift, gather, residuals=None):
+        """gwd_window_map for up to 4 maps of one geometry in one launch (residuals: list with None entries, or None)."""
+        n = len(srcs)
+        vpn, i32n = ctypes.c_void_p * n, ctypes.c_int32 * n
+        res = [None] * n if residuals is None else list(residuals)
+        addr = lambda t: None if t is None else _ptr(t).value
+        self._check(self.lib.gwd_window_map_multi(vpn(*[addr(t) for t in srcs]), vpn(*[addr(t) for t in dsts]), vpn(*[addr(t) for t in res]),
+                                                  i32n(*[int(c) for c in Cs]), n, B, H, W, shift, int(gather), dtype_code(srcs[0]),
+                                                  self._stream(*srcs, *dsts)), "gwd_window_map_multi")
 
     def sqnorm(self, g, sq, n):
         self._check(self.lib.gwd_sqnorm(_ptr(g), _ptr(sq), n, self._stream(g, sq)), "gwd_sqnorm")

@@ -512,6 +512,9 @@ def unroll_crop(win, H, W, Hp, Wp, shift):
     return t[:, :H, :W, :]
 
 
+FUSE_TOKEN_LAUNCHES = True      # class-token Swin blocks: the depth / seg token streams share launches with each other and the feature map
+
+
 class SwinBlock(nn.Module):
     """SwinTransformerBlock.forward, multiscale_transformerr.py:646-788."""
 
@@ -549,15 +552,19 @@ class SwinBlock(nn.Module):
             tC = dtok.shape[-1]
             dn, dtok = self.norm_depth1(dtok, fan=True)
             sn, stok = self.norm_seg1(stok, fan=True)
-            dn = ops.window_gather(dn.view(B, H, W, tC), shift)
-            sn = ops.window_gather(sn.view(B, H, W, tC), shift)
-            aw, dw, sw = self.attn(ops.window_gather(xn, shift), dn, sn, mask)
-            x = ops.window_scatter(aw, B, H, W, shift, residual=x).view(B, H * W, C)
-            x = self.mlp(*self.norm2(x, fan=True))
-            d = ops.window_scatter(dw, B, H, W, shift, residual=dtok).view(B, H * W, tC)
-            d = self.mlp_depth(*self.norm_depth2(d, fan=True))
-            s = ops.window_scatter(sw, B, H, W, shift, residual=stok).view(B, H * W, tC)
-            s = self.mlp_seg(*self.norm_seg2(s, fan=True))
+            # the three maps of the block are partitioned / reversed together: one launch each way instead of three
+            if FUSE_TOKEN_LAUNCHES:
+                xw, dn, sn = ops.window_gather_multi([xn, dn.view(B, H, W, tC), sn.view(B, H, W, tC)], shift)
+            else:
+                xw, dn, sn = (ops.window_gather(t, shift) for t in (xn, dn.view(B, H, W, tC), sn.view(B, H, W, tC)))
+            aw, dw, sw = self.attn(xw, dn, sn, mask)
+            if FUSE_TOKEN_LAUNCHES:
+                x, d, s = ops.window_scatter_multi([aw, dw, sw], B, H, W, shift, [x, dtok, stok])
+            else:
+                x, d, s = (ops.window_scatter(w_, B, H, W, shift, residual=r_) for w_, r_ in ((aw, x), (dw, dtok), (sw, stok)))
+            x = self.mlp(*self.norm2(x.view(B, H * W, C), fan=True))
+            d = self.mlp_depth(*self.norm_depth2(d.view(B, H * W, tC), fan=True))
+            s = self.mlp_seg(*self.norm_seg2(s.view(B, H * W, tC), fan=True))
             return x, d, s
         x = ops.window_scatter(aw, B, H, W, shift, residual=x).view(B, H * W, C)     # window reverse + un-shift + crop + skip
         x = self.mlp(*self.norm2(x, fan=True))              # mlp(norm(x), residual = x)

@@ -1490,6 +1490,60 @@ class _WindowScatterFn(torch.autograd.Function):
         return gw, None, None, None, None, (g.view(rshape) if rshape else None)
 
 
+class _WindowGatherMultiFn(torch.autograd.Function):
+    """window_gather of several maps of one geometry (features + class tokens of a Swin block) as ONE launch each way."""
+
+    @staticmethod
+    def forward(ctx, shift, *xs):
+        xs = [x.contiguous() for x in xs]
+        B, H, W = xs[0].shape[:3]
+        Hp, Wp = (H + 6) // 7 * 7, (W + 6) // 7 * 7
+        outs = [torch.empty((B * (Hp // 7) * (Wp // 7), 49, x.shape[-1]), dtype=x.dtype, device=x.device) for x in xs]
+        _lib().window_map_multi(xs, outs, B, H, W, [x.shape[-1] for x in xs], shift, True)
+        ctx.cfg = (B, H, W, shift, [x.shape[-1] for x in xs])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        B, H, W, shift, Cs = ctx.cfg
+        gs = [g.contiguous() for g in gs]
+        gxs = [torch.empty((B, H, W, c), dtype=g.dtype, device=g.device) for g, c in zip(gs, Cs)]
+        _lib().window_map_multi(gs, gxs, B, H, W, Cs, shift, False)
+        return (None,) + tuple(gxs)
+
+
+class _WindowScatterMultiFn(torch.autograd.Function):
+    """window_scatter (+ residual streams) of several maps of one geometry as ONE launch each way; args: n windows, then n residuals."""
+
+    @staticmethod
+    def forward(ctx, B, H, W, shift, n, *ts):
+        wins = [t.contiguous() for t in ts[:n]]
+        ress = [None if r is None else r.contiguous() for r in ts[n:]]
+        Cs = [w.shape[-1] for w in wins]
+        outs = [torch.empty((B, H, W, c), dtype=w.dtype, device=w.device) for w, c in zip(wins, Cs)]
+        _lib().window_map_multi(wins, outs, B, H, W, Cs, shift, False, residuals=ress)
+        ctx.cfg = (B, H, W, shift, Cs, [tuple(w.shape) for w in wins], [r is not None and tuple(r.shape) for r in ts[n:]])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        B, H, W, shift, Cs, shapes, rshapes = ctx.cfg
+        gs = [g.contiguous() for g in gs]
+        gws = [torch.empty(sh, dtype=g.dtype, device=g.device) for g, sh in zip(gs, shapes)]
+        _lib().window_map_multi(gs, gws, B, H, W, Cs, shift, True)
+        return (None,) * 5 + tuple(gws) + tuple((g.view(rs) if rs else None) for g, rs in zip(gs, rshapes))
+
+
+def window_gather_multi(xs, shift):
+    """[window_gather(x, shift) for x in xs] (maps of one (B, H, W), any channel counts, at most 4) in one launch."""
+    return _WindowGatherMultiFn.apply(int(shift), *xs)
+
+
+def window_scatter_multi(wins, B, H, W, shift, residuals):
+    """[window_scatter(w, B, H, W, shift, r) for w, r in zip(wins, residuals)] in one launch."""
+    return _WindowScatterMultiFn.apply(int(B), int(H), int(W), int(shift), len(wins), *wins, *residuals)
+
+
 def window_gather(x, shift):
     """(B,H,W,C) -> (B*nWin, 49, C): zero-pad to multiples of 7, cyclic shift by -shift, 7x7 window partition."""
     return _WindowGatherFn.apply(x, int(shift))

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GWD_VERSION 8
+#define GWD_VERSION 9
 
 enum { GWD_F32 = 0, GWD_BF16 = 1 };
 enum { GWD_ACT_NONE = 0, GWD_ACT_RELU = 1, GWD_ACT_GELU = 2, GWD_ACT_ELU = 3, GWD_ACT_SIGMOID = 4 };
@@ -376,6 +376,12 @@ int gwd_inorm_gelu_backward(const void *gy, const void *u, const float *stat, fl
  * map added to the result - the block's residual stream, `x = shortcut + x` of :749.                           */
 int gwd_window_map(const void *src, void *dst, const void *residual, int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift,
                    int32_t gather, int32_t dtype, void *stream);
+/* The same for n <= GWD_WINMAP_JOBS maps of one geometry (B, H, W, shift) and channel counts C[i] in ONE launch: the three maps a
+ * Swin block with class tokens hands over together (features, depth tokens, seg tokens: multiscale_transformerr.py:700-747).
+ * src / dst / residual: HOST arrays of n device pointers (residual, or single entries of it, may be NULL).        */
+#define GWD_WINMAP_JOBS 4
+int gwd_window_map_multi(const void *const *src, void *const *dst, const void *const *residual, const int32_t *C, int32_t n,
+                         int32_t B, int32_t H, int32_t W, int32_t shift, int32_t gather, int32_t dtype, void *stream);
 
 /* Pixel-major resampling ([B][H][W][C]).  mode 0 = bilinear align_corners=True (PSP branches of
  * src/models/points/points_sample.py:114-121, CertainSample :293), mode 1 = legacy nearest

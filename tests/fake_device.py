@@ -674,6 +674,10 @@ class FakeDevice:
                 x = (x.float() + residual.reshape(x.shape).float()).to(dst.dtype)
             dst.copy_(x.reshape(dst.shape))
 
+    def window_map_multi(self, srcs, dsts, B, H, W, Cs, shift, gather, residuals=None):
+        for i, (s_, d_, c_) in enumerate(zip(srcs, dsts, Cs)):
+            self.window_map(s_, d_, B, H, W, c_, shift, gather, residual=None if residuals is None else residuals[i])
+
     def inorm_gelu_forward(self, a, u, y, part, stat, B, L, C, S, eps):
         uf = u.reshape(B, L, C).float()
         mu = uf.mean(dim=1, keepdim=True)

@@ -417,6 +417,47 @@ def test_device_lsap_matches_scipy(dev, layers, B, Q, sizes):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("geom", [(2, 30, 40, 0), (2, 30, 40, 3), (1, 15, 20, 3)])
+def test_window_map_multi_equals_single_maps(dev, geom, dtype):
+    """gwd_window_map_multi: the three maps of a class-token Swin block (features, depth tokens, seg tokens) in one launch, both
+    directions, the reverse with residual streams (one of them absent) - bit for bit what three gwd_window_map calls give; and through
+    ops.window_gather_multi / window_scatter_multi the gradients of the single-map autograd nodes."""
+    from gw_depth_amd import ops
+    B, H, W, shift = geom
+    Cs = [128, 64, 64]
+    Hp, Wp = (H + 6) // 7 * 7, (W + 6) // 7 * 7
+    nwin = B * (Hp // 7) * (Wp // 7)
+    xs = [rnd(B, H, W, c, dtype=dtype, seed=3 + i).cuda() for i, c in enumerate(Cs)]
+    wins = [torch.full((nwin, 49, c), 7.0, dtype=dtype).cuda() for c in Cs]
+    dev.window_map_multi(xs, wins, B, H, W, Cs, shift, True)
+    for x, w, c in zip(xs, wins, Cs):
+        ref = torch.empty_like(w)
+        dev.window_map(x, ref, B, H, W, c, shift, True)
+        assert torch.equal(w, ref)
+    gs = [rnd(nwin, 49, c, dtype=dtype, seed=13 + i).cuda() for i, c in enumerate(Cs)]
+    ress = [rnd(B, H, W, Cs[0], dtype=dtype, seed=23).cuda(), None, rnd(B, H, W, Cs[2], dtype=dtype, seed=25).cuda()]
+    outs = [torch.empty(B, H, W, c, dtype=dtype).cuda() for c in Cs]
+    dev.window_map_multi(gs, outs, B, H, W, Cs, shift, False, residuals=ress)
+    for g, o, r, c in zip(gs, outs, ress, Cs):
+        ref = torch.empty_like(o)
+        dev.window_map(g, ref, B, H, W, c, shift, False, residual=r)
+        assert torch.equal(o, ref)
+    # autograd nodes
+    leaves = [x.clone().requires_grad_(True) for x in xs]
+    rl = [r.clone().requires_grad_(True) for r in (ress[0], xs[1], ress[2])]
+    multi = ops.window_scatter_multi(list(ops.window_gather_multi(leaves, shift)), B, H, W, shift, rl)
+    sum((m.float() * (i + 1)).sum() for i, m in enumerate(multi)).backward()
+    leaves1 = [x.clone().requires_grad_(True) for x in xs]
+    rl1 = [r.detach().clone().requires_grad_(True) for r in rl]
+    single = [ops.window_scatter(ops.window_gather(x, shift), B, H, W, shift, residual=r) for x, r in zip(leaves1, rl1)]
+    sum((m.float() * (i + 1)).sum() for i, m in enumerate(single)).backward()
+    for a_, b_ in zip(multi, single):
+        assert torch.equal(a_, b_)
+    for a_, b_ in zip(leaves + rl, leaves1 + rl1):
+        assert torch.equal(a_.grad, b_.grad)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(2, 30, 40, 32, 0), (2, 30, 40, 32, 3), (1, 14, 21, 8, 3), (2, 15, 20, 128, 3), (3, 12, 16, 4, 0)])
 def test_window_map(dev, shape, dtype):
     """Index remapping copy: bit-exact in both directions, padded slots zero, and scatter(gather(x)) == x."""
