@@ -39,6 +39,7 @@ struct OperandW {
 struct BiasRef {
     const int *rel;
     int heads, n_rel;
+    int grad_hm;                 // table-shaped gradient stored head-major [heads][n_rel] (a wave's flush is one contiguous run)
     __device__ __forceinline__ long at(int h, int e) const { return rel ? (long)rel[e] * heads + h : (long)h * (49 * 49) + e; }
 };
 
@@ -163,22 +164,55 @@ __device__ __forceinline__ bf16x8 region_frag(const int *__restrict__ region_w, 
     return f;
 }
 
+__device__ __forceinline__ void lds_settle() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // compiler-level ordering of the LDS writes before the reads below
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): this wave's LDS writes are visible to all of its lanes
+    __builtin_amdgcn_wave_barrier();
+}
+
 // the rel-pos bias of one head in S^T accumulator layout: element i of tile (kt, qt) in lane (c, h) is
 // bias[query 32 qt + c][key 32 kt + acc_row(i, h)]; padded keys get -1e30 (softmax weight 0), padded queries 0.
 // All 64 loads are unconditional (clamped addresses) so that they issue back to back - a load under a lane-dependent
 // condition waits for its predecessor: 64 serial L2 round trips were 80 us of fixed cost per wave.
-__device__ __forceinline__ void load_bias(f32x16 (&b)[2][2], const float *__restrict__ bias, const BiasRef &br, int head, int lane) {
+// With a relative-position TABLE ([n_rel][heads], the parameter itself) the head's n_rel entries are staged in wave-private LDS
+// first (three strided loads per lane) and the 64 per-lane values come from there: gathered straight from the table they were 64
+// scattered 4-byte loads per lane, each from its own 64-byte segment - 13-40 us of every forward AND backward launch (bisected with
+// the bias load compiled out: profiles/r03_ablations.txt 14).  tbl: >= 256 floats of the wave's own LDS, free at this point.
+__device__ __forceinline__ void load_bias(f32x16 (&b)[2][2], const float *__restrict__ bias, const BiasRef &br, int head, int lane, float *tbl) {
     const int c = lane & 31, h = lane >> 5;
     float raw[2][2][16];
+    if (br.rel) {
+        for (int e = lane; e < br.n_rel; e += 64) tbl[e] = bias[(long)e * br.heads + head];
+        int ridx[2][2][16];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+            for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int key = 32 * kt + acc_row(i, h), qry = 32 * qt + c;
-                raw[kt][qt][i] = bias[br.at(head, (qry < NT ? qry : NT - 1) * NT + (key < NT ? key : NT - 1))];
-            }
+                for (int i = 0; i < 16; ++i) {
+                    const int key = 32 * kt + acc_row(i, h), qry = 32 * qt + c;
+                    ridx[kt][qt][i] = br.rel[(qry < NT ? qry : NT - 1) * NT + (key < NT ? key : NT - 1)];
+                }
+        lds_settle();
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) raw[kt][qt][i] = tbl[ridx[kt][qt][i]];
+        lds_settle();
+    } else {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = 32 * kt + acc_row(i, h), qry = 32 * qt + c;
+                    raw[kt][qt][i] = bias[br.at(head, (qry < NT ? qry : NT - 1) * NT + (key < NT ? key : NT - 1))];
+                }
+    }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -214,12 +248,6 @@ __device__ __forceinline__ void store_t(const OperandW &op, long w, int head, in
     }
 }
 
-__device__ __forceinline__ void lds_settle() {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // compiler-level ordering of the LDS writes before the reads below
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): this wave's LDS writes are visible to all of its lanes
-    __builtin_amdgcn_wave_barrier();
-}
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int HD, int WAVES>
@@ -231,9 +259,9 @@ __global__ __launch_bounds__(64 * WAVES) void win_fwd_kernel(Operand q, Operand 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int head = blockIdx.y * WAVES + wave;
     __bf16 *qi = smem_f + wave * 3 * G::IMG, *ki = qi + G::IMG, *vi = ki + G::IMG;
-    for (int e = lane * 8; e < 3 * G::IMG; e += 512) *(uint4 *)(qi + e) = make_uint4(0, 0, 0, 0);     // padding rows stay zero
     f32x16 bs[2][2];
-    load_bias(bs, bias, br, head, lane);
+    load_bias(bs, bias, br, head, lane, (float *)qi);     // the images are its scratch: before the zero fill
+    for (int e = lane * 8; e < 3 * G::IMG; e += 512) *(uint4 *)(qi + e) = make_uint4(0, 0, 0, 0);     // padding rows stay zero
     lds_settle();
     constexpr bool WIDE = G::COLS == 32;
     Row<HD> rq, rk, rv;
@@ -320,9 +348,9 @@ __global__ __launch_bounds__(64 * WAVES) void win_bwd_kernel(Operand q, Operand 
     constexpr int PER_WAVE = 4 * G::IMG + 2 * 64 * PK;
     __bf16 *qi = smem_b + wave * PER_WAVE, *ki = qi + G::IMG, *vi = ki + G::IMG, *oi = vi + G::IMG;
     __bf16 *pi = oi + G::IMG, *si = pi + 64 * PK;       // P and dS as [query][key] images
-    for (int e = lane * 8; e < PER_WAVE; e += 512) *(uint4 *)(qi + e) = make_uint4(0, 0, 0, 0);
     f32x16 bs[2][2], db[2][2];
-    load_bias(bs, bias, br, head, lane);
+    load_bias(bs, bias, br, head, lane, (float *)qi);
+    for (int e = lane * 8; e < PER_WAVE; e += 512) *(uint4 *)(qi + e) = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -469,6 +497,9 @@ __global__ __launch_bounds__(64 * WAVES) void win_bwd_kernel(Operand q, Operand 
         float *acc = (float *)pi;
         for (int e = lane; e < 256; e += 64) acc[e] = 0.f;
         lds_settle();
+        // the 64 table-row indices of this lane first, unconditional (clamped addresses) and back to back: under the lane-dependent
+        // bound every one of them waits for its predecessor
+        int ridx[2][2][16];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -476,10 +507,26 @@ __global__ __launch_bounds__(64 * WAVES) void win_bwd_kernel(Operand q, Operand 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int key = 32 * kt + acc_row(i, h), qry = 32 * qt + c;
-                    if (key < NT && qry < NT) atomicAdd(acc + br.rel[qry * NT + key], db[kt][qt][i]);
+                    ridx[kt][qt][i] = br.rel[(qry < NT ? qry : NT - 1) * NT + (key < NT ? key : NT - 1)];
+                }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = 32 * kt + acc_row(i, h), qry = 32 * qt + c;
+                    if (key < NT && qry < NT) atomicAdd(acc + ridx[kt][qt][i], db[kt][qt][i]);
                 }
         lds_settle();
-        for (int e = lane; e < br.n_rel; e += 64) unsafeAtomicAdd(dbias + (long)e * br.heads + head, acc[e]);
+        // Table-shaped ([n_rel][heads]) the wave's n_rel atomics land 4 bytes each in n_rel different 64-byte segments, from every wave
+        // of the launch: the slow shape of MI355X_MICROARCH.md 'Global float atomics' (x17) - 41-59 us of EVERY backward launch.
+        // Head-major ([heads][n_rel]: the caller's scratch, added to the table gradient afterwards) it is one contiguous run per wave.
+        if (br.grad_hm) {
+            for (int e = lane; e < br.n_rel; e += 64) unsafeAtomicAdd(dbias + (long)head * br.n_rel + e, acc[e]);
+        } else {
+            for (int e = lane; e < br.n_rel; e += 64) unsafeAtomicAdd(dbias + (long)e * br.heads + head, acc[e]);
+        }
     }
 }
 
@@ -532,9 +579,9 @@ int launch(bool backward, const Args &a, const float *bias, float *dbias, const 
 int gwd_mfattn_window(bool backward, const gwd_strided *q, const gwd_strided *k, const gwd_strided *v, const gwd_strided *o_or_go,
                       const gwd_strided *gq, const gwd_strided *gk, const gwd_strided *gv, const float *bias, float *dbias,
                       const int32_t *rel_index, int32_t n_rel, const int32_t *region, int64_t n_windows, int32_t wpi, int32_t heads,
-                      int32_t head_dim, float scale, hipStream_t s) {
+                      int32_t head_dim, float scale, int32_t dbias_head_major, hipStream_t s) {
     using namespace mfattn;
-    const BiasRef br{rel_index, heads, n_rel};
+    const BiasRef br{rel_index, heads, n_rel, (rel_index && dbias_head_major) ? 1 : 0};
     Args a{};
     a.q = {q->p, q->ws, q->ts, q->hs};
     a.k = {k->p, k->ws, k->ts, k->hs};

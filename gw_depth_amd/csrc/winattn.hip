@@ -26,7 +26,9 @@ struct Operand {
 struct BiasRef {
     const int *rel;
     int heads;
+    int n_rel, grad_hm;          // grad_hm: the table-shaped GRADIENT is head-major [heads][n_rel] (gwd_winattn_backward's dbias_head_major)
     __device__ __forceinline__ long at(int h, int e) const { return rel ? (long)rel[e] * heads + h : (long)h * (NT * NT) + e; }
+    __device__ __forceinline__ long grad_at(int h, int e) const { return (rel && grad_hm) ? (long)h * n_rel + rel[e] : at(h, e); }
 };
 struct OperandW {
     void *p;
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(Operand q, Operand k, 
             for (int j = 0; j < NT; ++j) atomicAdd(&dbias_s[i * NT + j], db[j]);
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < NT * NT; e += blockDim.x) unsafeAtomicAdd(dbias + br.at(h, e), dbias_s[e]);
+        for (int e = threadIdx.x; e < NT * NT; e += blockDim.x) unsafeAtomicAdd(dbias + br.grad_at(h, e), dbias_s[e]);
     }
 }
 
@@ -332,7 +334,7 @@ int dispatch_hd(int hd, bool backward, const Args &a, const float *bias, float *
 int gwd_mfattn_window(bool backward, const gwd_strided *q, const gwd_strided *k, const gwd_strided *v, const gwd_strided *o_or_go,
                       const gwd_strided *gq, const gwd_strided *gk, const gwd_strided *gv, const float *bias, float *dbias,
                       const int32_t *rel_index, int32_t n_rel, const int32_t *region, int64_t n_windows, int32_t wpi, int32_t heads,
-                      int32_t head_dim, float scale, hipStream_t s);
+                      int32_t head_dim, float scale, int32_t dbias_head_major, hipStream_t s);
 
 static bool mfma_window_enabled() { return true; }      // bf16 with aligned operands: csrc/mfattn.hip; the lane-per-row kernels below are the fp32 (parity) path
 
@@ -342,7 +344,7 @@ extern "C" int gwd_winattn_forward(const gwd_strided *q, const gwd_strided *k, c
                                    int32_t dtype, void *stream) {
     if (!q || !k || !v || !o || !q->p || !k->p || !v->p || !o->p || !bias || n_windows <= 0 || heads <= 0) return -1;
     if (rel_index && (n_rel <= 0 || n_rel > 256)) return -1;
-    const BiasRef br{rel_index, heads};
+    const BiasRef br{rel_index, heads, n_rel, 0};
     if (region && windows_per_image <= 0) return -1;
     Args a{};
     a.q = {q->p, q->ws, q->ts, q->hs};
@@ -351,7 +353,7 @@ extern "C" int gwd_winattn_forward(const gwd_strided *q, const gwd_strided *k, c
     a.o = {o->p, o->ws, o->ts, o->hs};
     if (dtype == GWD_BF16 && mfma_window_enabled()) {
         const int rc = gwd_mfattn_window(false, q, k, v, o, nullptr, nullptr, nullptr, bias, nullptr, rel_index, n_rel, region, n_windows,
-                                         windows_per_image, heads, head_dim, scale, (hipStream_t)stream);
+                                         windows_per_image, heads, head_dim, scale, 0, (hipStream_t)stream);
         if (rc <= 0) {
             if (rc == 0) GWD_CHECK_LAUNCH();
             return rc;
@@ -365,11 +367,12 @@ extern "C" int gwd_winattn_forward(const gwd_strided *q, const gwd_strided *k, c
 extern "C" int gwd_winattn_backward(const gwd_strided *q, const gwd_strided *k, const gwd_strided *v, const gwd_strided *go,
                                     const gwd_strided *gq, const gwd_strided *gk, const gwd_strided *gv, const float *bias,
                                     float *dbias, const int32_t *rel_index, int32_t n_rel, const int32_t *region, int64_t n_windows,
-                                    int32_t windows_per_image, int32_t heads, int32_t head_dim, float scale, int32_t dtype,
-                                    void *stream) {
+                                    int32_t windows_per_image, int32_t heads, int32_t head_dim, float scale, int32_t dbias_head_major,
+                                    int32_t dtype, void *stream) {
     if (!q || !k || !v || !go || !gq || !gk || !gv || !bias || n_windows <= 0 || heads <= 0) return -1;
     if (rel_index && (n_rel <= 0 || n_rel > 256)) return -1;
-    const BiasRef br{rel_index, heads};
+    if (dbias_head_major && !rel_index) return -1;             // only the table-shaped gradient has a second layout
+    const BiasRef br{rel_index, heads, n_rel, dbias_head_major ? 1 : 0};
     if (!q->p || !k->p || !v->p || !go->p || !gq->p || !gk->p || !gv->p) return -1;
     if (region && windows_per_image <= 0) return -1;
     Args a{};
@@ -382,7 +385,7 @@ extern "C" int gwd_winattn_backward(const gwd_strided *q, const gwd_strided *k, 
     a.gv = {gv->p, gv->ws, gv->ts, gv->hs};
     if (dtype == GWD_BF16 && mfma_window_enabled()) {
         const int rc = gwd_mfattn_window(true, q, k, v, go, gq, gk, gv, bias, dbias, rel_index, n_rel, region, n_windows, windows_per_image,
-                                         heads, head_dim, scale, (hipStream_t)stream);
+                                         heads, head_dim, scale, dbias_head_major, (hipStream_t)stream);
         if (rc <= 0) {
             if (rc == 0) GWD_CHECK_LAUNCH();
             return rc;

@@ -202,7 +202,7 @@ class HipLibrary:
         L.gwd_avgpool_backward.argtypes = [vp, vp] + [i32] * 6 + [vp]
         sp = ctypes.POINTER(Strided)
         L.gwd_winattn_forward.argtypes = [sp, sp, sp, sp, vp, vp, i32, vp, i64, i32, i32, i32, f32, i32, vp]
-        L.gwd_winattn_backward.argtypes = [sp] * 7 + [vp, vp, vp, i32, vp, i64, i32, i32, i32, f32, i32, vp]
+        L.gwd_winattn_backward.argtypes = [sp] * 7 + [vp, vp, vp, i32, vp, i64, i32, i32, i32, f32, i32, i32, vp]
         L.gwd_ref_scores_forward.argtypes = [sp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
         L.gwd_ref_scores_backward.argtypes = [sp, vp, vp, sp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
         L.gwd_ref_mix_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
@@ -583,13 +583,14 @@ class HipLibrary:
         self._check(self.lib.gwd_winattn_forward(*[ctypes.byref(x) for x in s], _ptr(bias), _ptr(rel_index), n_rel, _ptr(region), W, wpi,
                                                  H, D, scale, dtype_code(q), self._stream(q, k, v, o, bias, rel_index)), "gwd_winattn_forward")
 
-    def winattn_backward(self, q, k, v, go, gq, gk, gv, bias, dbias, region, wpi, scale, rel_index=None):
-        """dbias: same layout as bias (dense, or the table's gradient with rel_index); ACCUMULATED into."""
+    def winattn_backward(self, q, k, v, go, gq, gk, gv, bias, dbias, region, wpi, scale, rel_index=None, head_major=False):
+        """dbias: same layout as bias (dense, or the table's gradient with rel_index); ACCUMULATED into.  head_major (rel_index only):
+        dbias is a (heads, n_rel) scratch instead of the (n_rel, heads) table gradient."""
         W, N, H, D = q.shape
         s = [_strided(t) for t in (q, k, v, go, gq, gk, gv)]
         n_rel = bias.shape[0] if rel_index is not None else 0
         self._check(self.lib.gwd_winattn_backward(*[ctypes.byref(x) for x in s], _ptr(bias), _ptr(dbias), _ptr(rel_index), n_rel,
-                                                  _ptr(region), W, wpi, H, D, scale, dtype_code(q),
+                                                  _ptr(region), W, wpi, H, D, scale, int(bool(head_major)), dtype_code(q),
                                                   self._stream(q, go, gq, bias, dbias, rel_index)), "gwd_winattn_backward")
 
     def ref_scores_forward(self, q, ref_k, ra, B, nwin, scale):

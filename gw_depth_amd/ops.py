@@ -1237,13 +1237,34 @@ class _WinAttnPackedFn(torch.autograd.Function):
         W, N, _, H, D = qkv.shape
         go = go.contiguous().view(W, N, H, D)
         g = torch.empty_like(qkv)
-        direct = ctx.sink is not None
-        dtab = ctx.sink[0] if direct else torch.zeros_like(tb)
-        _lib().winattn_backward(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], go, g[:, :, 0], g[:, :, 1], g[:, :, 2], tb, dtab, region,
-                                wpi, scale, rel_index=rel)
-        if direct and ctx.sink[1] is not None:
-            ctx.sink[1]()
-        return g, (None if direct else dtab), None, None, None, None, None
+        gtab = _winattn_table_grad(tb, ctx.sink, lambda dtab, hm: _lib().winattn_backward(
+            qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], go, g[:, :, 0], g[:, :, 1], g[:, :, 2], tb, dtab, region, wpi, scale, rel_index=rel, head_major=hm), rel)
+        return g, gtab, None, None, None, None, None
+
+
+TABLE_GRAD_HEAD_MAJOR = True
+
+
+def _winattn_table_grad(tb, sink, run, rel):
+    """Backward of the relative-position table of a window attention: run(dbias, head_major) launches the kernel.  On the device the
+    kernel accumulates into a zeroed (heads, n_rel) scratch - a wave's flush is then one contiguous run of atomics instead of n_rel
+    4-byte adds in n_rel different 64-byte segments, 41-59 us of every launch - and the transposed scratch is added to the table's
+    gradient (the flat-buffer slice when there is a sink).  Returns what autograd gets for the table (None with a sink)."""
+    direct = sink is not None
+    if TABLE_GRAD_HEAD_MAJOR and tb.is_cuda and rel is not None:
+        tmp = WGRADS.scratch((tb.shape[1], tb.shape[0]), tb.device)
+        run(tmp, True)
+        if not direct:
+            return tmp.t().contiguous()
+        sink[0].view(tb.shape).add_(tmp.t())
+    else:
+        dtab = sink[0] if direct else torch.zeros_like(tb)
+        run(dtab, False)
+        if not direct:
+            return dtab
+    if sink[1] is not None:
+        sink[1]()
+    return None
 
 
 class _WinAttnFn(torch.autograd.Function):
@@ -1269,12 +1290,9 @@ class _WinAttnFn(torch.autograd.Function):
         W, N, H, D = q.shape
         go = go.contiguous().view(W, N, H, D)
         gq, gk, gv = (torch.empty((W, N, H, D), dtype=q.dtype, device=q.device) for _ in range(3))
-        direct = ctx.sink is not None
-        dtab = ctx.sink[0] if direct else torch.zeros_like(tb)
-        _lib().winattn_backward(q, k, v, go, gq, gk, gv, tb, dtab, region, wpi, scale, rel_index=rel)
-        if direct and ctx.sink[1] is not None:
-            ctx.sink[1]()
-        return gq, gk, gv, (None if direct else dtab), None, None, None, None, None
+        gtab = _winattn_table_grad(tb, ctx.sink, lambda dtab, hm: _lib().winattn_backward(
+            q, k, v, go, gq, gk, gv, tb, dtab, region, wpi, scale, rel_index=rel, head_major=hm), rel)
+        return gq, gk, gv, gtab, None, None, None, None, None
 
 
 class _WinAttnQFn(torch.autograd.Function):
@@ -1302,12 +1320,9 @@ class _WinAttnQFn(torch.autograd.Function):
         gq = torch.empty_like(q_new)
         g = torch.empty_like(qkv)
         g[:, :, 0].zero_()
-        direct = ctx.sink is not None
-        dtab = ctx.sink[0] if direct else torch.zeros_like(tb)
-        _lib().winattn_backward(q_new, qkv[:, :, 1], qkv[:, :, 2], go, gq, g[:, :, 1], g[:, :, 2], tb, dtab, region, wpi, scale, rel_index=rel)
-        if direct and ctx.sink[1] is not None:
-            ctx.sink[1]()
-        return gq, g, (None if direct else dtab), None, None, None, None, None
+        gtab = _winattn_table_grad(tb, ctx.sink, lambda dtab, hm: _lib().winattn_backward(
+            q_new, qkv[:, :, 1], qkv[:, :, 2], go, gq, g[:, :, 1], g[:, :, 2], tb, dtab, region, wpi, scale, rel_index=rel, head_major=hm), rel)
+        return gq, g, gtab, None, None, None, None, None
 
 
 def window_attention_qkv(q_new, qkv, table, rel, region, windows_per_image, scale):

@@ -228,7 +228,11 @@ int gwd_winattn_forward(const gwd_strided *q, const gwd_strided *k, const gwd_st
 int gwd_winattn_backward(const gwd_strided *q, const gwd_strided *k, const gwd_strided *v, const gwd_strided *go,
                          const gwd_strided *gq, const gwd_strided *gk, const gwd_strided *gv, const float *bias,
                          float *dbias, const int32_t *rel_index, int32_t n_rel, const int32_t *region, int64_t n_windows,
-                         int32_t windows_per_image, int32_t heads, int32_t head_dim, float scale, int32_t dtype, void *stream);
+                         int32_t windows_per_image, int32_t heads, int32_t head_dim, float scale, int32_t dbias_head_major,
+                         int32_t dtype, void *stream);
+/* dbias_head_major (with rel_index only): dbias is a [heads][n_rel] scratch instead of the [n_rel][heads] table gradient - a wave's
+ * flush is then one contiguous run of atomics instead of n_rel 4-byte adds in n_rel different 64-byte segments (41-59 us of every
+ * backward launch); the caller adds the transposed scratch to the table's gradient.                                             */
 
 /* Line-point-guided query rewrite of the 1/32-stage WindowAttention (src/models/multiscale_transformerr.py:295-310), the two
  * batched einsums of the reference as kernels that write the layout their consumer reads:

@@ -589,7 +589,7 @@ class FakeDevice:
         p = F.softmax(self._winattn_scores(q, k, self._dense_bias(bias, rel_index), region, wpi, scale), dim=-1)
         o.copy_(torch.einsum("whij,wjhd->wihd", p, v.float()))
 
-    def winattn_backward(self, q, k, v, go, gq, gk, gv, bias, dbias, region, wpi, scale, rel_index=None):
+    def winattn_backward(self, q, k, v, go, gq, gk, gv, bias, dbias, region, wpi, scale, rel_index=None, head_major=False):
         qf, kf, vf = (t.detach().float().clone().requires_grad_(True) for t in (q, k, v))
         bf = bias.detach().clone().requires_grad_(True)
         with torch.enable_grad():
@@ -600,7 +600,7 @@ class FakeDevice:
         gk.copy_(g[1])
         gv.copy_(g[2])
         if dbias is not None:
-            dbias.add_(g[3])
+            dbias.add_(g[3].t() if head_major else g[3])
 
     def ref_scores_forward(self, q, ref_k, ra, B, nwin, scale):
         """multiscale_transformerr.py:296-298: (q * scale) @ ref_k^T per head, written pixel-major (B, nwin*49, R, H)."""

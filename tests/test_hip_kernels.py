@@ -369,6 +369,12 @@ def test_window_attention(dev, hd, nwin, wpi, shifted, dtype, table):
     for idx, name in enumerate(("dq", "dk", "dv")):
         assert rel(G[:, :, idx], g_r[:, :, idx]) < TOL[dtype], name
     assert rel(db, db_r) < TOL[dtype], "dbias"
+    if table:       # the head-major scratch form of the table gradient (dbias_head_major): what ops._winattn_table_grad uses on the device
+        G2, db_hm = torch.full_like(g_r, float("nan")).cuda(), torch.zeros(H, 169).cuda()
+        dev.winattn_backward(Q[:, :, 0], Q[:, :, 1], Q[:, :, 2], go.cuda(), G2[:, :, 0], G2[:, :, 1], G2[:, :, 2], bias.cuda(), db_hm,
+                             rg, wpi, scale, rel_index=rl, head_major=True)
+        assert rel(db_hm.t(), db_r) < TOL[dtype], "dbias, head-major"
+        assert rel(G2, g_r) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
