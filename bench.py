@@ -413,7 +413,7 @@ def dominant_kernel_roofline(lib, dtype):
     except (OSError, KeyError, ValueError):
         pass
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "traffic": traffic, "traffic_measured": stamp, "kernel": "igemm_dma_kernel<256,160,8,1,3,1,...> (%s) conv3x3 160->160 @ 8x120x160, data-gradient launch" % ("bf16" if dtype == torch.bfloat16 else "f32"),
+            "traffic": traffic, "traffic_measured": stamp, "kernel": "igemm_dma_kernel<256,160,8,1,3,GM=1,...,HALO> (%s) conv3x3 160->160 @ 8x120x160, data-gradient launch (halo-patch variant)" % ("bf16" if dtype == torch.bfloat16 else "f32"),
             "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(flops / 1e9, 2)}
 
 

@@ -2105,7 +2105,10 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
                     else { DMA_LAUNCH(64, 64, 2, 2, 4, dim3(((M + 63) / 64) * ((N + 63) / 64))) }
                 } else { DMA_LAUNCH(128, 128, 2, 2, 3, dim3(t128)) }
             } else if (N > 32) {
-                DMA_LAUNCH(128, 64, 2, 2, 4, dim3(gm))
+                // fewer 128-row tiles than two per CU: 64-row tiles (three workgroups per CU fit) run the map in one round instead of
+                // a round and a tail (conv3x3 64 -> 64 @ 8x60x80: 300 workgroups of 128 x 64 = 1.17 rounds)
+                if (bk64 && gm < 512 && d->KH * d->KW > 1) { DMA_LAUNCH_64(64, 64, 2, 2, 3, dim3((M + 63) / 64)) }      // same box: 18 -> 12 us, step -0.1 ms; 1x1: no gain
+                else DMA_LAUNCH(128, 64, 2, 2, 4, dim3(gm))
             } else {
                 DMA_LAUNCH(128, 32, 4, 1, 4, dim3(gm))
             }

@@ -60,14 +60,16 @@ def act_ref(v, act, act_scale):
 
 # name, (B, Hi, Wi), Cin, Cout, K, stride, pad, upsample_to, extras, tiles the dispatcher picks (documentation)
 CASES = [
+    ("pooled_64_64_3x3_60x80", (8, 60, 80), 64, 64, 3, 1, 1, None, {},
+     "N = 64 on a 1/8 map: 300 tiles of 128 rows would be a round and a tail - igemm_dma<64,64,..,BK 64> (600 workgroups, one round); halo variant not eligible"),
     ("pyramid2_layer_160_160_3x3", (8, 120, 160), 160, 160, 3, 1, 1, None, {},
-     "fwd igemm_dma_persist<256,160,8,1,3,0> (512 whole tiles + 44 rows per workgroup), dgrad <..,1>, wgrad_dma<160,128,1,4,3,1>: THE roofline kernel of bench.py"),
+     "fwd igemm_dma<256,160,8,1,3,0,...,HALO> (8 x 32 pixel patches, halo staged once per channel block), dgrad <..,1,...,HALO>, wgrad_taps_kernel: THE roofline kernel of bench.py"),
     ("persist_ragged_tail_605_tiles", (8, 121, 160), 160, 160, 3, 1, 1, None, {},
-     "igemm_dma_persist_kernel: 605 tiles = one round of 512 + 93 tiles dealt out 47 rows per workgroup, the last groups ragged / empty"),
+     "H = 121 is not a whole number of 8-row patches: the plain igemm_dma<256,160> (one tile per workgroup, ragged last tile), not the halo variant"),
     ("persist_short_tail_525_tiles", (7, 120, 160), 160, 160, 3, 1, 1, None, {},
-     "igemm_dma_persist_kernel: 13 tail tiles = 7 rows per workgroup (one active wave row, most lanes past the row limit)"),
+     "B = 7: halo variant on 525 patches (one round of 512 + 13)"),
     ("pyramid2_lastconv_800_320_3x3", (8, 120, 160), 800, 320, 3, 1, 1, None, {},
-     "fwd persist <256,160> two column tiles (2 rounds + 88 rows per group of two), K = 7200; dgrad 320->800 <256,160,..,1> (3000 tiles: plain launch); wgrad<160,128> 2 x 57 tiles"),
+     "fwd halo variant, two column tiles, 25 channel blocks x 9 taps; dgrad 320->800 halo variant (3000 tiles); wgrad_taps_kernel 50 tiles x 5 splits"),
     ("pyramid2_firstconv_80_160_3x3", (8, 120, 160), 80, 160, 3, 1, 1, None, {},
      "Cin = 80: igemm_dma<256,160,8,1,3,0> with the channel tail (was the register-staged kernel); dgrad 160->80 <256,128,4,2,3,1>; wgrad_dma<160,128>"),
     ("pyramid2_firstconv_80_80_3x3", (8, 120, 160), 80, 80, 3, 1, 1, None, {},

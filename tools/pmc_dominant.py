@@ -21,7 +21,7 @@ write, _ = mean(sys.argv[2], "WRITE_SIZE")
 hit, _ = mean(sys.argv[3], "TCC_HIT_sum")
 miss, _ = mean(sys.argv[3], "TCC_MISS_sum")
 out = {
-    "kernel": "igemm_dma_kernel<256,160,8,1,3,GM=1> (bf16) conv3x3 160->160 @ 8x120x160, data-gradient launch (tools/roofline_kernel.py, %d launches averaged)" % n,
+    "kernel": "igemm_dma_kernel<256,160,8,1,3,GM=1,...,HALO> (bf16) conv3x3 160->160 @ 8x120x160, data-gradient launch, halo-patch variant (tools/roofline_kernel.py, %d launches averaged)" % n,
     "measured": datetime.datetime.now().strftime("%Y-%m-%d %H:%M round 3"),
     "commit": (sys.argv[5] if len(sys.argv) > 5 else "?"),
     "how": "rocprofv3 --pmc <counters> --kernel-trace --output-format csv, one pass per counter group (FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum); "
