@@ -435,10 +435,16 @@ struct HaloCfg {
     static constexpr int RING = A_BUFS * A_BYTES + B_STAGES * B_BYTES;
 };
 
-template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT, bool TAIL, bool GATE, int ACTK, bool LN = false, int KPB = 1, int BK = 32, bool HALO = false>
+// PAR (round 3): data gradient of a 3x3 / stride 2 / pad 1 convolution, the transposed gather without its structural zeros.  Output pixel
+// (oh, ow) only meets the taps with kh = oh + 1 and kw = ow + 1 (mod 2): 1, 2, 2 or 4 of the nine, by the parity class of the pixel - walked
+// in image order three of every four staged A rows were the zero page (435 'TFLOP/s' of which 109 were arithmetic).  Here the rows are
+// dealt out by class (tile -> class (py, px), then pixels (b, y', x') with oh = 2 y' + py, ow = 2 x' + px), the reduction of a tile
+// visits only its class's taps (2.25 instead of 9 on average), and the epilogue stores each row at its own pixel.
+template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT, bool TAIL, bool GATE, int ACTK, bool LN = false, int KPB = 1, int BK = 32, bool HALO = false, bool PAR = false>
 __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, const int m0, const int n0) {
     typedef __bf16 T;
     static_assert(!HALO || (BM == 256 && BN == 160 && WM == 8 && WN == 1 && BK == 32 && KPB == 1 && !TAIL && GM <= 1), "halo tiles: 8 x 32 pixel patches, 160 columns");
+    static_assert(!PAR || (GM == 2 && !HALO && !LN && !TAIL && !MULT && KPB == 1), "parity classes: general transposed gather only");
     constexpr int NW = WM * WN;                          // 4 or 8 waves
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int RPI = 1024 / (BK * 2), CPR = BK / 8;   // rows per 1 KiB DMA wave-instruction (16 | 8), 16-byte chunks per row (4 | 8)
@@ -463,18 +469,32 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
     int p_h[A_IT], p_w[A_IT], a_ck[A_IT];
     size_t a_pix[A_IT];
     bool a_ok[A_IT];
-    const int gmode = GM == 0 ? (int)GWD_GATHER_CONV : (GM == 1 ? (int)GWD_GATHER_TRANSPOSED : d.gather);
+    const int gmode = GM == 0 ? (int)GWD_GATHER_CONV : (GM == 1 ? (int)GWD_GATHER_TRANSPOSED : (PAR ? (int)GWD_GATHER_TRANSPOSED : d.gather));
     const int gstride = GM == 1 ? 1 : d.stride;
+    // PAR: the launch covers 4 classes x ceil(Mq / BM) row tiles, Mq = B * (Ho / 2) * (Wo / 2) pixels per class
+    const int par_hh = d.Ho >> 1, par_wh = d.Wo >> 1, par_mq = d.B * par_hh * par_wh;
+    // classes interleaved over the row tiles (tile t -> class 3 - t % 4, rows t / 4): the XCD bands of the launch order get the same mix of
+    // four-tap and one-tap tiles (class-major order gave two XCDs all the four-tap tiles)
+    const int par_cls = PAR ? 3 - ((m0 / BM) & 3) : 0;
+    const int par_r0 = PAR ? ((m0 / BM) >> 2) * BM : 0, par_py = par_cls >> 1, par_px = par_cls & 1;
+    auto par_pixel = [&](int r, int &b, int &oh, int &ow) {          // row r of the class -> output pixel
+        b = r / (par_hh * par_wh);
+        const int rem = r - b * (par_hh * par_wh);
+        const int yq = rem / par_wh;
+        oh = 2 * yq + par_py;
+        ow = 2 * (rem - yq * par_wh) + par_px;
+    };
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int row = RPI * (wave * A_IT + i) + lane / CPR;
         a_ck[i] = ((lane % CPR) ^ swz(row)) * 8;
         const int m = m0 + row;
-        a_ok[i] = m < M;
+        a_ok[i] = PAR ? (par_r0 + row < par_mq) : (m < M);
         const int mm = a_ok[i] ? m : 0;
-        const int b = mm / (d.Ho * d.Wo);
+        int b = mm / (d.Ho * d.Wo);
         const int rem = mm - b * (d.Ho * d.Wo);
-        const int oh = rem / d.Wo, ow = rem - oh * d.Wo;
+        int oh = rem / d.Wo, ow = rem - oh * d.Wo;
+        if constexpr (PAR) par_pixel(a_ok[i] ? par_r0 + row : 0, b, oh, ow);
         a_pix[i] = (size_t)b * d.Hi * d.Wi;
         if (gmode == GWD_GATHER_CONV) {
             p_h[i] = oh * d.stride - d.pad;
@@ -510,11 +530,13 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int KT = TAIL ? d.KH * d.KW * ((d.Cin + BK - 1) / BK) : K / BK;
+    // PAR: taps kh0, kh0 + 2 (< KH) and kw0, kw0 + 2 only
+    const int t_step = PAR ? 2 : 1, kh0 = PAR ? (par_py ^ 1) : 0, kw0 = PAR ? (par_px ^ 1) : 0;
+    const int KT = TAIL ? d.KH * d.KW * ((d.Cin + BK - 1) / BK) : (PAR ? (par_py + 1) * (par_px + 1) * (d.Cin / BK) : K / BK);
     // reduction order: 64-channel group (one 128-byte line per pixel) outermost, then the filter taps, then the two
     // 32-channel halves of the group - a pixel's line is re-read for the next tap / half one or two tiles later, while
     // it is still in L2 (tap-outermost order has a reuse distance of Cin/32 tiles x every resident workgroup).
-    int u_kh = 0, u_kw = 0, u_cb = 0, u_sub = 0, u_c0 = 0;  // workgroup-uniform state of the next tile to issue
+    int u_kh = kh0, u_kw = kw0, u_cb = 0, u_sub = 0, u_c0 = 0;  // workgroup-uniform state of the next tile to issue
     int u_grp = (BK == 64) ? 1 : (d.Cin > 32 ? 2 : 1);   // K tiles in the current 64-channel group (BK 32: two halves, the last may be a partial tile: TAIL)
     auto issue = [&](int stage) {
         char *sb = smem + stage * STAGE_BYTES;
@@ -563,10 +585,10 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
         }
         if (++u_sub == u_grp) {
             u_sub = 0;
-            if (++u_kw == d.KW) {
-                u_kw = 0;
-                if (++u_kh == d.KH) {
-                    u_kh = 0;
+            if ((u_kw += t_step) >= d.KW) {
+                u_kw = kw0;
+                if ((u_kh += t_step) >= d.KH) {
+                    u_kh = kh0;
                     u_cb += 64;
                     u_grp = (BK == 64) ? 1 : (d.Cin - u_cb > 32 ? 2 : 1);
                 }
@@ -923,8 +945,14 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const int row = vr + 16 * half;
-                    const int m = wbase + i * 32 + row;
-                    if (m >= M) continue;
+                    int m = wbase + i * 32 + row;
+                    if constexpr (PAR) {
+                        const int r = par_r0 + wm * (BM / WM) + i * 32 + row;
+                        if (r >= par_mq) continue;
+                        int pb, poh, pow_;
+                        par_pixel(r, pb, poh, pow_);
+                        m = (pb * d.Ho + poh) * d.Wo + pow_;
+                    } else if (m >= M) continue;
                     const f32x4 lo = *(const f32x4 *)(stage + row * 36 + vc);
                     const f32x4 hi = *(const f32x4 *)(stage + row * 36 + vc + 4);
                     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -972,7 +1000,7 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
     }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false, bool TAIL = false, bool GATE = false, int ACTK = -1, bool LN = false, int KPB = 1, int BK = 32, bool HALO = false>
+template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false, bool TAIL = false, bool GATE = false, int ACTK = -1, bool LN = false, int KPB = 1, int BK = 32, bool HALO = false, bool PAR = false>
 __global__ __launch_bounds__(WM *WN * 64) __attribute__((amdgpu_waves_per_eu(HALO ? 4 : 1, HALO ? 4 : 8))) void igemm_dma_kernel(const gwd_conv_desc d, const int tile_base, const int tile_count) {
     constexpr int SM_ = DmaTileCfg<BM, BN, WM, WN, STAGES, BK>::SMEM;
     __shared__ __attribute__((aligned(1024))) char smem[HALO ? (HaloCfg::RING > DmaTileCfg<BM, BN, WM, WN, STAGES, BK>::EPI_BYTES ? HaloCfg::RING : DmaTileCfg<BM, BN, WM, WN, STAGES, BK>::EPI_BYTES) : SM_];
@@ -981,7 +1009,7 @@ __global__ __launch_bounds__(WM *WN * 64) __attribute__((amdgpu_waves_per_eu(HAL
     // whole rounds of 256-row tiles and a tail of 128-row tiles was measured in round 2: 0.125 -> 0.134 ms on the 160 -> 160
     // layer, the second launch and the lone waves of the tail cost more than the half-empty round they replace.)
     const int tile = tile_base + xcd_band(blockIdx.x, tile_count);             // column tiles of a row tile are adjacent
-    dma_tile<BM, BN, WM, WN, STAGES, GM, MULT, TAIL, GATE, ACTK, LN, KPB, BK, HALO>(d, smem, (tile / n_tiles) * BM, (tile % n_tiles) * BN);
+    dma_tile<BM, BN, WM, WN, STAGES, GM, MULT, TAIL, GATE, ACTK, LN, KPB, BK, HALO, PAR>(d, smem, (tile / n_tiles) * BM, (tile % n_tiles) * BN);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1947,6 +1975,15 @@ static bool halo_ok(const gwd_conv_desc *d) {
            (d->Cin % 32) == 0 && (d->Cout % 160) == 0 && (d->gather == GWD_GATHER_CONV || d->gather == GWD_GATHER_TRANSPOSED);
 }
 
+// data gradient of a 3x3 / stride 2 / pad 1 convolution onto a map of exactly twice the size: the parity-class variant
+static bool par_ok(const gwd_conv_desc *d) {
+#ifdef GWD_NO_PAR
+    return false;
+#endif
+    return d->gather == GWD_GATHER_TRANSPOSED && d->stride == 2 && d->KH == 3 && d->KW == 3 && d->pad == 1 && d->Ho == 2 * d->Hi && d->Wo == 2 * d->Wi &&
+           (d->Cin % 32) == 0;
+}
+
 static int launch_convln(const gwd_conv_desc *d, hipStream_t s) {
     const int M = d->B * d->Ho * d->Wo, N = d->Cout;
     if (d->dtype != GWD_BF16 || !dma_enabled() || !d->zero_page || !d->ln_rstd || !d->scale || !d->shift || d->mult || d->gate) return -4;
@@ -2083,7 +2120,20 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
             const bool kpb2 = ((d->KH * d->KW * (d->Cin / 32)) % 2) == 0;
             const bool big = big_tiles_enabled() && M >= 256 * 512;      // >= 2 workgroups per CU with 256-row tiles
             const unsigned gm2 = (M + 255) / 256;
-            if (N % 160 == 0) {
+            if (gmk == 2 && par_ok(d) && N > 64 && lean) {
+                // stride-2 3x3 data gradient by parity class (dma_tile<..., PAR>): 4 x ceil(M / 4 / BM) row tiles
+                const int mq = M / 4;
+                const unsigned t128 = 4u * ((mq + 127) / 128) * ((N + 127) / 128);
+                if (t128 >= 512 || !bk64) {
+                    const dim3 g(t128);
+                    if (d->gate) igemm_dma_kernel<128, 128, 2, 2, 3, 2, false, false, true, 0, false, 1, 32, false, true><<<g, 256, 0, s>>>(*d, 0, (int)g.x);
+                    else igemm_dma_kernel<128, 128, 2, 2, 3, 2, false, false, false, 0, false, 1, 32, false, true><<<g, 256, 0, s>>>(*d, 0, (int)g.x);
+                } else {
+                    const dim3 g(4u * ((mq + 63) / 64) * ((N + 63) / 64));
+                    if (d->gate) igemm_dma_kernel<64, 64, 2, 2, 3, 2, false, false, true, 0, false, 1, 64, false, true><<<g, 256, 0, s>>>(*d, 0, (int)g.x);
+                    else igemm_dma_kernel<64, 64, 2, 2, 3, 2, false, false, false, 0, false, 1, 64, false, true><<<g, 256, 0, s>>>(*d, 0, (int)g.x);
+                }
+            } else if (N % 160 == 0) {
                 if (big && gmk <= 1 && halo_ok(d)) {
                     const dim3 g(gm2 * (N / 160));
                     if (actk == 0) {

@@ -60,6 +60,12 @@ def act_ref(v, act, act_scale):
 
 # name, (B, Hi, Wi), Cin, Cout, K, stride, pad, upsample_to, extras, tiles the dispatcher picks (documentation)
 CASES = [
+    ("layer4_conv2_512_512_3x3_s2", (8, 30, 40), 512, 512, 3, 2, 1, None, dict(shift=True, act=hip.ACT_RELU),
+     "ResNet layer4 block 0: data gradient by parity class on 64 x 64 tiles (2 400 pixels per class: ragged last tile)"),
+    ("layer3_conv2_256_256_3x3_s2", (8, 60, 80), 256, 256, 3, 2, 1, None, dict(shift=True, act=hip.ACT_RELU),
+     "ResNet layer3 block 0: data gradient by parity class on 128 x 128 tiles"),
+    ("odd_map_3x3_s2", (2, 31, 41), 128, 128, 3, 2, 1, None, {},
+     "odd map: not a whole number of parity classes - the general transposed gather stays"),
     ("pooled_64_64_3x3_60x80", (8, 60, 80), 64, 64, 3, 1, 1, None, {},
      "N = 64 on a 1/8 map: 300 tiles of 128 rows would be a round and a tail - igemm_dma<64,64,..,BK 64> (600 workgroups, one round); halo variant not eligible"),
     ("pyramid2_layer_160_160_3x3", (8, 120, 160), 160, 160, 3, 1, 1, None, {},
@@ -153,6 +159,16 @@ def test_dispatch_size_conv_against_fp32_torch(dev, case):
     dev.conv_forward(gy.cuda(), wt, gx, (B, Ho, Wo, Cout, Hd, Wd, Cin, K, K), stride=s, pad=p, gather=hip.GATHER_TRANSPOSED)
     torch.cuda.synchronize()
     close(gx, gx_ref, TOL_BF16, name + " data gradient")
+    if s == 2 and K == 3 and virt is None:
+        # the same launch with the producer's ReLU backward as the epilogue gate (what a Bottleneck's data gradient carries): on even maps
+        # this is the parity-class kernel (dma_tile<..., PAR>), each row stored at its own pixel
+        prod = rnd(B, Hd, Wd, Cin, seed=17)
+        gxg = torch.full((B, Hd, Wd, Cin), float("nan"), dtype=torch.bfloat16, device="cuda")
+        dev.conv_forward(gy.cuda(), wt, gxg, (B, Ho, Wo, Cout, Hd, Wd, Cin, K, K), stride=s, pad=p, gather=hip.GATHER_TRANSPOSED,
+                         gate=prod.cuda(), gate_act=hip.ACT_RELU)
+        torch.cuda.synchronize()
+        close(gxg, gx_ref * (prod.float() > 0), TOL_BF16, name + " gated data gradient")
+        del gxg
     del gx, gx_ref
 
     # ---- weight gradient (fp32 atomics into a zeroed buffer, real split count for this M; the FrozenBN scale multiplies it)
