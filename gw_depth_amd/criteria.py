@@ -163,6 +163,9 @@ class SetCriterion(nn.Module):
             for i in range(L_ - 1):
                 losses[f"loss_ce_{i}"] = ce[i + 1]
                 losses[f"loss_line_{i}"] = l1[i + 1]
+            # the per-layer vectors themselves, for a caller that weights them as vectors (engine.TrainStep.losses): summed through the
+            # twelve select views above, the backward pass is twelve zero-fills, copies and accumulations of 6-element tensors
+            self.last_stacks = (ce, l1, ["loss_ce"] + [f"loss_ce_{i}" for i in range(L_ - 1)], ["loss_line"] + [f"loss_line_{i}" for i in range(L_ - 1)])
             return losses
         with torch.no_grad():                                                          # matcher.py:52-70
             prob = logits.softmax(-1)

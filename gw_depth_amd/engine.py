@@ -51,6 +51,9 @@ def _align(n):
     return (n + ALIGN - 1) // ALIGN * ALIGN
 
 
+VECTOR_SET_TERMS = True      # the set criterion's twelve per-layer terms enter the total as two weighted vector sums
+
+
 class TrainStep:
     def __init__(self, model, criterions, cfg, compute_dtype=torch.float32, bucket_mb=32.0, process_group=None,
                  check_finite=True, data_parallel=True, graph=False, segments=None):
@@ -254,10 +257,25 @@ class TrainStep:
     # ------------------------------------------------------------------ losses (engine_glassrgbd.py:62-115)
     def losses(self, out, depth_gt, seg_gt, targets, packed=None):
         cfg = self.cfg
+        self.criterion.last_stacks = None
         terms = self.criterion.forward_packed(out, packed, self.norm_world) if packed is not None else self.criterion(out, targets)
         wd = self.criterion.weight_dict
         keys = [k for k in terms if k in wd]
-        parts, coef = [terms[k] for k in keys], [float(wd[k]) for k in keys]
+        stacks = getattr(self.criterion, "last_stacks", None)
+        if VECTOR_SET_TERMS and stacks is not None and all(k in wd for k in stacks[2] + stacks[3]):
+            # the set criterion's per-layer terms as two weighted vector sums (same weights, same terms; the dict entries stay for logging)
+            ce, l1, kce, kl1 = stacks
+            skip = set(kce) | set(kl1)
+            keys = [k for k in keys if k not in skip]
+            wk = (tuple(float(wd[k]) for k in kce), tuple(float(wd[k]) for k in kl1), ce.device)
+            if getattr(self, "_stack_key", None) != wk:
+                self._stack_key = wk
+                self._stack_w = (torch.tensor(wk[0], dtype=torch.float32, device=ce.device), torch.tensor(wk[1], dtype=torch.float32, device=ce.device))
+            parts, coef = [(ce.float() * self._stack_w[0]).sum(), (l1.float() * self._stack_w[1]).sum()], [1.0, 1.0]
+        else:
+            parts, coef = [], []
+        parts += [terms[k] for k in keys]
+        coef += [float(wd[k]) for k in keys]
         names = ["1/16", "1/8", "1/4", "1"]
         for i, pd in enumerate(out["pred_depth"]):
             ld = self.criterion_depth.fused(pd, depth_gt, cfg.depth_loss_weights[i])
