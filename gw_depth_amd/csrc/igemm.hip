@@ -387,7 +387,7 @@ __device__ __forceinline__ int xcd_band(int id, int total) {
 
 // TAIL: Cin is a multiple of 8 but not of 32 (the 80-channel pyramid layers): the last 32-channel K tile of every tap is part data,
 // part zero page - compile-time variant, like MULT, so that the common kernels pay nothing for the per-lane channel bound.
-// GATE: desc.gate in the epilogue, compile-time as well - as a run-time branch it cost EVERY launch ~3 % (0.122 -> 0.126 ms on the
+// GATE (0 none | 1 ReLU / ELU from the producer's output | 2 GELU from its pre-activation value): desc.gate in the epilogue, compile-time as well - as a run-time branch it cost EVERY launch ~3 % (0.122 -> 0.126 ms on the
 // 160 -> 160 layer, 0.2 ms per step), and only the data gradients of the ResNet blocks carry one (never the 160-wide tiles).
 // LEAN: no activation, no pre-activation copy (every data gradient, every conv in front of a LayerNorm, every plain Linear) - the
 // activation switch (erf / expm1 / exp paths, inlined 8 x TM x TN x 2 times) is most of the epilogue's code: without it the 160 -> 160
@@ -440,7 +440,7 @@ struct HaloCfg {
 // in image order three of every four staged A rows were the zero page (435 'TFLOP/s' of which 109 were arithmetic).  Here the rows are
 // dealt out by class (tile -> class (py, px), then pixels (b, y', x') with oh = 2 y' + py, ow = 2 x' + px), the reduction of a tile
 // visits only its class's taps (2.25 instead of 9 on average), and the epilogue stores each row at its own pixel.
-template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT, bool TAIL, bool GATE, int ACTK, bool LN = false, int KPB = 1, int BK = 32, bool HALO = false, bool PAR = false>
+template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT, bool TAIL, int GATE, int ACTK, bool LN = false, int KPB = 1, int BK = 32, bool HALO = false, bool PAR = false>
 __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, const int m0, const int n0) {
     typedef __bf16 T;
     static_assert(!HALO || (BM == 256 && BN == 160 && WM == 8 && WN == 1 && BK == 32 && KPB == 1 && !TAIL && GM <= 1), "halo tiles: 8 x 32 pixel patches, 160 columns");
@@ -987,7 +987,9 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
                         if (gate) {
                             const bf16x8 gv = *(const bf16x8 *)(gate + o);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) gm[e] = gate_grad(d.act_scale, (float)gv[e], d.gate_act);
+                            for (int e = 0; e < 8; ++e)
+                                gm[e] = GATE == 2 ? d.act_scale * gelu_grad_fast((float)gv[e])       // the producer's GELU, from its PRE-activation value
+                                                  : gate_grad(d.act_scale, (float)gv[e], d.gate_act);
                         }
 #pragma unroll
                         for (int e = 0; e < 8; ++e)
@@ -1000,7 +1002,7 @@ __device__ __forceinline__ void dma_tile(const gwd_conv_desc &d, char *smem, con
     }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false, bool TAIL = false, bool GATE = false, int ACTK = -1, bool LN = false, int KPB = 1, int BK = 32, bool HALO = false, bool PAR = false>
+template <int BM, int BN, int WM, int WN, int STAGES, int GM, bool MULT = false, bool TAIL = false, int GATE = 0, int ACTK = -1, bool LN = false, int KPB = 1, int BK = 32, bool HALO = false, bool PAR = false>
 __global__ __launch_bounds__(WM *WN * 64) __attribute__((amdgpu_waves_per_eu(HALO ? 4 : 1, HALO ? 4 : 8))) void igemm_dma_kernel(const gwd_conv_desc d, const int tile_base, const int tile_count) {
     constexpr int SM_ = DmaTileCfg<BM, BN, WM, WN, STAGES, BK>::SMEM;
     __shared__ __attribute__((aligned(1024))) char smem[HALO ? (HaloCfg::RING > DmaTileCfg<BM, BN, WM, WN, STAGES, BK>::EPI_BYTES ? HaloCfg::RING : DmaTileCfg<BM, BN, WM, WN, STAGES, BK>::EPI_BYTES) : SM_];
@@ -1737,7 +1739,7 @@ int check_desc(const gwd_conv_desc *d) {
     if (d->gather == GWD_GATHER_UPSAMPLED && (d->stride != 1 || d->Hv <= 0 || d->Wv <= 0)) return -6;
     if ((int64_t)d->B * d->Ho * d->Wo >= (1LL << 31) || (int64_t)d->KH * d->KW * d->Cin >= (1LL << 31)) return -7;
     if ((int64_t)d->B * d->Hi * d->Wi * d->Cin >= (1LL << 40)) return -7;
-    if (d->gate && ((d->gate_act != GWD_ACT_RELU && d->gate_act != GWD_ACT_ELU) || d->mult)) return -4;
+    if (d->gate && ((d->gate_act != GWD_ACT_RELU && d->gate_act != GWD_ACT_ELU && d->gate_act != GWD_ACT_GELU) || d->mult)) return -4;
     return 0;
 }
 
@@ -1934,6 +1936,7 @@ static int launch_ksplit(const gwd_conv_desc *d, hipStream_t s) {
     if (ksplit_min_k() <= 0 || K < ksplit_min_k() || d->dtype != GWD_BF16 || !d->zero_page) return 0;
     if (d->gather == GWD_GATHER_UPSAMPLED || (d->gather == GWD_GATHER_TRANSPOSED && d->stride != 1)) return 0;
     if ((d->Cin % 32) || (N % 8)) return 0;
+    if (d->gate && d->gate_act == GWD_ACT_GELU) return 0;         // the GELU gate lives in the LDS-DMA tile kernels only
     const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
     if (tiles > 256) return 0;                            // one workgroup (128 KiB of LDS) per CU: beyond one round the ordinary tiles win (304 tiles, K = 4 608: 54 -> 58 us; 600 tiles: 17 -> 21 us)
     constexpr int ST = 4, LDS = 4 * ST * (64 + 64) * 64;  // 128 KiB: one workgroup per CU
@@ -2095,11 +2098,12 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
         default: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 2, false, false, G_, L_, false, KPB_><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;  \
     }
 #define DMA_LAUNCH_K(BM_, BN_, WM_, WN_, ST_, GRID, KPB_)                                                      \
-    if (BN_ % 160 != 0 && d->gate) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, (BN_ % 160 != 0), 0, KPB_) }   \
-    else if (actk == 0) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, 0, KPB_) }                         \
-    else if (actk == 1 && BN_ % 160 != 0) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, (BN_ % 160 != 0 ? 1 : -1), KPB_) } \
-    else if (actk == 2 && BN_ % 160 != 0) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, (BN_ % 160 != 0 ? 2 : -1), KPB_) } \
-    else { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, false, -1, KPB_) }
+    if (BN_ % 160 != 0 && d->gate && d->gate_act == GWD_ACT_GELU) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, (BN_ % 160 != 0 ? 2 : 0), 0, KPB_) }   \
+    else if (BN_ % 160 != 0 && d->gate) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, (BN_ % 160 != 0 ? 1 : 0), 0, KPB_) }   \
+    else if (actk == 0) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, 0, 0, KPB_) }                         \
+    else if (actk == 1 && BN_ % 160 != 0) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, 0, (BN_ % 160 != 0 ? 1 : -1), KPB_) } \
+    else if (actk == 2 && BN_ % 160 != 0) { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, 0, (BN_ % 160 != 0 ? 2 : -1), KPB_) } \
+    else { DMA_LAUNCH_G(BM_, BN_, WM_, WN_, ST_, GRID, 0, -1, KPB_) }
 #define DMA_LAUNCH(BM_, BN_, WM_, WN_, ST_, GRID) DMA_LAUNCH_K(BM_, BN_, WM_, WN_, ST_, GRID, 1)
 #define DMA_LAUNCH_G64(BM_, BN_, WM_, WN_, ST_, GRID, G_, L_)                                                   \
     switch (gmk) {                                                                                              \
@@ -2108,11 +2112,12 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
         default: igemm_dma_kernel<BM_, BN_, WM_, WN_, ST_, 2, false, false, G_, L_, false, 1, 64><<<GRID, WM_ * WN_ * 64, 0, s>>>(*d, 0, (int)(GRID).x); break;  \
     }
 #define DMA_LAUNCH_64(BM_, BN_, WM_, WN_, ST_, GRID)                                                           \
-    if (d->gate) { DMA_LAUNCH_G64(BM_, BN_, WM_, WN_, ST_, GRID, true, 0) }                                     \
-    else if (actk == 0) { DMA_LAUNCH_G64(BM_, BN_, WM_, WN_, ST_, GRID, false, 0) }                             \
-    else if (actk == 1) { DMA_LAUNCH_G64(BM_, BN_, WM_, WN_, ST_, GRID, false, 1) }                             \
-    else if (actk == 2) { DMA_LAUNCH_G64(BM_, BN_, WM_, WN_, ST_, GRID, false, 2) }                             \
-    else { DMA_LAUNCH_G64(BM_, BN_, WM_, WN_, ST_, GRID, false, -1) }
+    if (d->gate && d->gate_act == GWD_ACT_GELU) { DMA_LAUNCH_G64(BM_, BN_, WM_, WN_, ST_, GRID, 2, 0) }          \
+    else if (d->gate) { DMA_LAUNCH_G64(BM_, BN_, WM_, WN_, ST_, GRID, 1, 0) }                                   \
+    else if (actk == 0) { DMA_LAUNCH_G64(BM_, BN_, WM_, WN_, ST_, GRID, 0, 0) }                             \
+    else if (actk == 1) { DMA_LAUNCH_G64(BM_, BN_, WM_, WN_, ST_, GRID, 0, 1) }                             \
+    else if (actk == 2) { DMA_LAUNCH_G64(BM_, BN_, WM_, WN_, ST_, GRID, 0, 2) }                             \
+    else { DMA_LAUNCH_G64(BM_, BN_, WM_, WN_, ST_, GRID, 0, -1) }
             // 64-channel K tiles (whole 128-byte lines per staged row piece) where every tap is a whole number of them; for the 64 x 64
             // tiles only (128 x 64 and 128 x 128 with two stages: no gain, measured)
             const bool bk64 = (d->Cin % 64) == 0;
@@ -2120,7 +2125,7 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
             const bool kpb2 = ((d->KH * d->KW * (d->Cin / 32)) % 2) == 0;
             const bool big = big_tiles_enabled() && M >= 256 * 512;      // >= 2 workgroups per CU with 256-row tiles
             const unsigned gm2 = (M + 255) / 256;
-            if (gmk == 2 && par_ok(d) && N > 64 && lean) {
+            if (gmk == 2 && par_ok(d) && N > 64 && lean && !(d->gate && d->gate_act == GWD_ACT_GELU)) {
                 // stride-2 3x3 data gradient by parity class (dma_tile<..., PAR>): 4 x ceil(M / 4 / BM) row tiles
                 const int mq = M / 4;
                 const unsigned t128 = 4u * ((mq + 127) / 128) * ((N + 127) / 128);
@@ -2171,6 +2176,7 @@ int launch_fwd(const gwd_conv_desc *d, hipStream_t s) {
             return 0;
         }
     }
+    if (d->gate && d->gate_act == GWD_ACT_GELU) return -4;       // GELU gate: LDS-DMA tile kernels only; the caller applies it in a pass of its own
     // fewer than two tiles per CU (the 60/120-channel pyramid at 1/8 resolution: 300 tiles of 128 rows = one full round plus
     // a tail round of 44): quarter tiles give four times as many workgroups
     const bool quarter = N > 32 && gm * ((N + 127) / 128) < 512;

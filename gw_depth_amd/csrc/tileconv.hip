@@ -380,7 +380,7 @@ int gwd_tile_conv_forward(const gwd_conv_desc *d, hipStream_t s) {
     if (!enabled() || d->dtype != GWD_BF16 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1) return 0;
     if (d->scale || d->z || d->mult || !d->w) return 0;
     if (d->residual && ((uintptr_t)d->residual % 8)) return 0;
-    if (d->gate && ((uintptr_t)d->gate % 8)) return 0;
+    if (d->gate && (((uintptr_t)d->gate % 8) || d->gate_act == GWD_ACT_GELU)) return 0;
     if ((long)d->B * d->Ho * d->Wo < 131072 || (long)d->B * d->Ho * d->Wo >= (1L << 31)) return 0;
     if (((uintptr_t)d->x | (uintptr_t)d->w | (uintptr_t)d->y) % 16) return 0;
     const bool up = d->gather == GWD_GATHER_UPSAMPLED, flip = d->gather == GWD_GATHER_TRANSPOSED;

@@ -281,6 +281,8 @@ class HipLibrary:
         rc = self.lib.gwd_conv_forward(ctypes.byref(d), self._stream(x, w, y))
         if rc == -4 and kw.get("ln") is not None:
             return False                                # no fused ConvLn kernel for this shape: the caller runs the two kernels
+        if rc == -4 and kw.get("gate") is not None and kw.get("gate_act") == ACT_GELU:
+            return False                                # no kernel with the GELU gate for this shape: the caller applies it in a pass of its own
         self._check(rc, "gwd_conv_forward")
 
     def conv_wgrad(self, x, gy, dw, dims, **kw):

@@ -42,8 +42,8 @@ class Linear(nn.Module):
         nn.init.trunc_normal_(self.weight, std=0.02)
         self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
 
-    def forward(self, x, act=ops.ACT_NONE, residual=None, mult=None, fan=False):
-        return ops.linear(x, self.weight, self.bias, act, residual=residual, mult=mult, fanout=fan)
+    def forward(self, x, act=ops.ACT_NONE, residual=None, mult=None, fan=False, defer=False, in_gate=ops.ACT_NONE, gate_src=None):
+        return ops.linear(x, self.weight, self.bias, act, residual=residual, mult=mult, fanout=fan, defer=defer, in_gate=in_gate, gate_src=gate_src)
 
 
 class LayerNorm(nn.Module):
@@ -88,6 +88,9 @@ class FrozenBN(nn.Module):
         return self._cache[1], self._cache[2]
 
 
+GELU_GATE = True     # MLPs: GELU backward in fc2's data-gradient epilogue
+
+
 class Mlp(nn.Module):
     """fc1 -> GELU -> fc2 (/root/reference/src/models/multiscale_transformerr.py:55-73, drop=0)."""
 
@@ -97,7 +100,11 @@ class Mlp(nn.Module):
         self.fc2 = Linear(hidden or cin, cout or cin)
 
     def forward(self, x, residual=None):
-        """fc2(gelu(fc1(x))) [+ residual, added in fc2's GEMM epilogue]."""
+        """fc2(gelu(fc1(x))) [+ residual, added in fc2's GEMM epilogue].  With gradients on, GELU's backward runs in the epilogue of fc2's
+        data-gradient GEMM (from fc1's pre-activation tensor) instead of as a pass over the hidden map."""
+        if GELU_GATE and torch.is_grad_enabled() and x.requires_grad:
+            h, z = self.fc1(x, ops.ACT_GELU, defer=True)
+            return self.fc2(h, residual=residual, in_gate=ops.ACT_GELU, gate_src=z)
         return self.fc2(self.fc1(x, ops.ACT_GELU), residual=residual)
 
 

@@ -423,17 +423,19 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, residual, row_scale, shift_const, stride, pad, act, act_scale, virt, shadow, sinks, mult=None, fanout=False,
-                in_gate=ACT_NONE, defer=False):
+                in_gate=ACT_NONE, defer=False, gate_src=None):
         lib = _lib()
         ctx.fan = bool(fanout)
         # in_gate / defer: the activation backward of a ReLU / ELU layer moves into the data-gradient epilogue of its ONLY consumer
         # (gwd_conv_desc.gate = the consumer's saved input): the producer (defer) passes the incoming gradient on unchanged, the
         # consumer (in_gate = the producer's activation) returns the gradient w.r.t. the producer's PRE-activation value
+        # GELU (the MLPs): its derivative needs the producer's PRE-activation value, so the producer (defer) returns it as a second
+        # output and the consumer gets it as gate_src (in_gate = ACT_GELU); ReLU / ELU gates are rebuilt from the consumer's own input
         ctx.in_gate, ctx.defer = int(in_gate), bool(defer)
-        if defer and (act not in (ACT_RELU, ACT_ELU) or act_scale != 1.0 or mult is not None):
-            raise ValueError("conv2d: defer needs ReLU / ELU with act_scale 1 and no dropout multiplier")
-        if in_gate not in (ACT_NONE, ACT_RELU, ACT_ELU):
-            raise ValueError("conv2d: in_gate is ReLU or ELU")
+        if defer and (act not in (ACT_RELU, ACT_ELU, ACT_GELU) or act_scale != 1.0 or mult is not None or (act == ACT_GELU and fanout)):
+            raise ValueError("conv2d: defer needs ReLU / ELU / GELU with act_scale 1 and no dropout multiplier")
+        if in_gate not in (ACT_NONE, ACT_RELU, ACT_ELU, ACT_GELU) or (in_gate == ACT_GELU) != (gate_src is not None):
+            raise ValueError("conv2d: in_gate is ReLU or ELU, or GELU with the producer's pre-activation tensor as gate_src")
         B, Hi, Wi, Cin = x.shape
         Cout, KH, KW, Cw = w.shape
         if Cw != Cin:
@@ -464,7 +466,12 @@ class _ConvFn(torch.autograd.Function):
             raise ValueError("conv2d: a dropout multiplier is supported behind no activation (+ skip) or behind ReLU (no skip) only")
         # ReLU's backward needs only the sign of the output: y * mult has the sign of relu(v) wherever mult > 0, and where
         # mult == 0 the incoming gradient is multiplied by zero anyway
-        ctx.save_for_backward(x, w, row_scale, z if act == ACT_GELU else (y if act != ACT_NONE else None), mult)
+        ctx.save_for_backward(x, w, row_scale, z if act == ACT_GELU else (y if act != ACT_NONE else None), mult, gate_src)
+        if defer and act == ACT_GELU:
+            if z is None:                               # no gradient wanted anywhere: nobody will read it
+                z = y
+            ctx.mark_non_differentiable(z)
+            return y, z
         if fanout:
             # second output: x again, for a second consumer of the layer's input (a skip connection).  With it this node is x's only
             # consumer, both gradients arrive in ONE backward call and the skip's joins the data gradient in the kernel epilogue -
@@ -476,7 +483,7 @@ class _ConvFn(torch.autograd.Function):
     def backward(ctx, gy, *g_fan):
         lib = _lib()
         g_in = g_fan[0].contiguous() if (ctx.fan and g_fan and g_fan[0] is not None) else None
-        x, w, row_scale, ref, mult = ctx.saved_tensors
+        x, w, row_scale, ref, mult, gate_src = ctx.saved_tensors
         dims, stride, pad, act, act_scale, gather, vv, has_bias, has_res = ctx.cfg
         B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW = dims
         gy = gy.contiguous()
@@ -513,7 +520,7 @@ class _ConvFn(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             wt = _weight_transposed(w, row_scale, x.dtype)
-            gate = dict(gate=x, gate_act=ctx.in_gate) if ctx.in_gate != ACT_NONE else {}
+            gate = dict(gate=(x if gate_src is None else gate_src), gate_act=ctx.in_gate) if ctx.in_gate != ACT_NONE else {}
             if gather == GATHER_UPSAMPLED:
                 gxv = torch.empty((B, vv[0], vv[1], Cin), dtype=x.dtype, device=x.device)
                 lib.conv_forward(dv, wt, gxv, (B, Ho, Wo, Cout, vv[0], vv[1], Cin, KH, KW), stride=1, pad=pad,
@@ -538,8 +545,14 @@ class _ConvFn(torch.autograd.Function):
                     lib.conv_forward(dv, wt, q, (B, Ho, Wo, Cout, Ho, Wo, Cin, 1, 1), stride=1, pad=0, gather=GATHER_TRANSPOSED)
                     done = lib.stride_place(q, g_in, gx, stride)
                 if not done:
-                    lib.conv_forward(dv, wt, gx, (B, Ho, Wo, Cout, Hi, Wi, Cin, KH, KW), stride=stride, pad=pad,
-                                     gather=GATHER_TRANSPOSED, residual=g_in, **gate)
+                    if lib.conv_forward(dv, wt, gx, (B, Ho, Wo, Cout, Hi, Wi, Cin, KH, KW), stride=stride, pad=pad,
+                                        gather=GATHER_TRANSPOSED, residual=g_in, **gate) is False:
+                        # no kernel with the GELU gate for this shape: the data gradient, then the gate as a pass of its own
+                        lib.conv_forward(dv, wt, gx, (B, Ho, Wo, Cout, Hi, Wi, Cin, KH, KW), stride=stride, pad=pad,
+                                         gather=GATHER_TRANSPOSED, residual=g_in)
+                        gated = torch.empty_like(gx)
+                        lib.act_backward(gx, gate["gate"], gated, None, B * Hi * Wi, Cin, ctx.in_gate, 1.0)
+                        gx = gated
         elif g_in is not None:
             gx = g_in
         if ctx.needs_input_grad[1]:
@@ -557,7 +570,7 @@ class _ConvFn(torch.autograd.Function):
                 gb = torch.zeros(Cout, dtype=torch.float32, device=gy.device)
                 lib.colsum(dv, gb, rows, Cout)
         gres = (g_skip if mult is not None else dv) if (has_res and ctx.needs_input_grad[3]) else None
-        return gx, gw, gb, gres, None, None, None, None, None, None, None, None, None, None, None, None, None
+        return gx, gw, gb, gres, None, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def _nearest_upsample_backward(gv, Hi, Wi, gate=None, gate_act=ACT_NONE):
@@ -602,7 +615,7 @@ def act_gate_enabled():
     return True
 
 
-def linear(x, w, bias=None, act=ACT_NONE, rows=None, residual=None, mult=None, fanout=False):
+def linear(x, w, bias=None, act=ACT_NONE, rows=None, residual=None, mult=None, fanout=False, defer=False, in_gate=ACT_NONE, gate_src=None):
     """x (..., K) @ w(N, K)^T + bias, optional fused activation; same kernel as conv2d (1x1, one pixel per row).
     rows=(r0, r1): use only that row range of a packed parameter (the q/k/v blocks of an attention in-projection);
     the gradient then goes straight into that slice of the parameter's flat gradient instead of through a
@@ -626,9 +639,14 @@ def linear(x, w, bias=None, act=ACT_NONE, rows=None, residual=None, mult=None, f
     res = None if residual is None else residual.reshape(-1, 1, 1, n)
     mul = None if mult is None else mult.reshape(-1, 1, 1, n)
     fan = bool(fanout)
+    # defer (act = GELU): the activation's backward runs in the data-gradient epilogue of the layer's ONLY consumer; returns (y, z), z the
+    # pre-activation tensor that consumer takes as gate_src (with in_gate = ACT_GELU) - the fc1 / fc2 pair of an MLP (layers.Mlp)
+    gs = None if gate_src is None else gate_src.reshape(-1, 1, 1, K)
     y = _ConvFn.apply(x2, w.view(n, 1, 1, K), bias, res, None, None, 1, 0, act, 1.0, None,
                       None if shadow is None else shadow.view(n, 1, 1, K),
-                      sinks if (sinks[0] or sinks[1]) else None, mul, fan)
+                      sinks if (sinks[0] or sinks[1]) else None, mul, fan, int(in_gate), bool(defer), gs)
+    if defer and act == ACT_GELU:
+        return y[0].view(*lead, n), y[1].view(*lead, n)
     if fanout:                              # (y, x again for the input's second consumer): see _ConvFn.forward
         return (y[0].view(*lead, n), y[1].view(x.shape)) if fan else (y.view(*lead, n), x)
     return y.view(*lead, n)

@@ -109,7 +109,10 @@ class FakeDevice:
                 out = out + residual.reshape(v.shape).float()
         if gate is not None:                          # gwd_conv_desc.gate: act'(.) of the activation whose output is `gate`, last
             r = gate.reshape(v.shape).float()
-            out = out * ((r > 0).float() if gate_act == hip.ACT_RELU else torch.where(r > 0, torch.ones_like(r), r + 1))
+            if gate_act == hip.ACT_GELU:              # from the producer's PRE-activation value
+                out = out * (0.5 * (1 + torch.erf(r * 0.7071067811865476)) + r * torch.exp(-0.5 * r * r) * 0.3989422804014327)
+            else:
+                out = out * ((r > 0).float() if gate_act == hip.ACT_RELU else torch.where(r > 0, torch.ones_like(r), r + 1))
         y.copy_(out.reshape(y.shape))
 
     def conv_wgrad(self, x, gy, dw, dims, stride=1, pad=0, gather=hip.GATHER_CONV, virt=(0, 0), scale=None, **_):

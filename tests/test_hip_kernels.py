@@ -1123,9 +1123,46 @@ def test_conv_gate_rejects_what_it_cannot_do(dev):
     x, w, y = (torch.zeros(s, device="cuda", dtype=torch.bfloat16) for s in ((1, 8, 8, 32), (32, 1, 1, 32), (1, 8, 8, 32)))
     dims = (1, 8, 8, 32, 8, 8, 32, 1, 1)
     with pytest.raises(RuntimeError):
-        dev.conv_forward(x, w, y, dims, gate=x, gate_act=hip.ACT_GELU)
+        dev.conv_forward(x, w, y, dims, gate=x, gate_act=hip.ACT_SIGMOID)
     with pytest.raises(RuntimeError):
         dev.conv_forward(x, w, y, dims, gate=x, gate_act=hip.ACT_RELU, mult=x)
+    # a GELU gate (from the producer's pre-activation tensor) exists in the LDS-DMA tile kernels only: elsewhere the call says so (False)
+    xf, wf, yf = x.float(), w.float(), y.float()
+    assert dev.conv_forward(xf, wf, yf, dims, gate=xf, gate_act=hip.ACT_GELU) is False
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,cin,hidden", [(11760, 384, 768), (2400, 64, 128), (777, 64, 128), (3528, 512, 1024)])
+def test_mlp_gelu_backward_in_the_data_gradient_epilogue(dev, rows, cin, hidden, dtype):
+    """layers.Mlp with GELU's backward as the gate of fc2's data-gradient GEMM (gwd_conv_desc.gate = fc1's pre-activation tensor,
+    gate_act GELU; bf16: dma_tile<..., GATE = 2>, fp32: the call refuses and the gate runs as a pass of its own) against the same MLP
+    with the separate activation-backward pass: same output, same gradients for the input, both weights and both biases."""
+    from gw_depth_amd import layers
+    torch.manual_seed(3)
+    mlp = layers.Mlp(cin, hidden).cuda()
+    with torch.no_grad():
+        mlp.fc1.bias.normal_(0, 0.1)
+        mlp.fc2.bias.normal_(0, 0.1)
+        mlp.fc1.weight.mul_(3.0)
+    x0 = torch.randn(rows, cin, device="cuda").to(dtype)
+    res0 = torch.randn(rows, cin, device="cuda").to(dtype)
+    got = {}
+    for mode in (True, False):
+        layers.GELU_GATE = mode
+        try:
+            for p_ in mlp.parameters():
+                p_.grad = None
+            x = x0.clone().requires_grad_(True)
+            r = res0.clone().requires_grad_(True)
+            out = mlp(x, residual=r)
+            (out.float() * torch.linspace(-1, 1, cin, device="cuda")).sum().backward()
+            torch.cuda.synchronize()
+            got[mode] = [out.detach().float(), x.grad.float(), r.grad.float()] + [p_.grad.float() for p_ in mlp.parameters()]
+        finally:
+            layers.GELU_GATE = True
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for a_, b_ in zip(got[True], got[False]):
+        assert rel(a_, b_) < tol
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
