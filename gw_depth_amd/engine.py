@@ -137,6 +137,7 @@ class TrainStep:
         self._state = None          # per-backward bookkeeping of the bucket hooks
         self._works = []
         self._cut = None            # graph capture: called with the bucket ids that just became ready
+        self._const_cache = {}      # small constant device tensors of losses(), never freed (captured graphs read them by address)
         if self.world > 1 or self.segments:
             for bi, (_, _, mem) in enumerate(self.buckets):
                 for n in mem:
@@ -268,10 +269,11 @@ class TrainStep:
             skip = set(kce) | set(kl1)
             keys = [k for k in keys if k not in skip]
             wk = (tuple(float(wd[k]) for k in kce), tuple(float(wd[k]) for k in kl1), ce.device)
-            if getattr(self, "_stack_key", None) != wk:
-                self._stack_key = wk
-                self._stack_w = (torch.tensor(wk[0], dtype=torch.float32, device=ce.device), torch.tensor(wk[1], dtype=torch.float32, device=ce.device))
-            parts, coef = [(ce.float() * self._stack_w[0]).sum(), (l1.float() * self._stack_w[1]).sum()], [1.0, 1.0]
+            sw = self._const_cache.get(wk)
+            if sw is None:
+                sw = self._const_cache[wk] = (torch.tensor(wk[0], dtype=torch.float32, device=ce.device),
+                                              torch.tensor(wk[1], dtype=torch.float32, device=ce.device))
+            parts, coef = [(ce.float() * sw[0]).sum(), (l1.float() * sw[1]).sum()], [1.0, 1.0]
         else:
             parts, coef = [], []
         parts += [terms[k] for k in keys]
@@ -294,10 +296,15 @@ class TrainStep:
         parts.append(ls)
         coef.append(1.0)
         # engine_glassrgbd.py:120-134: the weighted sum of the 17 terms, as one stack/multiply/sum instead of 34 scalar kernels
+        # constant tensors read by the step are kept for the life of the TrainStep, one per distinct value: a captured HIP graph reads them
+        # by address, and a step that takes another path (the host-matcher fallback has 17 terms, the packed path 7) must not free the
+        # tensor a captured chain still uses - with ONE cached slot the replay after such a step read recycled memory (found by the
+        # two-rank graph test: |g| 187 instead of 250 on the step behind the fallback)
         ck = (tuple(coef), parts[0].device)
-        if getattr(self, "_coef_key", None) != ck:
-            self._coef_key, self._coef = ck, torch.tensor(coef, dtype=torch.float32, device=parts[0].device)
-        total = (torch.stack([p.float().reshape(()) for p in parts]) * self._coef).sum()
+        cf = self._const_cache.get(ck)
+        if cf is None:
+            cf = self._const_cache[ck] = torch.tensor(coef, dtype=torch.float32, device=parts[0].device)
+        total = (torch.stack([p.float().reshape(()) for p in parts]) * cf).sum()
         return total, terms
 
     # ------------------------------------------------------------------ the step

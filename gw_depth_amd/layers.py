@@ -71,7 +71,8 @@ class FrozenBN(nn.Module):
 
     def _load_from_state_dict(self, state_dict, prefix, *args):
         state_dict.pop(prefix + "num_batches_tracked", None)      # backbone.py:35-43
-        self._cache = None
+        if self._cache is not None:
+            self._cache = (None,) + self._cache[1:]               # stale: folded() refreshes the two tensors in place
         super()._load_from_state_dict(state_dict, prefix, *args)
 
     def _apply(self, fn, *a, **k):
@@ -84,7 +85,14 @@ class FrozenBN(nn.Module):
         if self._cache is None or self._cache[0] != key:
             scale = self.weight * (self.running_var + 1e-5).rsqrt()
             shift = self.bias - self.running_mean * scale
-            self._cache = (key, scale.float().contiguous(), shift.float().contiguous())
+            old = self._cache
+            if old is not None and old[1].device == scale.device and old[1].shape == scale.shape:
+                # refreshed IN PLACE: a captured HIP graph reads these two tensors by address (buffers reloaded after a capture)
+                old[1].copy_(scale.float())
+                old[2].copy_(shift.float())
+                self._cache = (key, old[1], old[2])
+            else:
+                self._cache = (key, scale.float().contiguous(), shift.float().contiguous())
         return self._cache[1], self._cache[2]
 
 
