@@ -272,6 +272,24 @@ def _weight_transposed(w, row_scale, dtype):
 
 
 _DIM_T = {}
+UPSAMPLED_DGRAD_AS_STRIDED_CONV = True
+
+
+def _upsampled_dgrad_weight(w, dtype):
+    """Data gradient of `3x3 conv over a 2x nearest-upsampled map` onto the LOW-resolution input, as ONE 4x4 / stride 2 / pad 1
+    convolution of the output gradient: summing the 2 x 2 children of a low-res pixel commutes into the taps,
+        gx[y', x'] = sum_{t, s = 0..3} gy[2 y' - 1 + t, 2 x' - 1 + s] . Wk[t][s],   Wk[t][s] = sum_{kh in G(t), kw in G(s)} W[kh][kw],
+        G(0) = {2}, G(1) = {1, 2}, G(2) = {0, 1}, G(3) = {0}
+    - 16 taps per low-res pixel = 4 per high-res one instead of 9, and no high-resolution gradient map in memory (the transposed
+    gather wrote it, 314 MB for the last decoder stage, and the footprint sum read it back).  w (Cout, 3, 3, Cin) fp32 master ->
+    (Cin, 4, 4, Cout) in `dtype`: the weight operand of gwd_conv_forward with x = gy."""
+    # element-wise sums only: an einsum here becomes a library batched GEMM, which cannot be issued inside a HIP-graph capture
+    wp = w.detach().float().permute(3, 1, 2, 0)                                             # (Cin, kh, kw, Cout)
+    r = torch.stack([wp[:, 2], wp[:, 1] + wp[:, 2], wp[:, 0] + wp[:, 1], wp[:, 0]], dim=1)       # (Cin, 4, kw, Cout)
+    wk = torch.stack([r[:, :, 2], r[:, :, 1] + r[:, :, 2], r[:, :, 0] + r[:, :, 1], r[:, :, 0]], dim=2)
+    return wk.to(dtype).contiguous()
+
+
 
 
 def mask_levels(pad_mask, sizes):
@@ -521,7 +539,13 @@ class _ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = _weight_transposed(w, row_scale, x.dtype)
             gate = dict(gate=(x if gate_src is None else gate_src), gate_act=ctx.in_gate) if ctx.in_gate != ACT_NONE else {}
-            if gather == GATHER_UPSAMPLED:
+            if (gather == GATHER_UPSAMPLED and UPSAMPLED_DGRAD_AS_STRIDED_CONV and x.is_cuda and x.dtype == torch.bfloat16 and KH == 3 and KW == 3
+                    and pad == 1 and vv == (2 * Hi, 2 * Wi) and row_scale is None and (g_in is None or not gate)):
+                # one strided convolution of the gradient with the 4x4 collapse of the weights (see _upsampled_dgrad_weight)
+                gx = torch.empty_like(x)
+                lib.conv_forward(dv, _upsampled_dgrad_weight(w, x.dtype), gx, (B, Ho, Wo, Cout, Hi, Wi, Cin, 4, 4), stride=2, pad=1,
+                                 residual=g_in, **gate)
+            elif gather == GATHER_UPSAMPLED:
                 gxv = torch.empty((B, vv[0], vv[1], Cin), dtype=x.dtype, device=x.device)
                 lib.conv_forward(dv, wt, gxv, (B, Ho, Wo, Cout, vv[0], vv[1], Cin, KH, KW), stride=1, pad=pad,
                                  gather=GATHER_TRANSPOSED)
