@@ -581,7 +581,23 @@ class _ConvFn(torch.autograd.Function):
             gx = g_in
         if ctx.needs_input_grad[1]:
             # row_scale (folded FrozenBN: the layer ran with w * scale) multiplies the gradient inside the kernel's epilogue
-            if w_sink is not None:
+            if (w_sink is not None and gather == GATHER_UPSAMPLED and UPSAMPLED_DGRAD_AS_STRIDED_CONV and x.is_cuda and x.dtype == torch.bfloat16
+                    and KH == 3 and KW == 3 and pad == 1 and vv == (2 * Hi, 2 * Wi) and row_scale is None):
+                # the weight gradient through the same 4x4 / stride 2 form: D[ci][t][s][co] = sum_{y', x'} x[y', x', ci] gy[2 y' - 1 + t, 2 x' - 1 + s, co]
+                # is the ordinary weight gradient of that strided convolution (operands swapped: its input is gy, its output side x) - 16 taps per
+                # low-res pixel instead of 36, on the grouped GEMM kernels - and dW[co][kh][kw][ci] = sum_{t in T(kh), s in T(kw)} D[ci][t][s][co],
+                # T(0) = {2, 3}, T(1) = {1, 2}, T(2) = {0, 1}, added to the flat gradient when the batch has been issued
+                D = WGRADS.scratch((Cin, 4, 4, Cout), x.device)
+
+                def fold(D=D, sink=w_sink, shape=(Cout, KH, KW, Cin)):
+                    r = torch.stack([D[:, 2] + D[:, 3], D[:, 1] + D[:, 2], D[:, 0] + D[:, 1]], dim=1)
+                    q = torch.stack([r[:, :, 2] + r[:, :, 3], r[:, :, 1] + r[:, :, 2], r[:, :, 0] + r[:, :, 1]], dim=2)
+                    sink[0].view(shape).add_(q.permute(3, 1, 2, 0))
+                    if sink[1] is not None:
+                        sink[1]()
+
+                WGRADS.add(dv, x, D, (B, Ho, Wo, Cout, Hi, Wi, Cin, 4, 4), dict(stride=2, pad=1), fold)
+            elif w_sink is not None:
                 # the kernel ACCUMULATES (fp32 atomics): add straight into the flat gradient buffer, no temporary
                 WGRADS.add(x, dv, w_sink[0], dims, dict(stride=stride, pad=pad, gather=gather, virt=vv, scale=row_scale), w_sink[1])
             else:
