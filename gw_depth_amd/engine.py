@@ -51,9 +51,6 @@ def _align(n):
     return (n + ALIGN - 1) // ALIGN * ALIGN
 
 
-VECTOR_SET_TERMS = True      # the set criterion's twelve per-layer terms enter the total as two weighted vector sums
-
-
 class TrainStep:
     def __init__(self, model, criterions, cfg, compute_dtype=torch.float32, bucket_mb=32.0, process_group=None,
                  check_finite=True, data_parallel=True, graph=False, segments=None):
@@ -263,7 +260,7 @@ class TrainStep:
         wd = self.criterion.weight_dict
         keys = [k for k in terms if k in wd]
         stacks = getattr(self.criterion, "last_stacks", None)
-        if VECTOR_SET_TERMS and stacks is not None and all(k in wd for k in stacks[2] + stacks[3]):
+        if stacks is not None and all(k in wd for k in stacks[2] + stacks[3]):
             # the set criterion's per-layer terms as two weighted vector sums (same weights, same terms; the dict entries stay for logging)
             ce, l1, kce, kl1 = stacks
             skip = set(kce) | set(kl1)

@@ -96,7 +96,7 @@ class FrozenBN(nn.Module):
         return self._cache[1], self._cache[2]
 
 
-GELU_GATE = True     # MLPs: GELU backward in fc2's data-gradient epilogue
+GELU_GATE = True     # TEST HOOK (tests/test_hip_kernels.py compares the two forms): MLPs run GELU's backward in fc2's data-gradient epilogue
 
 
 class Mlp(nn.Module):

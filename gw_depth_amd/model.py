@@ -512,9 +512,6 @@ def unroll_crop(win, H, W, Hp, Wp, shift):
     return t[:, :H, :W, :]
 
 
-FUSE_TOKEN_LAUNCHES = True      # class-token Swin blocks: the depth / seg token streams share launches with each other and the feature map
-
-
 class SwinBlock(nn.Module):
     """SwinTransformerBlock.forward, multiscale_transformerr.py:646-788."""
 
@@ -553,15 +550,9 @@ class SwinBlock(nn.Module):
             dn, dtok = self.norm_depth1(dtok, fan=True)
             sn, stok = self.norm_seg1(stok, fan=True)
             # the three maps of the block are partitioned / reversed together: one launch each way instead of three
-            if FUSE_TOKEN_LAUNCHES:
-                xw, dn, sn = ops.window_gather_multi([xn, dn.view(B, H, W, tC), sn.view(B, H, W, tC)], shift)
-            else:
-                xw, dn, sn = (ops.window_gather(t, shift) for t in (xn, dn.view(B, H, W, tC), sn.view(B, H, W, tC)))
+            xw, dn, sn = ops.window_gather_multi([xn, dn.view(B, H, W, tC), sn.view(B, H, W, tC)], shift)
             aw, dw, sw = self.attn(xw, dn, sn, mask)
-            if FUSE_TOKEN_LAUNCHES:
-                x, d, s = ops.window_scatter_multi([aw, dw, sw], B, H, W, shift, [x, dtok, stok])
-            else:
-                x, d, s = (ops.window_scatter(w_, B, H, W, shift, residual=r_) for w_, r_ in ((aw, x), (dw, dtok), (sw, stok)))
+            x, d, s = ops.window_scatter_multi([aw, dw, sw], B, H, W, shift, [x, dtok, stok])
             x = self.mlp(*self.norm2(x.view(B, H * W, C), fan=True))
             d = self.mlp_depth(*self.norm_depth2(d.view(B, H * W, tC), fan=True))
             s = self.mlp_seg(*self.norm_seg2(s.view(B, H * W, tC), fan=True))

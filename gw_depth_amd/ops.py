@@ -272,7 +272,6 @@ def _weight_transposed(w, row_scale, dtype):
 
 
 _DIM_T = {}
-UPSAMPLED_DGRAD_AS_STRIDED_CONV = True
 
 
 def _upsampled_dgrad_weight(w, dtype):
@@ -539,7 +538,7 @@ class _ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = _weight_transposed(w, row_scale, x.dtype)
             gate = dict(gate=(x if gate_src is None else gate_src), gate_act=ctx.in_gate) if ctx.in_gate != ACT_NONE else {}
-            if (gather == GATHER_UPSAMPLED and UPSAMPLED_DGRAD_AS_STRIDED_CONV and x.is_cuda and x.dtype == torch.bfloat16 and KH == 3 and KW == 3
+            if (gather == GATHER_UPSAMPLED and x.is_cuda and x.dtype == torch.bfloat16 and KH == 3 and KW == 3
                     and pad == 1 and vv == (2 * Hi, 2 * Wi) and row_scale is None and (g_in is None or not gate)):
                 # one strided convolution of the gradient with the 4x4 collapse of the weights (see _upsampled_dgrad_weight)
                 gx = torch.empty_like(x)
@@ -581,7 +580,7 @@ class _ConvFn(torch.autograd.Function):
             gx = g_in
         if ctx.needs_input_grad[1]:
             # row_scale (folded FrozenBN: the layer ran with w * scale) multiplies the gradient inside the kernel's epilogue
-            if (w_sink is not None and gather == GATHER_UPSAMPLED and UPSAMPLED_DGRAD_AS_STRIDED_CONV and x.is_cuda and x.dtype == torch.bfloat16
+            if (w_sink is not None and gather == GATHER_UPSAMPLED and x.is_cuda and x.dtype == torch.bfloat16
                     and KH == 3 and KW == 3 and pad == 1 and vv == (2 * Hi, 2 * Wi) and row_scale is None):
                 # the weight gradient through the same 4x4 / stride 2 form: D[ci][t][s][co] = sum_{y', x'} x[y', x', ci] gy[2 y' - 1 + t, 2 x' - 1 + s, co]
                 # is the ordinary weight gradient of that strided convolution (operands swapped: its input is gy, its output side x) - 16 taps per
@@ -1300,16 +1299,13 @@ class _WinAttnPackedFn(torch.autograd.Function):
         return g, gtab, None, None, None, None, None
 
 
-TABLE_GRAD_HEAD_MAJOR = True
-
-
 def _winattn_table_grad(tb, sink, run, rel):
     """Backward of the relative-position table of a window attention: run(dbias, head_major) launches the kernel.  On the device the
     kernel accumulates into a zeroed (heads, n_rel) scratch - a wave's flush is then one contiguous run of atomics instead of n_rel
     4-byte adds in n_rel different 64-byte segments, 41-59 us of every launch - and the transposed scratch is added to the table's
     gradient (the flat-buffer slice when there is a sink).  Returns what autograd gets for the table (None with a sink)."""
     direct = sink is not None
-    if TABLE_GRAD_HEAD_MAJOR and tb.is_cuda and rel is not None:
+    if tb.is_cuda and rel is not None:
         tmp = WGRADS.scratch((tb.shape[1], tb.shape[0]), tb.device)
         run(tmp, True)
         if not direct:

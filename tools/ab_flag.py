@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Same-box A/B of a module-level switch of the Python layer: tools/ab_flag.py gw_depth_amd.model.FUSE_TOKEN_LAUNCHES [bench args] runs
+"""Same-box A/B of a module-level switch of the Python layer: tools/ab_flag.py gw_depth_amd.layers.GELU_GATE [bench args] runs
 bench.py with the flag False / True, twice, interleaved (each in its own process), and prints ms_per_step."""
 import importlib, json, os, runpy, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
