@@ -12,6 +12,7 @@
 
 namespace {
 
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 constexpr int C = 32, TILE = 16, HALO = TILE + 2, PIX = 80;     // PIX: LDS bytes per pixel (64 + 16: conflict-free 16-byte reads)
 
 // x tile with halo -> LDS (zero outside the image); tile origin (h0, w0) of image b
@@ -52,14 +53,13 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(const gwd_conv_desc d) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const bf16x8 xv = *(const bf16x8 *)(px + v * 16);
+            const uint32_t *xw = (const uint32_t *)&xv;
 #pragma unroll
             for (int n = 0; n < NO; ++n) {
                 const uint32_t *wp = wq + ((n * 9 + tap) * C + v * 8) / 2;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t pr = wp[j];
-                    acc[n] += (float)xv[2 * j] * __builtin_bit_cast(float, pr << 16) + (float)xv[2 * j + 1] * __builtin_bit_cast(float, pr & 0xffff0000u);
-                }
+                for (int j = 0; j < 4; ++j)         // v_dot2c_f32_bf16: two multiply-adds per instruction straight from the packed pairs (was: two conversions + two FMAs)
+                    acc[n] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, xw[j]), __builtin_bit_cast(bf16x2, wp[j]), acc[n], false);
             }
         }
     }
@@ -165,12 +165,19 @@ __global__ __launch_bounds__(320) void thin_wgrad_kernel(const gwd_conv_desc d, 
         }
         __syncthreads();
         if (worker) {
-#pragma unroll 4
-            for (int p = 0; p < TILE * TILE; ++p) {
-                const int py = p / TILE, px = p % TILE;
-                const float xv = (float)*(const __bf16 *)(xs + ((py + kh) * HALO + px + kw) * PIX + c * 2);
+            // one tile row per trip, its 16 pixels unrolled: every LDS address of the row is the row's base plus a constant.  The flat pixel
+            // loop spent ~6 vector instructions per multiply-add on index arithmetic (SQ_INSTS_VALU 64 M per launch against 11 M useful
+            // ones): the kernel is bound by instruction issue, not by its 157 MB of activations - 167 / 148 -> 136 / 102 us.  (Channel pairs
+            // per thread with 16-byte gradient reads: fewer instructions still, but 144 busy threads of 320: 178 / 133 us.)
+            for (int py = 0; py < TILE; ++py) {
+                const char *xrow = xs + ((py + kh) * HALO + kw) * PIX + c * 2;
+                const float *grow = gs + py * TILE * NO;
 #pragma unroll
-                for (int n = 0; n < NO; ++n) acc[n] += gs[p * NO + n] * xv;
+                for (int px = 0; px < TILE; ++px) {
+                    const float xv = (float)*(const __bf16 *)(xrow + px * PIX);
+#pragma unroll
+                    for (int n = 0; n < NO; ++n) acc[n] += grow[px * NO + n] * xv;
+                }
             }
         }
     }
