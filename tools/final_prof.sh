@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp PYTHONUNBUFFERED=1; R=$GRAFT_REPO_ROOT; O=$R/gpuru
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/p4/f -- python3 $R/tools/roofline_kernel.py 20 > $O/p4/f.log 2>&1; echo pass1;
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/p4/w -- python3 $R/tools/roofline_kernel.py 20 > $O/p4/w.log 2>&1; echo pass2;
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/p4/h -- python3 $R/tools/roofline_kernel.py 20 > $O/p4/h.log 2>&1; echo pass3;
-cd $R; python tools/pmc_dominant.py $O/p4/f $O/p4/w $O/p4/h $O/pmc_dominant_kernel.json eb411b5 > $O/p4/pmc_dom.log 2>&1; tail -3 $O/p4/pmc_dom.log;
+cd $R; python tools/pmc_dominant.py $O/p4/f $O/p4/w $O/p4/h $O/pmc_dominant_kernel.json a1aabfd > $O/p4/pmc_dom.log 2>&1; tail -3 $O/p4/pmc_dom.log;
 # 2. whole step: two counter passes over an eager bench run
 cd /tmp; rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/p4/sf -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph > $O/p4/sf.log 2>&1; echo pass4;
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/p4/sw -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph > $O/p4/sw.log 2>&1; echo pass5;
