@@ -639,11 +639,14 @@ __device__ __forceinline__ void put_row_e(__bf16 *img, const __bf16 *src, int la
         }
     }
 }
-__device__ __forceinline__ void put_row_4(__bf16 *img, const __bf16 *src, int lane) {      // q / dO rows: 4 channels, zero-filled to 16
+// q / dO rows: 4 channels (R = 8: the 4 channels of a second query set behind them - the two class tokens share k and v, and the softmax is per
+// query channel, so the pair is ONE problem with 8 query channels: k / v staged once, dk / dv come out summed), zero-filled to 16
+template <int R>
+__device__ __forceinline__ void put_row_4(__bf16 *img, const __bf16 *src, const __bf16 *src2, int lane) {
     if (lane < NT) {
         __bf16 *dst = img + lane * QS;
         *(uint2 *)dst = *(const uint2 *)src;
-        *(uint2 *)(dst + 4) = make_uint2(0, 0);
+        *(uint2 *)(dst + 4) = R == 8 ? *(const uint2 *)src2 : make_uint2(0, 0);
         *(uint4 *)(dst + 8) = make_uint4(0, 0, 0, 0);
     }
 }
@@ -694,18 +697,24 @@ __device__ __forceinline__ void softmax_rows(f32x16 &x, float scale, int h) {
     for (int i = 0; i < 16; ++i) x[i] *= inv;
 }
 
-__device__ __forceinline__ void store4(const TOp &o, long w, int head, int nt, const f32x16 &z, float mul, int lane) {
-    const int tokn = 32 * nt + (lane & 31);
-    if ((lane >> 5) == 0 && tokn < NT) {                  // rows r = 0..3 are registers 0..3 of the lower half
+__device__ __forceinline__ const __bf16 *tok_row(const TOp &t, long w, int tok, int head) {
+    return (const __bf16 *)t.p + w * t.ws + (long)tok * t.ts + (long)head * t.hs;
+}
+
+template <int R>
+__device__ __forceinline__ void store4(const TOp &o, const TOp &o2, long w, int head, int nt, const f32x16 &z, float mul, int lane) {
+    const int tokn = 32 * nt + (lane & 31), h = lane >> 5;
+    if ((h == 0 || R == 8) && tokn < NT) {                // rows r = 0..3 are registers 0..3 of the lower half, rows 4..7 of the upper half
         union { uint2 u; __bf16 e[4]; } v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v.e[j] = (__bf16)(z[j] * mul);
-        *(uint2 *)((__bf16 *)o.p + w * o.ws + (long)tokn * o.ts + (long)head * o.hs) = v.u;
+        const TOp &t = (R == 8 && h) ? o2 : o;
+        *(uint2 *)((__bf16 *)t.p + w * t.ws + (long)tokn * t.ts + (long)head * t.hs) = v.u;
     }
 }
 
-template <int E, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void tok_fwd_kernel(TOp q, TOp k, TOp v, TOp o, long n_problems, int heads, float scale) {
+template <int E, int WAVES, int R>
+__global__ __launch_bounds__(64 * WAVES) void tok_fwd_kernel(TOp q, TOp k, TOp v, TOp o, TOp q2, TOp o2, long n_problems, int heads, float scale) {
     extern __shared__ __attribute__((aligned(16))) __bf16 smem_t[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     constexpr int PER = 64 * QS + 2 * 64 * KSTR;
@@ -717,22 +726,23 @@ __global__ __launch_bounds__(64 * WAVES) void tok_fwd_kernel(TOp q, TOp k, TOp v
     for (long pb = vblock * WAVES + wave; pb < n_problems; pb += (long)gridDim.x * WAVES) {
         const long w = pb / heads;
         const int head = (int)(pb - w * heads);
-        put_row_4(qi, (const __bf16 *)q.p + w * q.ws + (long)tokc * q.ts + (long)head * q.hs, lane);
+        put_row_4<R>(qi, tok_row(q, w, tokc, head), R == 8 ? tok_row(q2, w, tokc, head) : nullptr, lane);
         put_row_e<E>(ki, (const __bf16 *)k.p + w * k.ws + (long)tokc * k.ts + (long)head * k.hs, lane);
         put_row_e<E>(vi, (const __bf16 *)v.p + w * v.ws + (long)tokc * v.ts + (long)head * v.hs, lane);
         lds_settle();
         f32x16 a = tokens_product(ki, qi, lane);           // S^T[c][r]
         softmax_rows<E>(a, scale, h);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) store4(o, w, head, nt, channels_product<E>(a, vi, nt, lane), 1.0f, lane);
+        for (int nt = 0; nt < 2; ++nt) store4<R>(o, o2, w, head, nt, channels_product<E>(a, vi, nt, lane), 1.0f, lane);
         lds_settle();
     }
 }
 
-// accumulator X[c][r] (lane = r < 4 real) -> bf16 image [c][16] (columns 4..15 stay zero)
+// accumulator X[c][r] (lane = r < R real) -> bf16 image [c][16] (columns R..15 stay zero)
+template <int R>
 __device__ __forceinline__ void put_cr(__bf16 *img, const f32x16 &x, int lane) {
     const int r = lane & 31, h = lane >> 5;
-    if (r < 4) {
+    if (r < R) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) img[acc_row(i, h) * AS + r] = (__bf16)x[i];
     }
@@ -764,9 +774,9 @@ __device__ __forceinline__ void store_e(const TOp &o, long w, int head, int nt, 
     }
 }
 
-template <int E, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void tok_bwd_kernel(TOp q, TOp k, TOp v, TOp go, TOp gq, TOp gk, TOp gv, long n_problems, int heads,
-                                                            float scale) {
+template <int E, int WAVES, int R>
+__global__ __launch_bounds__(64 * WAVES) void tok_bwd_kernel(TOp q, TOp k, TOp v, TOp go, TOp gq, TOp gk, TOp gv, TOp q2, TOp go2, TOp gq2, long n_problems,
+                                                            int heads, float scale) {
     extern __shared__ __attribute__((aligned(16))) __bf16 smem_u[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     constexpr int PER = 2 * 64 * QS + 2 * 64 * KSTR + 2 * 32 * AS;
@@ -778,8 +788,8 @@ __global__ __launch_bounds__(64 * WAVES) void tok_bwd_kernel(TOp q, TOp k, TOp v
     for (long pb = vblock * WAVES + wave; pb < n_problems; pb += (long)gridDim.x * WAVES) {
         const long w = pb / heads;
         const int head = (int)(pb - w * heads);
-        put_row_4(qi, (const __bf16 *)q.p + w * q.ws + (long)tokc * q.ts + (long)head * q.hs, lane);
-        put_row_4(oi, (const __bf16 *)go.p + w * go.ws + (long)tokc * go.ts + (long)head * go.hs, lane);
+        put_row_4<R>(qi, tok_row(q, w, tokc, head), R == 8 ? tok_row(q2, w, tokc, head) : nullptr, lane);
+        put_row_4<R>(oi, tok_row(go, w, tokc, head), R == 8 ? tok_row(go2, w, tokc, head) : nullptr, lane);
         put_row_e<E>(ki, (const __bf16 *)k.p + w * k.ws + (long)tokc * k.ts + (long)head * k.hs, lane);
         put_row_e<E>(vi, (const __bf16 *)v.p + w * v.ws + (long)tokc * v.ts + (long)head * v.hs, lane);
         lds_settle();
@@ -792,10 +802,10 @@ __global__ __launch_bounds__(64 * WAVES) void tok_bwd_kernel(TOp q, TOp k, TOp v
         dot += __shfl_xor(dot, 32, 64);
 #pragma unroll
         for (int i = 0; i < 16; ++i) da[i] = a[i] * (da[i] - dot);      // dS^T (unscaled; the scale rides on the stores)
-        put_cr(ai, a, lane);
-        put_cr(si, da, lane);
+        put_cr<R>(ai, a, lane);
+        put_cr<R>(si, da, lane);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) store4(gq, w, head, nt, channels_product<E>(da, ki, nt, lane), scale, lane);     // dq[n][r] = scale sum_c dS[r][c] k[n][c]
+        for (int nt = 0; nt < 2; ++nt) store4<R>(gq, gq2, w, head, nt, channels_product<E>(da, ki, nt, lane), scale, lane);     // dq[n][r] = scale sum_c dS[r][c] k[n][c]
         lds_settle();
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -806,9 +816,10 @@ __global__ __launch_bounds__(64 * WAVES) void tok_bwd_kernel(TOp q, TOp k, TOp v
     }
 }
 
-template <int E>
+// operands: forward q k v o [q2 o2], backward q k v go gq gk gv [q2 go2 gq2]
+template <int E, int R>
 int run(bool bwd, const gwd_strided *const *s, long n_problems, int heads, float scale, hipStream_t st) {
-    for (int i = 0; i < (bwd ? 7 : 4); ++i)                 // 8-byte rows everywhere
+    for (int i = 0; i < (bwd ? 7 : 4) + (R == 8 ? (bwd ? 3 : 2) : 0); ++i)                 // 8-byte rows everywhere
         if ((uintptr_t)s[i]->p % 8 || s[i]->ws % 4 || s[i]->ts % 4 || s[i]->hs % 4) return 1;
     auto mk = [](const gwd_strided *x) { return TOp{x->p, x->ws, x->ts, x->hs}; };
     if (!bwd) {
@@ -816,14 +827,15 @@ int run(bool bwd, const gwd_strided *const *s, long n_problems, int heads, float
         long bx = (n_problems + WAVES - 1) / WAVES;
         if (bx > 1024) bx = 1024;
         const size_t lds = (size_t)WAVES * (64 * QS + 2 * 64 * KSTR) * 2;
-        tok_fwd_kernel<E, WAVES><<<(unsigned)bx, 64 * WAVES, lds, st>>>(mk(s[0]), mk(s[1]), mk(s[2]), mk(s[3]), n_problems, heads, scale);
+        tok_fwd_kernel<E, WAVES, R><<<(unsigned)bx, 64 * WAVES, lds, st>>>(mk(s[0]), mk(s[1]), mk(s[2]), mk(s[3]), mk(s[R == 8 ? 4 : 0]), mk(s[R == 8 ? 5 : 3]),
+                                                                           n_problems, heads, scale);
     } else {
         constexpr int WAVES = 2;
         long bx = (n_problems + WAVES - 1) / WAVES;
         if (bx > 2048) bx = 2048;
         const size_t lds = (size_t)WAVES * (2 * 64 * QS + 2 * 64 * KSTR + 2 * 32 * AS) * 2;
-        tok_bwd_kernel<E, WAVES><<<(unsigned)bx, 64 * WAVES, lds, st>>>(mk(s[0]), mk(s[1]), mk(s[2]), mk(s[3]), mk(s[4]), mk(s[5]), mk(s[6]), n_problems,
-                                                                         heads, scale);
+        tok_bwd_kernel<E, WAVES, R><<<(unsigned)bx, 64 * WAVES, lds, st>>>(mk(s[0]), mk(s[1]), mk(s[2]), mk(s[3]), mk(s[4]), mk(s[5]), mk(s[6]), mk(s[R == 8 ? 7 : 0]),
+                                                                            mk(s[R == 8 ? 8 : 3]), mk(s[R == 8 ? 9 : 4]), n_problems, heads, scale);
     }
     return 0;
 }
@@ -831,16 +843,16 @@ int run(bool bwd, const gwd_strided *const *s, long n_problems, int heads, float
 }  // namespace tok
 
 // 0 = launched, 1 = not covered (the caller keeps the lane-per-token kernels); bf16 only
-int gwd_mfattn_token(bool backward, const gwd_strided *const *ops, long n_problems, int heads, int e, float scale, hipStream_t s) {
+int gwd_mfattn_token(bool backward, bool pair, const gwd_strided *const *ops, long n_problems, int heads, int e, float scale, hipStream_t s) {
     // measured per launch (53 k problems at E = 12, 13.8 k at 16, 3.8 k at 24): forward 107 / 39 / 23 us on the lane-per-token kernels ->
     // 90 / 20 / ~12 here; backward 224 / 77 / 43 -> 269 / 52 / 20: at E = 12 the 48 wave reductions of the VALU form are cheaper than this
     // kernel's 8-24-byte-per-lane row traffic, so that one case stays there
     // (with a window's head groups on one XCD - xcd_grouped_block - the E = 12 backward is the faster one here as well: same-box
     //  A/B -0.1 ... -0.25 ms per step)
     switch (e) {
-        case 12: return tok::run<12>(backward, ops, n_problems, heads, scale, s);
-        case 16: return tok::run<16>(backward, ops, n_problems, heads, scale, s);
-        case 24: return tok::run<24>(backward, ops, n_problems, heads, scale, s);
+        case 12: return pair ? tok::run<12, 8>(backward, ops, n_problems, heads, scale, s) : tok::run<12, 4>(backward, ops, n_problems, heads, scale, s);
+        case 16: return pair ? tok::run<16, 8>(backward, ops, n_problems, heads, scale, s) : tok::run<16, 4>(backward, ops, n_problems, heads, scale, s);
+        case 24: return pair ? tok::run<24, 8>(backward, ops, n_problems, heads, scale, s) : tok::run<24, 4>(backward, ops, n_problems, heads, scale, s);
         default: return 1;
     }
 }

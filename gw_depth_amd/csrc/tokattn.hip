@@ -198,7 +198,7 @@ int by_e(int e, bool bwd, const gwd_strided *const *s, long np, int heads, float
 }  // namespace
 
 // mfattn.hip: the same problem on the matrix cores (bf16); 0 = launched, 1 = not covered
-int gwd_mfattn_token(bool backward, const gwd_strided *const *ops, long n_problems, int heads, int e, float scale, hipStream_t s);
+int gwd_mfattn_token(bool backward, bool pair, const gwd_strided *const *ops, long n_problems, int heads, int e, float scale, hipStream_t s);
 
 static bool mfma_token_enabled() { return true; }       // bf16: csrc/mfattn.hip; the lane-per-token kernels below are the fp32 (parity) path
 
@@ -206,7 +206,7 @@ extern "C" int gwd_tokattn_forward(const gwd_strided *q, const gwd_strided *k, c
                                    int64_t n_windows, int32_t heads, int32_t e, float scale, int32_t dtype, void *stream) {
     if (!q || !k || !v || !o || !q->p || !k->p || !v->p || !o->p || n_windows <= 0 || heads <= 0) return -1;
     const gwd_strided *s[4] = {q, k, v, o};
-    if (dtype == GWD_BF16 && mfma_token_enabled() && gwd_mfattn_token(false, s, n_windows * heads, heads, e, scale, (hipStream_t)stream) == 0) {
+    if (dtype == GWD_BF16 && mfma_token_enabled() && gwd_mfattn_token(false, false, s, n_windows * heads, heads, e, scale, (hipStream_t)stream) == 0) {
         GWD_CHECK_LAUNCH();
         return 0;
     }
@@ -221,11 +221,36 @@ extern "C" int gwd_tokattn_backward(const gwd_strided *q, const gwd_strided *k, 
     if (!q || !k || !v || !go || !gq || !gk || !gv || n_windows <= 0 || heads <= 0) return -1;
     if (!q->p || !k->p || !v->p || !go->p || !gq->p || !gk->p || !gv->p) return -1;
     const gwd_strided *s[7] = {q, k, v, go, gq, gk, gv};
-    if (dtype == GWD_BF16 && mfma_token_enabled() && gwd_mfattn_token(true, s, n_windows * heads, heads, e, scale, (hipStream_t)stream) == 0) {
+    if (dtype == GWD_BF16 && mfma_token_enabled() && gwd_mfattn_token(true, false, s, n_windows * heads, heads, e, scale, (hipStream_t)stream) == 0) {
         GWD_CHECK_LAUNCH();
         return 0;
     }
     if (dtype == GWD_BF16) return by_e<__bf16>(e, true, s, n_windows * heads, heads, scale, (hipStream_t)stream);
     if (dtype == GWD_F32) return by_e<float>(e, true, s, n_windows * heads, heads, scale, (hipStream_t)stream);
     return -2;
+}
+
+// Both class tokens of a WindowClassAttention block in one launch (multiscale_transformerr.py:561-578: the depth and the segmentation token query
+// the SAME global_k / global_v): q / q2 (W,49,heads,4) -> o / o2; the backward returns gq / gq2 and the SUM of the two calls' gk / gv.  bf16 only
+// (-2 otherwise: the caller issues two gwd_tokattn_* calls), e in {12, 16, 24} (-4).
+extern "C" int gwd_tokattn_pair_forward(const gwd_strided *q, const gwd_strided *q2, const gwd_strided *k, const gwd_strided *v, const gwd_strided *o,
+                                        const gwd_strided *o2, int64_t n_windows, int32_t heads, int32_t e, float scale, int32_t dtype, void *stream) {
+    if (!q || !q2 || !k || !v || !o || !o2 || !q->p || !q2->p || !k->p || !v->p || !o->p || !o2->p || n_windows <= 0 || heads <= 0) return -1;
+    if (dtype != GWD_BF16) return -2;
+    const gwd_strided *s[6] = {q, k, v, o, q2, o2};
+    if (gwd_mfattn_token(false, true, s, n_windows * heads, heads, e, scale, (hipStream_t)stream) != 0) return -4;
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gwd_tokattn_pair_backward(const gwd_strided *q, const gwd_strided *q2, const gwd_strided *k, const gwd_strided *v, const gwd_strided *go,
+                                         const gwd_strided *go2, const gwd_strided *gq, const gwd_strided *gq2, const gwd_strided *gk, const gwd_strided *gv,
+                                         int64_t n_windows, int32_t heads, int32_t e, float scale, int32_t dtype, void *stream) {
+    if (!q || !q2 || !k || !v || !go || !go2 || !gq || !gq2 || !gk || !gv || n_windows <= 0 || heads <= 0) return -1;
+    if (!q->p || !q2->p || !k->p || !v->p || !go->p || !go2->p || !gq->p || !gq2->p || !gk->p || !gv->p) return -1;
+    if (dtype != GWD_BF16) return -2;
+    const gwd_strided *s[10] = {q, k, v, go, gq, gk, gv, q2, go2, gq2};
+    if (gwd_mfattn_token(true, true, s, n_windows * heads, heads, e, scale, (hipStream_t)stream) != 0) return -4;
+    GWD_CHECK_LAUNCH();
+    return 0;
 }

@@ -25,7 +25,7 @@ ENTRY_POINTS = [
     "gwd_softmax_backward", "gwd_silog_sums", "gwd_silog_backward", "gwd_seg_ce_sum", "gwd_seg_ce_backward",
     "gwd_sqnorm", "gwd_adamw_step", "gwd_resample_forward", "gwd_resample_backward", "gwd_avgpool_forward",
     "gwd_avgpool_backward", "gwd_winattn_forward", "gwd_winattn_backward", "gwd_tokattn_forward",
-    "gwd_tokattn_backward", "gwd_certain_sample", "gwd_lsap", "gwd_window_map", "gwd_window_map_multi",
+    "gwd_tokattn_backward", "gwd_tokattn_pair_forward", "gwd_tokattn_pair_backward", "gwd_certain_sample", "gwd_lsap", "gwd_window_map", "gwd_window_map_multi",
     "gwd_inorm_gelu_forward", "gwd_inorm_gelu_backward", "gwd_weight_prep_batch",
     "gwd_point_sample_forward", "gwd_point_sample_backward", "gwd_act_backward_colsum", "gwd_resample_backward_sep",
     "gwd_softmax_masked_forward", "gwd_softmax_scaled_backward", "gwd_query_workspace", "gwd_eval_accumulate", "gwd_colsum_batch", "gwd_conv_wgrad_batch",
@@ -209,6 +209,8 @@ class HipLibrary:
         L.gwd_ref_mix_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_tokattn_forward.argtypes = [sp] * 4 + [i64, i32, i32, f32, i32, vp]
         L.gwd_tokattn_backward.argtypes = [sp] * 7 + [i64, i32, i32, f32, i32, vp]
+        L.gwd_tokattn_pair_forward.argtypes = [sp] * 6 + [i64, i32, i32, f32, i32, vp]
+        L.gwd_tokattn_pair_backward.argtypes = [sp] * 10 + [i64, i32, i32, f32, i32, vp]
         L.gwd_certain_sample.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp]
         L.gwd_lsap.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
         L.gwd_inorm_gelu_forward.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, ctypes.c_float, i32, vp]
@@ -633,6 +635,20 @@ class HipLibrary:
         s = [_strided(t) for t in (q, k, v, go, gq, gk, gv)]
         self._check(self.lib.gwd_tokattn_backward(*[ctypes.byref(x) for x in s], W, H, k.shape[3], scale, dtype_code(q),
                                                   self._stream(q, go, gq)), "gwd_tokattn_backward")
+
+    def tokattn_pair_forward(self, q, q2, k, v, o, o2, scale):
+        """Both class tokens against the same k / v in one launch (bf16): q, q2 -> o, o2."""
+        W, N, H, _ = q.shape
+        s = [_strided(t) for t in (q, q2, k, v, o, o2)]
+        self._check(self.lib.gwd_tokattn_pair_forward(*[ctypes.byref(x) for x in s], W, H, k.shape[3], scale, dtype_code(q),
+                                                      self._stream(q, q2, k, v, o, o2)), "gwd_tokattn_pair_forward")
+
+    def tokattn_pair_backward(self, q, q2, k, v, go, go2, gq, gq2, gk, gv, scale):
+        """gq, gq2 per token; gk, gv summed over both tokens."""
+        W, N, H, _ = q.shape
+        s = [_strided(t) for t in (q, q2, k, v, go, go2, gq, gq2, gk, gv)]
+        self._check(self.lib.gwd_tokattn_pair_backward(*[ctypes.byref(x) for x in s], W, H, k.shape[3], scale, dtype_code(q),
+                                                       self._stream(q, go, gq)), "gwd_tokattn_pair_backward")
 
     def certain_sample(self, small, large, coords, edges, sample_num):
         """small (B,1,hs,ws), large (B,1,H,W) fp32; edges (I+1,) fp32; coords (B,S,1,2) fp32 out."""

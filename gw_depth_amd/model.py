@@ -489,11 +489,11 @@ class WindowClassAttention(WindowAttnBase):
         tk = self.global_k(tx).view(B_, N, HEADS, tC // HEADS)
         tv = self.global_v(tx).view(B_, N, HEADS, tC // HEADS)
 
-        def tok(q_lin, t):                                   # :561-578; both tokens go through proj_dth
-            q = q_lin(t).view(B_, N, HEADS, tdim // HEADS)
-            return self.proj_dth(ops.token_attention(q, tk, tv, self.scale))
-
-        return x, tok(self.cls_dth_q, dtok), tok(self.cls_seg_q, stok)
+        # :561-578; the two tokens query the same tk / tv (one launch for the pair), and both go through proj_dth
+        qd = self.cls_dth_q(dtok).view(B_, N, HEADS, tdim // HEADS)
+        qs = self.cls_seg_q(stok).view(B_, N, HEADS, tdim // HEADS)
+        od, os_ = ops.token_attention_pair(qd, qs, tk, tv, self.scale)
+        return x, self.proj_dth(od), self.proj_dth(os_)
 
 
 def pad_roll(t, H, W, shift):

@@ -1520,6 +1520,41 @@ def token_attention(q, k, v, scale):
     return _TokAttnFn.apply(q, k, v, float(scale))
 
 
+class _TokAttnPairFn(torch.autograd.Function):
+    """token_attention for both class tokens at once (bf16): the pair shares k / v, one launch each way, and the backward's gk / gv are
+    already the sum autograd would have formed from two nodes."""
+
+    @staticmethod
+    def forward(ctx, q, q2, k, v, scale):
+        fix = lambda t: t if t.stride(3) == 1 else t.contiguous()
+        q, q2, k, v = fix(q), fix(q2), fix(k), fix(v)
+        W, N, H, R = q.shape
+        o = torch.empty((W, N, H, R), dtype=q.dtype, device=q.device)
+        o2 = torch.empty_like(o)
+        _lib().tokattn_pair_forward(q, q2, k, v, o, o2, scale)
+        ctx.save_for_backward(q, q2, k, v)
+        ctx.scale = scale
+        return o.view(W, N, H * R), o2.view(W, N, H * R)
+
+    @staticmethod
+    def backward(ctx, go, go2):
+        q, q2, k, v = ctx.saved_tensors
+        W, N, H, R = q.shape
+        go, go2 = go.contiguous().view(W, N, H, R), go2.contiguous().view(W, N, H, R)
+        gq, gq2 = torch.empty_like(go), torch.empty_like(go)
+        gk = torch.empty(k.shape, dtype=k.dtype, device=k.device)
+        gv = torch.empty(v.shape, dtype=v.dtype, device=v.device)
+        _lib().tokattn_pair_backward(q, q2, k, v, go, go2, gq, gq2, gk, gv, ctx.scale)
+        return gq, gq2, gk, gv, None
+
+
+def token_attention_pair(q, q2, k, v, scale):
+    """token_attention(q, k, v), token_attention(q2, k, v); bf16 with e in {12, 16, 24}: one launch for the pair."""
+    if q.dtype == torch.bfloat16 and k.shape[3] in (12, 16, 24):
+        return _TokAttnPairFn.apply(q, q2, k, v, float(scale))
+    return token_attention(q, k, v, scale), token_attention(q2, k, v, scale)
+
+
 class _WindowGatherFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, shift):

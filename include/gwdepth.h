@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GWD_VERSION 9
+#define GWD_VERSION 10
 
 enum { GWD_F32 = 0, GWD_BF16 = 1 };
 enum { GWD_ACT_NONE = 0, GWD_ACT_RELU = 1, GWD_ACT_GELU = 2, GWD_ACT_ELU = 3, GWD_ACT_SIGMOID = 4 };
@@ -260,6 +260,18 @@ int gwd_tokattn_forward(const gwd_strided *q, const gwd_strided *k, const gwd_st
 int gwd_tokattn_backward(const gwd_strided *q, const gwd_strided *k, const gwd_strided *v, const gwd_strided *go,
                          const gwd_strided *gq, const gwd_strided *gk, const gwd_strided *gv, int64_t n_windows,
                          int32_t heads, int32_t e, float scale, int32_t dtype, void *stream);
+
+/* Both class tokens of a WindowClassAttention block in ONE launch (multiscale_transformerr.py:561-578: the depth token and the
+ * segmentation token query the same global_k / global_v).  The softmax is per query channel, so the pair is one problem with 8
+ * query channels: k / v are staged once and the backward's gk / gv are the SUM over both tokens (what autograd adds up after two
+ * gwd_tokattn_backward calls).  bf16 only (-2 otherwise: issue the two single calls), e in {12, 16, 24} (-4).                  */
+int gwd_tokattn_pair_forward(const gwd_strided *q, const gwd_strided *q2, const gwd_strided *k, const gwd_strided *v,
+                             const gwd_strided *o, const gwd_strided *o2, int64_t n_windows, int32_t heads, int32_t e,
+                             float scale, int32_t dtype, void *stream);
+int gwd_tokattn_pair_backward(const gwd_strided *q, const gwd_strided *q2, const gwd_strided *k, const gwd_strided *v,
+                              const gwd_strided *go, const gwd_strided *go2, const gwd_strided *gq, const gwd_strided *gq2,
+                              const gwd_strided *gk, const gwd_strided *gv, int64_t n_windows, int32_t heads, int32_t e,
+                              float scale, int32_t dtype, void *stream);
 
 /* CertainSample entirely on the device (src/models/points/points_sample.py:291-364): pred_small [B][hs][ws],
  * pred_large [B][H][W] fp32 sigmoid maps, edges[n_intervals+1] fp32 interval bounds -> coords [B][S][2] fp32

@@ -644,6 +644,18 @@ class FakeDevice:
         gk.copy_(g[1])
         gv.copy_(g[2])
 
+    def tokattn_pair_forward(self, q, q2, k, v, o, o2, scale):
+        self.tokattn_forward(q, k, v, o, scale)
+        self.tokattn_forward(q2, k, v, o2, scale)
+
+    def tokattn_pair_backward(self, q, q2, k, v, go, go2, gq, gq2, gk, gv, scale):
+        gk2, gv2 = torch.empty_like(gk, dtype=torch.float32), torch.empty_like(gv, dtype=torch.float32)
+        gk1, gv1 = torch.empty_like(gk2), torch.empty_like(gv2)
+        self.tokattn_backward(q, k, v, go, gq, gk1, gv1, scale)
+        self.tokattn_backward(q2, k, v, go2, gq2, gk2, gv2, scale)
+        gk.copy_(gk1 + gk2)
+        gv.copy_(gv1 + gv2)
+
     def certain_sample(self, small, large, coords, edges, sample_num):
         e = [float(v) for v in edges.tolist()]
         coords.copy_(_certain_sample_reference(small, large, e[1:-1], sample_num, e[0]))

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_entry_points():
         assert hasattr(lib, name), name
     lib.gwd_arch.restype = ctypes.c_char_p
-    assert lib.gwd_version() == 9 and lib.gwd_arch() == b"gfx950"
+    assert lib.gwd_version() == 10 and lib.gwd_arch() == b"gfx950"
 
 
 def test_code_object_targets_gfx950_only():

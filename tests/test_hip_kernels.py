@@ -399,6 +399,54 @@ def test_token_attention(dev, e, nwin, dtype):
     assert rel(o, o_r) < TOL[dtype] and rel(gq, gq_r) < TOL[dtype] and rel(gkv, gkv_r) < TOL[dtype]
 
 
+@pytest.mark.parametrize("e,nwin", [(12, 40), (16, 9), (24, 3), (12, 3000), (16, 1)])
+def test_token_attention_pair_is_two_single_calls(dev, e, nwin):
+    """Both class tokens in one launch (gwd_tokattn_pair_*): outputs and query gradients per token, k / v gradients summed."""
+    fake = FakeDevice()
+    H, dtype, scale = 16, torch.bfloat16, 0.5
+    q, q2 = rnd(nwin, 49, H, 4, dtype=dtype, seed=1), rnd(nwin, 49, H, 4, dtype=dtype, seed=5)
+    kv = rnd(nwin, 49, 2, H, e, dtype=dtype, seed=2)
+    go, go2 = rnd(nwin, 49, H, 4, dtype=dtype, seed=3), rnd(nwin, 49, H, 4, dtype=dtype, seed=4)
+    o_r, o2_r, gq_r, gq2_r = (torch.empty(nwin, 49, H, 4) for _ in range(4))
+    gkv_r = torch.empty(nwin, 49, 2, H, e)
+    fake.tokattn_pair_forward(q, q2, kv[:, :, 0], kv[:, :, 1], o_r, o2_r, scale)
+    fake.tokattn_pair_backward(q, q2, kv[:, :, 0], kv[:, :, 1], go, go2, gq_r, gq2_r, gkv_r[:, :, 0], gkv_r[:, :, 1], scale)
+    Q, Q2, KV = q.cuda(), q2.cuda(), kv.cuda()
+    nan = lambda *shape: torch.full(shape, float("nan"), dtype=dtype, device="cuda")
+    o, o2, gq, gq2, gkv = nan(nwin, 49, H, 4), nan(nwin, 49, H, 4), nan(nwin, 49, H, 4), nan(nwin, 49, H, 4), nan(nwin, 49, 2, H, e)
+    dev.tokattn_pair_forward(Q, Q2, KV[:, :, 0], KV[:, :, 1], o, o2, scale)
+    dev.tokattn_pair_backward(Q, Q2, KV[:, :, 0], KV[:, :, 1], go.cuda(), go2.cuda(), gq, gq2, gkv[:, :, 0], gkv[:, :, 1], scale)
+    torch.cuda.synchronize()
+    for name, a, b in (("o", o, o_r), ("o2", o2, o2_r), ("gq", gq, gq_r), ("gq2", gq2, gq2_r), ("gkv", gkv, gkv_r)):
+        assert rel(a, b) < TOL[dtype], name
+    # and against the single-call kernels themselves: the per-token halves are the same arithmetic
+    o_s = nan(nwin, 49, H, 4)
+    dev.tokattn_forward(Q2, KV[:, :, 0], KV[:, :, 1], o_s, scale)
+    torch.cuda.synchronize()
+    assert torch.equal(o_s, o2)
+    # fp32 is not covered: the binding raises, ops.token_attention_pair issues the two single calls instead
+    with pytest.raises(RuntimeError):
+        dev.tokattn_pair_forward(Q.float(), Q2.float(), KV[:, :, 0].float(), KV[:, :, 1].float(), o.float(), o2.float(), scale)
+
+
+def test_token_attention_pair_autograd_matches_two_nodes(dev):
+    from gw_depth_amd import ops
+    nwin, H, e = 24, 16, 16
+    mk = lambda *s, seed: rnd(*s, dtype=torch.bfloat16, seed=seed).cuda().requires_grad_(True)
+    q, q2, k, v = mk(nwin, 49, H, 4, seed=1), mk(nwin, 49, H, 4, seed=2), mk(nwin, 49, H, e, seed=3), mk(nwin, 49, H, e, seed=4)
+    w1, w2 = rnd(nwin, 49, H * 4, dtype=torch.bfloat16, seed=5).cuda(), rnd(nwin, 49, H * 4, dtype=torch.bfloat16, seed=6).cuda()
+    a, b = ops.token_attention_pair(q, q2, k, v, 0.5)
+    g_pair = torch.autograd.grad((a.float() * w1).sum() + (b.float() * w2).sum(), [q, q2, k, v])
+    a1, b1 = ops.token_attention(q, k, v, 0.5), ops.token_attention(q2, k, v, 0.5)
+    g_two = torch.autograd.grad((a1.float() * w1).sum() + (b1.float() * w2).sum(), [q, q2, k, v])
+    assert torch.equal(a, a1) and torch.equal(b, b1)
+    for x, y in zip(g_pair, g_two):
+        assert rel(x, y) < TOL[torch.bfloat16]
+    # fp32 operands take the two-call route
+    a32, b32 = ops.token_attention_pair(q.float(), q2.float(), k.float(), v.float(), 0.5)
+    assert rel(a32, a) < TOL[torch.bfloat16] and rel(b32, b) < TOL[torch.bfloat16]
+
+
 @pytest.mark.parametrize("layers,B,Q,sizes", [(6, 8, 100, [7] * 8), (2, 3, 100, [1, 12, 5]), (1, 2, 37, [37, 20]), (3, 2, 1000, [30, 64])])
 def test_device_lsap_matches_scipy(dev, layers, B, Q, sizes):
     from scipy.optimize import linear_sum_assignment
