@@ -458,13 +458,14 @@ class WindowAttention(WindowAttnBase):
         rq, rv = self.ref_qk(x_ref).split(C, dim=-1)       # split, not two slices: its backward is ONE cat (two slices = 2 fills + 2 copies + 1 add)
         rB = rq.shape[0]
         ref_k = ops.row_affine(rq, self.diff_mu, self.diff_logsigma)              # mu + exp(logsigma) * x, (rB, nrf, C), :289-292
-        ra = ops.ref_scores(qkv, ref_k, rB, self.scale)                          # (rB, nWin*N, nrf, heads): pixel-major map, :295-298
+        link = ops.GradLink()                                                     # one packed qkv gradient from the two consumers below
+        ra = ops.ref_scores(qkv, ref_k, rB, self.scale, link)                    # (rB, nWin*N, nrf, heads): pixel-major map, :295-298
         for _ in range(3):                                                        # :299-302
             upd, ra = ops.conv2d(ra, self.ref_attn_diffusion.weight, self.ref_attn_diffusion.bias, pad=1, fanout=True)     # ra again, for the skip
             ra = ops.inorm_gelu_residual(ra, upd, 1e-5)
         q_new = ops.ref_mix(ra, rv, HEADS).view(B_, N, HEADS, hd)      # softmax over the ref tokens, . ref_v; second *scale: in-kernel
         wpi = regions.shape[0] if regions is not None else 1
-        x = ops.window_attention_qkv(q_new, qkv, self.relative_position_bias_table, self.rel_index(), regions, wpi, self.scale)
+        x = ops.window_attention_qkv(q_new, qkv, self.relative_position_bias_table, self.rel_index(), regions, wpi, self.scale, link)
         return self.proj(x)
 
 

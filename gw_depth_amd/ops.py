@@ -488,6 +488,7 @@ class _ConvFn(torch.autograd.Function):
             if z is None:                               # no gradient wanted anywhere: nobody will read it
                 z = y
             ctx.mark_non_differentiable(z)
+            ctx.set_materialize_grads(False)            # or every backward starts with a zero fill the size of z for "its" gradient
             return y, z
         if fanout:
             # second output: x again, for a second consumer of the layer's input (a skip connection).  With it this node is x's only
@@ -499,6 +500,8 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, *g_fan):
         lib = _lib()
+        if gy is None:                                 # (only where materialize_grads is off: a GELU producer nobody consumed)
+            return (None,) * 18
         g_in = g_fan[0].contiguous() if (ctx.fan and g_fan and g_fan[0] is not None) else None
         x, w, row_scale, ref, mult, gate_src = ctx.saved_tensors
         dims, stride, pad, act, act_scale, gather, vv, has_bias, has_res = ctx.cfg
@@ -1349,12 +1352,23 @@ class _WinAttnFn(torch.autograd.Function):
         return gq, gk, gv, gtab, None, None, None, None, None
 
 
+class GradLink:
+    """Hands the packed qkv gradient of window_attention_qkv (k / v slots written) to ref_scores' backward, which writes the q slot and
+    returns the ONE tensor: q feeds ref_scores -> ... -> q_new -> window_attention_qkv, so that backward always runs first.  Without the
+    link each node returns a packed tensor with the other's slots zero-filled and autograd adds the two (2 fills + 1 add per block)."""
+    __slots__ = ("g",)
+
+    def __init__(self):
+        self.g = None
+
+
 class _WinAttnQFn(torch.autograd.Function):
     """Rewritten query q_new (W,49,H,D) against the k / v slots of the packed projection qkv (W,49,3,H,D): the gradient of qkv
     comes back as ONE packed tensor (q slot zero) instead of two zero-filled select-backward temporaries and their sum."""
 
     @staticmethod
-    def forward(ctx, q_new, qkv, table, rel, region, wpi, scale, sink):
+    def forward(ctx, q_new, qkv, table, rel, region, wpi, scale, sink, link=None):
+        ctx.link = link
         q_new, qkv = q_new.contiguous(), qkv.contiguous()
         W, N, H, D = q_new.shape
         out = torch.empty((W, N, H, D), dtype=q_new.dtype, device=q_new.device)
@@ -1373,15 +1387,19 @@ class _WinAttnQFn(torch.autograd.Function):
         go = go.contiguous().view(W, N, H, D)
         gq = torch.empty_like(q_new)
         g = torch.empty_like(qkv)
-        g[:, :, 0].zero_()
+        if ctx.link is None:
+            g[:, :, 0].zero_()
         gtab = _winattn_table_grad(tb, ctx.sink, lambda dtab, hm: _lib().winattn_backward(
             q_new, qkv[:, :, 1], qkv[:, :, 2], go, gq, g[:, :, 1], g[:, :, 2], tb, dtab, region, wpi, scale, rel_index=rel, head_major=hm), rel)
-        return gq, g, gtab, None, None, None, None, None
+        if ctx.link is not None:                       # ref_scores' backward completes and returns it
+            ctx.link.g, g = g, None
+        return gq, g, gtab, None, None, None, None, None, None
 
 
-def window_attention_qkv(q_new, qkv, table, rel, region, windows_per_image, scale):
-    """softmax(scale*q_new k^T + bias (+shift mask)) v with k, v = qkv[:, :, 1], qkv[:, :, 2] (the 1/32 stage)."""
-    return _WinAttnQFn.apply(q_new, qkv, table, rel, region, int(windows_per_image), float(scale), _sink(table))
+def window_attention_qkv(q_new, qkv, table, rel, region, windows_per_image, scale, link=None):
+    """softmax(scale*q_new k^T + bias (+shift mask)) v with k, v = qkv[:, :, 1], qkv[:, :, 2] (the 1/32 stage).  link: the GradLink also given
+    to the ref_scores call q_new descends from."""
+    return _WinAttnQFn.apply(q_new, qkv, table, rel, region, int(windows_per_image), float(scale), _sink(table), link)
 
 
 def window_attention_packed(qkv, table, rel, region, windows_per_image, scale):
@@ -1438,7 +1456,8 @@ class _RefScoresFn(torch.autograd.Function):
     qkv projection (W, 49, 3, H, hd) and its gradient comes back as ONE packed tensor (k and v slots zero)."""
 
     @staticmethod
-    def forward(ctx, qkv, ref_k, B, scale):
+    def forward(ctx, qkv, ref_k, B, scale, link=None):
+        ctx.link = link
         qkv, ref_k = qkv.contiguous(), ref_k.contiguous()
         W, N, _, H, hd = qkv.shape
         R = ref_k.shape[1]
@@ -1452,10 +1471,14 @@ class _RefScoresFn(torch.autograd.Function):
     def backward(ctx, g):
         qkv, ref_k = ctx.saved_tensors
         B, scale = ctx.cfg
-        gqkv = torch.zeros_like(qkv)
+        gqkv = None
+        if ctx.link is not None:
+            gqkv, ctx.link.g = ctx.link.g, None         # k / v slots already hold window_attention_qkv's gradient
+        if gqkv is None:
+            gqkv = torch.zeros_like(qkv)
         dk = torch.empty(ref_k.shape, dtype=torch.float32, device=g.device)
         _lib().ref_scores_backward(qkv[:, :, 0], ref_k, g.contiguous(), gqkv[:, :, 0], dk, B, qkv.shape[0] // B, scale)
-        return gqkv, dk.to(ref_k.dtype), None, None
+        return gqkv, dk.to(ref_k.dtype), None, None, None
 
 
 class _RefMixFn(torch.autograd.Function):
@@ -1481,9 +1504,9 @@ class _RefMixFn(torch.autograd.Function):
         return d_ra, dv.to(ref_v.dtype), None
 
 
-def ref_scores(qkv, ref_k, images, scale):
+def ref_scores(qkv, ref_k, images, scale, link=None):
     """qkv (images*nwin, 49, 3, H, hd) packed projection, ref_k (images, R, H*hd) -> (images, nwin*49, R, H)."""
-    return _RefScoresFn.apply(qkv, ref_k, int(images), float(scale))
+    return _RefScoresFn.apply(qkv, ref_k, int(images), float(scale), link)
 
 
 def ref_mix(ra, ref_v, heads):

@@ -399,6 +399,37 @@ def test_token_attention(dev, e, nwin, dtype):
     assert rel(o, o_r) < TOL[dtype] and rel(gq, gq_r) < TOL[dtype] and rel(gkv, gkv_r) < TOL[dtype]
 
 
+def test_packed_qkv_gradient_link_of_the_1_32_stage(dev, monkeypatch):
+    """ops.GradLink: window_attention_qkv's backward hands its packed gradient (k / v slots) to ref_scores' backward, which writes the q slot -
+    same gradients as the two zero-filled tensors autograd used to add."""
+    from gw_depth_amd import model as M, ops
+    torch.manual_seed(0)
+    att = M.WindowAttention(512).cuda()
+    for p in att.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    xw = (torch.randn(18, 49, 512, device="cuda") * 0.5).bfloat16().requires_grad_(True)        # 2 images x 9 windows
+    x_ref = (torch.randn(2, 40, 512, device="cuda") * 0.5).bfloat16().requires_grad_(True)
+    wgt = torch.randn(18, 49, 512, device="cuda")
+    ps = [p for p in att.parameters() if p.requires_grad]
+
+    def run():
+        y = att(xw, x_ref, None)
+        return y, torch.autograd.grad((y.float() * wgt).sum(), [xw, x_ref] + ps, allow_unused=True)
+
+    y1, g_link = run()
+    monkeypatch.setattr(ops, "GradLink", lambda: None)
+    y2, g_two = run()
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2)
+    n = 0
+    for a, b in zip(g_link, g_two):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.isfinite(a).all() and rel(a, b) < 1e-3
+            n += 1
+    assert n >= 6
+
+
 @pytest.mark.parametrize("e,nwin", [(12, 40), (16, 9), (24, 3), (12, 3000), (16, 1)])
 def test_token_attention_pair_is_two_single_calls(dev, e, nwin):
     """Both class tokens in one launch (gwd_tokattn_pair_*): outputs and query gradients per token, k / v gradients summed."""
