@@ -683,3 +683,59 @@ extern "C" int gwd_stride_place(const void *src, const void *residual, void *dst
     GWD_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 convolution over a 2x nearest-upsampled map == 4x4 / stride 2 / pad 1 taps on the low-resolution side (ops._upsampled_dgrad_weight:
+// the 2 x 2 children of a low-res pixel commute into the taps).  Two tiny layout kernels, one launch each instead of ~8 element-wise ones:
+//   collapse: w (Cout,3,3,Cin) fp32 -> wk (Cin,4,4,Cout), wk[ci][t][s][co] = sum_{kh in G(t), kw in G(s)} w[co][kh][kw][ci], G(t) = [max(0, 2-t), min(2, 3-t)]
+//   fold:     D (Cin,4,4,Cout) fp32 -> dw (Cout,3,3,Cin) += sum_{t in T(kh), s in T(kw)} D[ci][t][s][co],                   T(k) = [2-k, 3-k]
+namespace {
+
+template <typename T>
+__global__ void ups_taps_collapse_kernel(const float *__restrict__ w, T *__restrict__ wk, int Cout, int Cin) {
+    const int total = Cin * 16 * Cout;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int co = i % Cout, ts = (i / Cout) & 15, ci = i / (16 * Cout);
+        const int t = ts >> 2, s = ts & 3;
+        float acc = 0.f;
+        for (int kh = max(0, 2 - t); kh <= min(2, 3 - t); ++kh)
+            for (int kw = max(0, 2 - s); kw <= min(2, 3 - s); ++kw) acc += w[((size_t)(co * 3 + kh) * 3 + kw) * Cin + ci];
+        wk[i] = from_f32<T>(acc);
+    }
+}
+
+__global__ void ups_taps_fold_kernel(const float *__restrict__ D, float *__restrict__ dw, int Cout, int Cin) {
+    const int total = Cout * 9 * Cin;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ci = i % Cin, k = (i / Cin) % 9, co = i / (9 * Cin);
+        const int kh = k / 3, kw = k - 3 * kh;
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) acc += D[((size_t)(ci * 4 + 2 - kh + t) * 4 + 2 - kw + s) * Cout + co];
+        dw[i] += acc;
+    }
+}
+
+}  // namespace
+
+extern "C" int gwd_upsample_taps_collapse(const float *w, void *wk, int32_t Cout, int32_t Cin, int32_t dtype, void *stream) {
+    if (!w || !wk || Cout <= 0 || Cin <= 0 || (int64_t)Cout * Cin * 16 > INT32_MAX) return -1;
+    const int64_t total = (int64_t)Cin * 16 * Cout;
+    if (dtype == GWD_BF16)
+        ups_taps_collapse_kernel<__bf16><<<flat_grid(total), 256, 0, (hipStream_t)stream>>>(w, (__bf16 *)wk, Cout, Cin);
+    else if (dtype == GWD_F32)
+        ups_taps_collapse_kernel<float><<<flat_grid(total), 256, 0, (hipStream_t)stream>>>(w, (float *)wk, Cout, Cin);
+    else
+        return -2;
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gwd_upsample_taps_fold(const float *D, float *dw, int32_t Cout, int32_t Cin, void *stream) {
+    if (!D || !dw || Cout <= 0 || Cin <= 0 || (int64_t)Cout * Cin * 16 > INT32_MAX) return -1;
+    ups_taps_fold_kernel<<<flat_grid((int64_t)Cout * 9 * Cin), 256, 0, (hipStream_t)stream>>>(D, dw, Cout, Cin);
+    GWD_CHECK_LAUNCH();
+    return 0;
+}

@@ -25,7 +25,7 @@ ENTRY_POINTS = [
     "gwd_softmax_backward", "gwd_silog_sums", "gwd_silog_backward", "gwd_seg_ce_sum", "gwd_seg_ce_backward",
     "gwd_sqnorm", "gwd_adamw_step", "gwd_resample_forward", "gwd_resample_backward", "gwd_avgpool_forward",
     "gwd_avgpool_backward", "gwd_winattn_forward", "gwd_winattn_backward", "gwd_tokattn_forward",
-    "gwd_tokattn_backward", "gwd_tokattn_pair_forward", "gwd_tokattn_pair_backward", "gwd_certain_sample", "gwd_lsap", "gwd_window_map", "gwd_window_map_multi",
+    "gwd_tokattn_backward", "gwd_tokattn_pair_forward", "gwd_tokattn_pair_backward", "gwd_upsample_taps_collapse", "gwd_upsample_taps_fold", "gwd_certain_sample", "gwd_lsap", "gwd_window_map", "gwd_window_map_multi",
     "gwd_inorm_gelu_forward", "gwd_inorm_gelu_backward", "gwd_weight_prep_batch",
     "gwd_point_sample_forward", "gwd_point_sample_backward", "gwd_act_backward_colsum", "gwd_resample_backward_sep",
     "gwd_softmax_masked_forward", "gwd_softmax_scaled_backward", "gwd_query_workspace", "gwd_eval_accumulate", "gwd_colsum_batch", "gwd_conv_wgrad_batch",
@@ -209,6 +209,8 @@ class HipLibrary:
         L.gwd_ref_mix_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_tokattn_forward.argtypes = [sp] * 4 + [i64, i32, i32, f32, i32, vp]
         L.gwd_tokattn_backward.argtypes = [sp] * 7 + [i64, i32, i32, f32, i32, vp]
+        L.gwd_upsample_taps_collapse.argtypes = [vp, vp, i32, i32, i32, vp]
+        L.gwd_upsample_taps_fold.argtypes = [vp, vp, i32, i32, vp]
         L.gwd_tokattn_pair_forward.argtypes = [sp] * 6 + [i64, i32, i32, f32, i32, vp]
         L.gwd_tokattn_pair_backward.argtypes = [sp] * 10 + [i64, i32, i32, f32, i32, vp]
         L.gwd_certain_sample.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp]
@@ -635,6 +637,21 @@ class HipLibrary:
         s = [_strided(t) for t in (q, k, v, go, gq, gk, gv)]
         self._check(self.lib.gwd_tokattn_backward(*[ctypes.byref(x) for x in s], W, H, k.shape[3], scale, dtype_code(q),
                                                   self._stream(q, go, gq)), "gwd_tokattn_backward")
+
+    def upsample_taps_collapse(self, w, wk):
+        """w (Cout,3,3,Cin) fp32 -> wk (Cin,4,4,Cout): the 4x4 / stride-2 taps of a 3x3 convolution over a 2x nearest-upsampled map."""
+        Cout, KH, KW, Cin = w.shape
+        if (KH, KW) != (3, 3) or tuple(wk.shape) != (Cin, 4, 4, Cout) or w.dtype != torch.float32 or not (w.is_contiguous() and wk.is_contiguous()):
+            raise ValueError("upsample_taps_collapse: w (Cout,3,3,Cin) fp32 -> wk (Cin,4,4,Cout), both contiguous")
+        self._check(self.lib.gwd_upsample_taps_collapse(_ptr(w), _ptr(wk), Cout, Cin, dtype_code(wk), self._stream(w, wk)), "gwd_upsample_taps_collapse")
+
+    def upsample_taps_fold(self, D, dw):
+        """dw (Cout,3,3,Cin) fp32 += the 4x4-form weight gradient D (Cin,4,4,Cout) fp32 folded back onto the nine taps."""
+        Cout, KH, KW, Cin = dw.shape
+        if (KH, KW) != (3, 3) or tuple(D.shape) != (Cin, 4, 4, Cout) or D.dtype != torch.float32 or dw.dtype != torch.float32 \
+                or not (D.is_contiguous() and dw.is_contiguous()):
+            raise ValueError("upsample_taps_fold: D (Cin,4,4,Cout) fp32 -> dw (Cout,3,3,Cin) fp32, both contiguous")
+        self._check(self.lib.gwd_upsample_taps_fold(_ptr(D), _ptr(dw), Cout, Cin, self._stream(D, dw)), "gwd_upsample_taps_fold")
 
     def tokattn_pair_forward(self, q, q2, k, v, o, o2, scale):
         """Both class tokens against the same k / v in one launch (bf16): q, q2 -> o, o2."""

@@ -282,11 +282,10 @@ def _upsampled_dgrad_weight(w, dtype):
     - 16 taps per low-res pixel = 4 per high-res one instead of 9, and no high-resolution gradient map in memory (the transposed
     gather wrote it, 314 MB for the last decoder stage, and the footprint sum read it back).  w (Cout, 3, 3, Cin) fp32 master ->
     (Cin, 4, 4, Cout) in `dtype`: the weight operand of gwd_conv_forward with x = gy."""
-    # element-wise sums only: an einsum here becomes a library batched GEMM, which cannot be issued inside a HIP-graph capture
-    wp = w.detach().float().permute(3, 1, 2, 0)                                             # (Cin, kh, kw, Cout)
-    r = torch.stack([wp[:, 2], wp[:, 1] + wp[:, 2], wp[:, 0] + wp[:, 1], wp[:, 0]], dim=1)       # (Cin, 4, kw, Cout)
-    wk = torch.stack([r[:, :, 2], r[:, :, 1] + r[:, :, 2], r[:, :, 0] + r[:, :, 1], r[:, :, 0]], dim=2)
-    return wk.to(dtype).contiguous()
+    Cout, _, _, Cin = w.shape
+    wk = torch.empty((Cin, 4, 4, Cout), dtype=dtype, device=w.device)
+    _lib().upsample_taps_collapse(w.detach().float().contiguous(), wk)       # one launch (was ~8 element-wise ones; an einsum would be a library GEMM)
+    return wk
 
 
 
@@ -592,9 +591,7 @@ class _ConvFn(torch.autograd.Function):
                 D = WGRADS.scratch((Cin, 4, 4, Cout), x.device)
 
                 def fold(D=D, sink=w_sink, shape=(Cout, KH, KW, Cin)):
-                    r = torch.stack([D[:, 2] + D[:, 3], D[:, 1] + D[:, 2], D[:, 0] + D[:, 1]], dim=1)
-                    q = torch.stack([r[:, :, 2] + r[:, :, 3], r[:, :, 1] + r[:, :, 2], r[:, :, 0] + r[:, :, 1]], dim=2)
-                    sink[0].view(shape).add_(q.permute(3, 1, 2, 0))
+                    lib.upsample_taps_fold(D, sink[0].view(shape))
                     if sink[1] is not None:
                         sink[1]()
 

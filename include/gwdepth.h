@@ -261,6 +261,16 @@ int gwd_tokattn_backward(const gwd_strided *q, const gwd_strided *k, const gwd_s
                          const gwd_strided *gq, const gwd_strided *gk, const gwd_strided *gv, int64_t n_windows,
                          int32_t heads, int32_t e, float scale, int32_t dtype, void *stream);
 
+/* A 3x3 convolution over a 2x nearest-upsampled map (src/models/dense_upsample.py:150-181, F.interpolate + Conv2d) seen from its
+ * low-resolution input is a 4x4 / stride 2 / pad 1 convolution: the data gradient and the weight gradient run in that form on
+ * gwd_conv_forward / gwd_conv_wgrad_batch, 16 taps per low-res pixel instead of 36.  These two are its tap bookkeeping:
+ * collapse: w (Cout,3,3,Cin) fp32 -> wk (Cin,4,4,Cout) in `dtype`, wk[ci][t][s][co] = sum_{kh in G(t), kw in G(s)} w[co][kh][kw][ci],
+ *           G(0) = {2}, G(1) = {1,2}, G(2) = {0,1}, G(3) = {0};
+ * fold:     D (Cin,4,4,Cout) fp32 (the weight gradient of the 4x4 form) -> dw (Cout,3,3,Cin) fp32 += sum_{t in T(kh), s in T(kw)} D[ci][t][s][co],
+ *           T(0) = {2,3}, T(1) = {1,2}, T(2) = {0,1}.                                                                              */
+int gwd_upsample_taps_collapse(const float *w, void *wk, int32_t Cout, int32_t Cin, int32_t dtype, void *stream);
+int gwd_upsample_taps_fold(const float *D, float *dw, int32_t Cout, int32_t Cin, void *stream);
+
 /* Both class tokens of a WindowClassAttention block in ONE launch (multiscale_transformerr.py:561-578: the depth token and the
  * segmentation token query the same global_k / global_v).  The softmax is per query channel, so the pair is one problem with 8
  * query channels: k / v are staged once and the backward's gk / gv are the SUM over both tokens (what autograd adds up after two

@@ -644,6 +644,16 @@ class FakeDevice:
         gk.copy_(g[1])
         gv.copy_(g[2])
 
+    def upsample_taps_collapse(self, w, wk):
+        wp = w.detach().float().permute(3, 1, 2, 0)                                             # (Cin, kh, kw, Cout)
+        r = torch.stack([wp[:, 2], wp[:, 1] + wp[:, 2], wp[:, 0] + wp[:, 1], wp[:, 0]], dim=1)
+        wk.copy_(torch.stack([r[:, :, 2], r[:, :, 1] + r[:, :, 2], r[:, :, 0] + r[:, :, 1], r[:, :, 0]], dim=2))
+
+    def upsample_taps_fold(self, D, dw):
+        r = torch.stack([D[:, 2] + D[:, 3], D[:, 1] + D[:, 2], D[:, 0] + D[:, 1]], dim=1)
+        q = torch.stack([r[:, :, 2] + r[:, :, 3], r[:, :, 1] + r[:, :, 2], r[:, :, 0] + r[:, :, 1]], dim=2)
+        dw.add_(q.permute(3, 1, 2, 0))
+
     def tokattn_pair_forward(self, q, q2, k, v, o, o2, scale):
         self.tokattn_forward(q, k, v, o, scale)
         self.tokattn_forward(q2, k, v, o2, scale)

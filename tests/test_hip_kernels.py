@@ -399,6 +399,29 @@ def test_token_attention(dev, e, nwin, dtype):
     assert rel(o, o_r) < TOL[dtype] and rel(gq, gq_r) < TOL[dtype] and rel(gkv, gkv_r) < TOL[dtype]
 
 
+@pytest.mark.parametrize("Cout,Cin", [(64, 64), (32, 64), (160, 96), (1, 3)])
+def test_upsample_taps_collapse_and_fold(dev, Cout, Cin):
+    """gwd_upsample_taps_collapse / _fold against the element-wise formulas (3x3 over a 2x nearest-upsampled map == 4x4 / stride 2 taps)."""
+    fake = FakeDevice()
+    w = rnd(Cout, 3, 3, Cin, seed=1)
+    for dtype in (torch.float32, torch.bfloat16):
+        wk_r = torch.empty(Cin, 4, 4, Cout)
+        fake.upsample_taps_collapse(w, wk_r)
+        wk = torch.full((Cin, 4, 4, Cout), float("nan"), dtype=dtype, device="cuda")
+        dev.upsample_taps_collapse(w.cuda(), wk)
+        torch.cuda.synchronize()
+        assert rel(wk, wk_r.to(dtype)) < (1e-6 if dtype == torch.float32 else 4e-3)
+    D, dw0 = rnd(Cin, 4, 4, Cout, seed=2), rnd(Cout, 3, 3, Cin, seed=3)
+    dw_r = dw0.clone()
+    fake.upsample_taps_fold(D, dw_r)
+    dw = dw0.clone().cuda()
+    dev.upsample_taps_fold(D.cuda(), dw)
+    torch.cuda.synchronize()
+    assert rel(dw, dw_r) < 1e-6
+    with pytest.raises(ValueError):
+        dev.upsample_taps_fold(D.cuda(), dw0.cuda().permute(0, 2, 1, 3))
+
+
 def test_packed_qkv_gradient_link_of_the_1_32_stage(dev, monkeypatch):
     """ops.GradLink: window_attention_qkv's backward hands its packed gradient (k / v slots) to ref_scores' backward, which writes the q slot -
     same gradients as the two zero-filled tensors autograd used to add."""
