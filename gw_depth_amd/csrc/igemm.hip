@@ -1475,14 +1475,23 @@ __global__ __launch_bounds__(256) void igemm_wgrad_group_kernel(const WgradGroup
 // igemm_wgrad_dma_kernel<160,128> stages 18 KB per 32-pixel step for 40 MFMAs (4 waves x 10) - 450 bytes of LDS-DMA fill per MFMA,
 // every input pixel's channels fetched once per tap by different workgroups - and runs at ~6 TB/s of fill = 21 % of the MFMA peak
 // (DESIGN.md section 4).  Here a workgroup owns ONE 32-channel slice of the input for ALL nine taps and a 160-wide slice of the
-// outputs: nine waves, wave = filter tap, 5 accumulator tiles (160 x 32) each.  A step is 32 consecutive pixels of one image row:
+// outputs: 45 accumulator tiles (9 taps x five 32-column tiles) over nine or fifteen waves (layout note below).  A step is 32 consecutive pixels of one image row:
 // their dY rows [32][160] (10 KB) and ONE halo patch of x - rows oh-1 .. oh+1, columns ow0-1 .. ow0+32, 32 channels: 102 x 64 B -
 // land in LDS once; tap (kh, kw) reads its 32 pixels at image row kh * 34 + kw of the patch.  16.5 KB per 90 MFMAs = 183 B / MFMA.
 // Both operands are needed pixel-major (the reduction runs over pixels): ds_read_b64_tr_b16, as in wgrad_dma_body; pitches of 320 B
-// and 64 B put the four rows of a transposed read 16 banks apart - conflict free without a swizzle.  One workgroup per CU (nine
-// waves hold 80 accumulator registers each), a ring of WT_STAGES steps in dynamic LDS, counted vmcnt + one barrier per step.
+// and 64 B put the four rows of a transposed read 16 banks apart - conflict free without a swizzle.  One workgroup per CU (80 or 48
+// accumulator registers per wave), a ring of WT_STAGES steps in dynamic LDS, counted vmcnt + one barrier per step.
 // The reduction over pixels is split over workgroups (tiles x splits ~ one per CU), fp32 atomics into the flat gradient.
 constexpr int WT_STAGES = 8, WT_YB = 10240, WT_XB = 7168, WT_STAGE = WT_YB + WT_XB;
+// Wave layout.  9: wave = tap, its five 32-column tiles (1 x fragment + 5 dY fragments per 5 MFMAs) - nine waves sit 3-2-2-2 on the four SIMDs.
+// 15: wave = (kh, column tile), its three kw taps (3 x fragments at patch offsets kw + 1 dY fragment per 3 MFMAs) - 4-4-4-3.
+// Same box, 9 / 15 (tools/convbench.py): 160 -> 160 0.130-0.133 / 0.126-0.131 ms, 800 -> 320 0.834 / 0.806, 320 -> 320 0.338 / 0.328-0.342; whole step
+// 31.35 31.29 / 31.23 31.23 ms.  The small gain says the step is not bound by the busiest SIMD's MFMA stream (DMA fill + barrier: section 4b).
+#ifndef GWD_WT_WAVES
+#define GWD_WT_WAVES 15
+#endif
+constexpr int WT_W = GWD_WT_WAVES, WT_NX = WT_W == 9 ? 1 : 3, WT_NY = WT_W == 9 ? 5 : 1, WT_ACC = WT_NX * WT_NY;
+static_assert(WT_W == 9 || WT_W == 15, "wgrad_taps wave layout");
 // NB the body is a function of its own with a __restrict__ parameter ON PURPOSE: inlining it gives every memory access of the body
 // alias-scope metadata, and only with that does the compiler's wait-count pass accept that the transposed LDS reads do not alias the
 // LDS-DMA writes still in flight.  Without it an `s_waitcnt vmcnt(0)` lands in front of the first ds_read_b64_tr_b16 of every step and
@@ -1491,7 +1500,7 @@ constexpr int WT_STAGES = 8, WT_YB = 10240, WT_XB = 7168, WT_STAGE = WT_YB + WT_
 __device__ __forceinline__ void wgrad_taps_body(const gwd_conv_desc &d, float *__restrict__ dw, char *wt_smem, const int chunks_per_split, const int wg_count) {
     typedef __bf16 T;
     const int N = d.Cout, Cin = d.Cin, H = d.Ho, W = d.Wo, K = 9 * Cin;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;          // wave = tap
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;          // WT_W waves: see the layout note above
     const int tiles_c = (Cin + 31) / 32, tiles = tiles_c * (N / 160);
     const int band = xcd_band((int)blockIdx.x, wg_count);                // the tiles of one pixel range are neighbours on one XCD
     const int tile = band % tiles, split = band / tiles;
@@ -1514,7 +1523,7 @@ __device__ __forceinline__ void wgrad_taps_body(const gwd_conv_desc &d, float *_
     bool is_y[2], l_ok[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int j = wave + 9 * i;
+        const int j = wave + WT_W * i;
         is_y[i] = j < 10;
         const int q = (is_y[i] ? j : j - 10) * 64 + lane;
         if (is_y[i]) {
@@ -1531,7 +1540,7 @@ __device__ __forceinline__ void wgrad_taps_body(const gwd_conv_desc &d, float *_
             l_ok[i] = q < 408 && co < Cin;
         }
     }
-    const int my_loads = wave < 8 ? 2 : 1;
+    const int my_loads = wave + WT_W < 17 ? 2 : 1;
     int issued = 0;
     // coordinates of the next step to request (workgroup-uniform -> scalar registers)
     int n_b = __builtin_amdgcn_readfirstlane(s0 / (H * cpr));
@@ -1545,7 +1554,7 @@ __device__ __forceinline__ void wgrad_taps_body(const gwd_conv_desc &d, float *_
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (i >= my_loads) break;                                     // wave-uniform
-            const int j = wave + 9 * i;
+            const int j = wave + WT_W * i;
             const int ih = n_oh + l_dh[i], iw = n_ow + l_dw[i];
             const bool ok = l_ok[i] & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
             const char *src = ok ? (const char *)((is_y[i] ? y_row : x_row) + l_off[i]) : zero;
@@ -1563,30 +1572,33 @@ __device__ __forceinline__ void wgrad_taps_body(const gwd_conv_desc &d, float *_
         }
     };
 
-    f32x16 acc[5];
+    f32x16 acc[WT_ACC];
 #pragma unroll
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < WT_ACC; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     const int g = lane >> 4, t = lane & 15;
-    const int kh = wave / 3, kw = wave - kh * 3;
+    const int kh = WT_W == 9 ? wave / 3 : wave / 5, kw = WT_W == 9 ? wave - kh * 3 : 0, ct = WT_W == 9 ? 0 : wave - kh * 5;
     const int r_lo = 8 * (g >> 1) + (t >> 2), cw = 16 * (g & 1) + 4 * (t & 3);
-    const int x_base = ((kh * 34 + kw + r_lo) * 64) + cw * 2;             // byte offset of this lane's first transposed read in the patch
-    const int y_base = r_lo * 320 + cw * 2;
+    const int x_base = ((kh * 34 + kw + r_lo) * 64) + cw * 2;             // byte offset of this lane's first transposed read in the patch (tap kw + xi: + xi * 64)
+    const int y_base = r_lo * 320 + cw * 2 + ct * 64;
 
     // Software pipeline over the two 16-pixel halves of a step: while the MFMAs of one half run, the transposed reads of the next
     // half (the second half of this step, or the first half of the NEXT step) are in flight - with 2-3 waves per SIMD nothing else
     // covers the ds_read -> MFMA latency.  The barrier that certifies step s + 1 therefore sits in the MIDDLE of iteration s; the
     // ring slot refilled behind it is the one of step s - 1, whose reads every wave finished before it got here.
     typedef union { s16x4 h[2]; bf16x8 v; } Frag;
-    auto read_half = [&](int slot, int ks, Frag &bx, Frag (&ay)[5]) {
+    auto read_half = [&](int slot, int ks, Frag (&bx)[WT_NX], Frag (&ay)[WT_NY]) {
         const char *Yb = wt_smem + slot * WT_STAGE;
         const char *Xb = Yb + WT_YB;
-        bx.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(Xb + x_base + ks * 16 * 64));
-        bx.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(Xb + x_base + (ks * 16 + 4) * 64));
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < WT_NX; ++i) {
+            bx[i].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(Xb + x_base + i * 64 + ks * 16 * 64));
+            bx[i].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(Xb + x_base + i * 64 + (ks * 16 + 4) * 64));
+        }
+#pragma unroll
+        for (int i = 0; i < WT_NY; ++i) {
             ay[i].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(Yb + y_base + ks * 16 * 320 + i * 64));
             ay[i].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(Yb + y_base + (ks * 16 + 4) * 320 + i * 64));
         }
@@ -1604,20 +1616,20 @@ __device__ __forceinline__ void wgrad_taps_body(const gwd_conv_desc &d, float *_
         if (s < steps) issue(s);
     certify(0);
     if (WT_STAGES - 2 < steps) issue(WT_STAGES - 2);
-    Frag bx0, ay0[5], bx1, ay1[5];
+    Frag bx0[WT_NX], ay0[WT_NY], bx1[WT_NX], ay1[WT_NY];
     read_half(0, 0, bx0, ay0);
 #pragma unroll 1
     for (int s = 0; s < steps; ++s) {
         read_half(s % WT_STAGES, 1, bx1, ay1);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) acc[i] = mma(ay0[i].v, bx0.v, acc[i]);
+        for (int i = 0; i < WT_ACC; ++i) acc[i] = mma(ay0[i % WT_NY].v, bx0[i / WT_NY].v, acc[i]);
         if (s + 1 < steps) {
             certify(s + 1);
             if (s + WT_STAGES - 1 < steps) issue((s + WT_STAGES - 1) % WT_STAGES);
             read_half((s + 1) % WT_STAGES, 0, bx0, ay0);
         }
 #pragma unroll
-        for (int i = 0; i < 5; ++i) acc[i] = mma(ay1[i].v, bx1.v, acc[i]);
+        for (int i = 0; i < WT_ACC; ++i) acc[i] = mma(ay1[i % WT_NY].v, bx1[i / WT_NY].v, acc[i]);
     }
 
     // ---- flush: D[row = n][col = c]; one register of a tile = two 128-byte row segments per wave instruction (full atomic rate)
@@ -1625,22 +1637,23 @@ __device__ __forceinline__ void wgrad_taps_body(const gwd_conv_desc &d, float *_
     const int c = c0 + fr;
     if (d.scale) {                                                        // before the first atomic: see wgrad_dma_body
 #pragma unroll
-        for (int i = 0; i < 5; ++i)
+        for (int i = 0; i < WT_ACC; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] *= d.scale[n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh];
+            for (int r = 0; r < 16; ++r) acc[i][r] *= d.scale[n0 + (ct + i % WT_NY) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh];
     }
     if (c < Cin) {
-        const size_t kcol = (size_t)wave * Cin + c;
 #pragma unroll
-        for (int i = 0; i < 5; ++i)
+        for (int i = 0; i < WT_ACC; ++i) {
+            const size_t kcol = (size_t)(kh * 3 + kw + i / WT_NY) * Cin + c;          // accumulator i: tap kw + i / NY, column tile ct + i % NY
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int n = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int n = n0 + (ct + i % WT_NY) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 unsafeAtomicAdd(dw + (size_t)n * K + kcol, acc[i][r]);
             }
+        }
     }
 }
-__global__ __launch_bounds__(576) void wgrad_taps_kernel(const gwd_conv_desc d, float *__restrict__ dw, const int chunks_per_split, const int wg_count) {
+__global__ __launch_bounds__(64 * WT_W) void wgrad_taps_kernel(const gwd_conv_desc d, float *__restrict__ dw, const int chunks_per_split, const int wg_count) {
     extern __shared__ __attribute__((aligned(1024))) char wt_dyn_smem[];
     wgrad_taps_body(d, dw, wt_dyn_smem, chunks_per_split, wg_count);
 }
@@ -2301,7 +2314,7 @@ static int launch_wgrad_taps(const gwd_conv_desc *d, float *dw, hipStream_t s) {
     if (cps < 8) cps = 8;
     splits = (total + cps - 1) / cps;
     const int wgs = tiles * splits;
-    wgrad_taps_kernel<<<wgs, 576, LDS, s>>>(*d, dw, cps, wgs);
+    wgrad_taps_kernel<<<wgs, 64 * WT_W, LDS, s>>>(*d, dw, cps, wgs);
     return 1;
 }
 
