@@ -11,20 +11,38 @@ namespace {
 
 __device__ __forceinline__ float unnormalize(float coord, int size) { return ((coord + 1.f) * size - 1.f) / 2.f; }
 
+// Nearest sampling of the map as torch.roll(F.pad(map, to (Hf, Wf)), (-shift, -shift)) would present it (the shifted-window frame of the 1/32
+// stage, multiscale_transformerr.py:662-691) without building that tensor: the coordinates address the (Hf, Wf) frame, frame pixel (y, x) is map
+// pixel ((y + shift) mod Hf, (x + shift) mod Wf), zero where that lies in the padding.  Hf = 0: no frame.
+struct Frame {
+    int Hf, Wf, shift;
+};
+// frame pixel -> map pixel; false: outside the frame or in its padding
+__device__ __forceinline__ bool frame_pixel(const Frame &f, int H, int W, int &xn, int &yn) {
+    if (f.Hf > 0) {
+        if (xn < 0 || xn >= f.Wf || yn < 0 || yn >= f.Hf) return false;
+        xn += f.shift;
+        yn += f.shift;
+        xn -= xn >= f.Wf ? f.Wf : 0;
+        yn -= yn >= f.Hf ? f.Hf : 0;
+    }
+    return xn >= 0 && xn < W && yn >= 0 && yn < H;
+}
+
 template <typename T>
 __global__ void point_sample_fwd_kernel(const T *__restrict__ map, const float *__restrict__ coords, float *__restrict__ out,
-                                        int B, int H, int W, int C, int S, int mode) {
+                                        int B, int H, int W, int C, int S, int mode, Frame fr) {
     const int64_t total = (int64_t)B * S * C;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const int64_t bs = i / C;
         const int b = (int)(bs / S);
-        const float ix = unnormalize(coords[bs * 2], W), iy = unnormalize(coords[bs * 2 + 1], H);
+        const float ix = unnormalize(coords[bs * 2], fr.Hf > 0 ? fr.Wf : W), iy = unnormalize(coords[bs * 2 + 1], fr.Hf > 0 ? fr.Hf : H);
         const T *img = map + (int64_t)b * H * W * C + c;
         float r = 0.f;
         if (mode == 1) {
-            const int xn = (int)nearbyintf(ix), yn = (int)nearbyintf(iy);
-            if (xn >= 0 && xn < W && yn >= 0 && yn < H) r = to_f32(img[((int64_t)yn * W + xn) * C]);
+            int xn = (int)nearbyintf(ix), yn = (int)nearbyintf(iy);
+            if (frame_pixel(fr, H, W, xn, yn)) r = to_f32(img[((int64_t)yn * W + xn) * C]);
         } else {
             const float fx = floorf(ix), fy = floorf(iy);
             const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
@@ -77,17 +95,19 @@ __global__ void point_sample_bwd_kernel(const float *__restrict__ gout, const fl
 // the 1/32 stage, where the scatter form has only B x C = 4 096 threads).
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void point_sample_bwd_gather_kernel(const float *__restrict__ gout, const float *__restrict__ coords,
-                                                                      T *__restrict__ gmap, int H, int W, int C, int S, int mode) {
+                                                                      T *__restrict__ gmap, int H, int W, int C, int S, int mode, Frame fr) {
     constexpr int SMAX = 256;                    // VEC = 16 bytes of channels per thread, or 1 channel (any C: the 1-channel depth maps)
     __shared__ int px[SMAX], py[SMAX];
     __shared__ float wgt[SMAX][4];
     const int b = blockIdx.y, tid = threadIdx.x;
     for (int s = tid; s < S; s += 256) {
         const int64_t bs = (int64_t)b * S + s;
-        const float ix = unnormalize(coords[bs * 2], W), iy = unnormalize(coords[bs * 2 + 1], H);
+        const float ix = unnormalize(coords[bs * 2], fr.Hf > 0 ? fr.Wf : W), iy = unnormalize(coords[bs * 2 + 1], fr.Hf > 0 ? fr.Hf : H);
         if (mode == 1) {
-            px[s] = (int)nearbyintf(ix);
-            py[s] = (int)nearbyintf(iy);
+            int xn = (int)nearbyintf(ix), yn = (int)nearbyintf(iy);
+            if (fr.Hf > 0 && !frame_pixel(fr, H, W, xn, yn)) xn = yn = -(1 << 20);       // meets no pixel
+            px[s] = xn;
+            py[s] = yn;
             wgt[s][0] = 1.f;
             wgt[s][1] = wgt[s][2] = wgt[s][3] = 0.f;
         } else {
@@ -139,8 +159,8 @@ __global__ __launch_bounds__(256) void point_sample_bwd_gather_kernel(const floa
 
 }  // namespace
 
-extern "C" int gwd_point_sample_backward_gather(const float *gout, const float *coords, void *gmap, int32_t B, int32_t H, int32_t W,
-                                                int32_t C, int32_t S, int32_t mode, int32_t dtype, void *stream) {
+static int point_sample_backward_gather(const float *gout, const float *coords, void *gmap, int32_t B, int32_t H, int32_t W,
+                                        int32_t C, int32_t S, int32_t mode, int32_t dtype, void *stream, Frame fr) {
     if (!gout || !coords || !gmap || B <= 0 || H <= 0 || W <= 0 || C <= 0 || S <= 0 || (mode != 0 && mode != 1)) return -1;
     int vec = dtype == GWD_BF16 ? 8 : (dtype == GWD_F32 ? 4 : 0);
     if (!vec) return -2;
@@ -151,28 +171,51 @@ extern "C" int gwd_point_sample_backward_gather(const float *gout, const float *
     dim3 grid((unsigned)((per + 255) / 256), (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == GWD_BF16) {
-        if (vec == 1) point_sample_bwd_gather_kernel<__bf16, 1><<<grid, 256, 0, st>>>(gout, coords, (__bf16 *)gmap, H, W, C, S, mode);
-        else point_sample_bwd_gather_kernel<__bf16, 8><<<grid, 256, 0, st>>>(gout, coords, (__bf16 *)gmap, H, W, C, S, mode);
+        if (vec == 1) point_sample_bwd_gather_kernel<__bf16, 1><<<grid, 256, 0, st>>>(gout, coords, (__bf16 *)gmap, H, W, C, S, mode, fr);
+        else point_sample_bwd_gather_kernel<__bf16, 8><<<grid, 256, 0, st>>>(gout, coords, (__bf16 *)gmap, H, W, C, S, mode, fr);
     } else {
-        if (vec == 1) point_sample_bwd_gather_kernel<float, 1><<<grid, 256, 0, st>>>(gout, coords, (float *)gmap, H, W, C, S, mode);
-        else point_sample_bwd_gather_kernel<float, 4><<<grid, 256, 0, st>>>(gout, coords, (float *)gmap, H, W, C, S, mode);
+        if (vec == 1) point_sample_bwd_gather_kernel<float, 1><<<grid, 256, 0, st>>>(gout, coords, (float *)gmap, H, W, C, S, mode, fr);
+        else point_sample_bwd_gather_kernel<float, 4><<<grid, 256, 0, st>>>(gout, coords, (float *)gmap, H, W, C, S, mode, fr);
     }
+    GWD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gwd_point_sample_backward_gather(const float *gout, const float *coords, void *gmap, int32_t B, int32_t H, int32_t W,
+                                                int32_t C, int32_t S, int32_t mode, int32_t dtype, void *stream) {
+    return point_sample_backward_gather(gout, coords, gmap, B, H, W, C, S, mode, dtype, stream, Frame{0, 0, 0});
+}
+
+static int point_sample_forward(const void *map, const float *coords, float *out, int32_t B, int32_t H, int32_t W,
+                                int32_t C, int32_t S, int32_t mode, int32_t dtype, void *stream, Frame fr) {
+    if (!map || !coords || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || S <= 0 || (mode != 0 && mode != 1)) return -1;
+    const int64_t total = (int64_t)B * S * C;
+    int64_t nb = (total + 255) / 256;
+    const int grid = (int)(nb > 4096 ? 4096 : nb);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GWD_BF16) point_sample_fwd_kernel<__bf16><<<grid, 256, 0, st>>>((const __bf16 *)map, coords, out, B, H, W, C, S, mode, fr);
+    else if (dtype == GWD_F32) point_sample_fwd_kernel<float><<<grid, 256, 0, st>>>((const float *)map, coords, out, B, H, W, C, S, mode, fr);
+    else return -2;
     GWD_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int gwd_point_sample_forward(const void *map, const float *coords, float *out, int32_t B, int32_t H, int32_t W,
                                         int32_t C, int32_t S, int32_t mode, int32_t dtype, void *stream) {
-    if (!map || !coords || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || S <= 0 || (mode != 0 && mode != 1)) return -1;
-    const int64_t total = (int64_t)B * S * C;
-    int64_t nb = (total + 255) / 256;
-    const int grid = (int)(nb > 4096 ? 4096 : nb);
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == GWD_BF16) point_sample_fwd_kernel<__bf16><<<grid, 256, 0, st>>>((const __bf16 *)map, coords, out, B, H, W, C, S, mode);
-    else if (dtype == GWD_F32) point_sample_fwd_kernel<float><<<grid, 256, 0, st>>>((const float *)map, coords, out, B, H, W, C, S, mode);
-    else return -2;
-    GWD_CHECK_LAUNCH();
-    return 0;
+    return point_sample_forward(map, coords, out, B, H, W, C, S, mode, dtype, stream, Frame{0, 0, 0});
+}
+
+// Nearest sampling in the padded / rolled frame (see Frame): Hf >= H, Wf >= W, 0 <= shift < min(Hf, Wf).  The backward is the gather form
+// (every element of gmap written; -4 when S > 256: build the frame with pad + roll and use the plain entry points).
+extern "C" int gwd_point_sample_framed_forward(const void *map, const float *coords, float *out, int32_t B, int32_t H, int32_t W, int32_t C,
+                                               int32_t S, int32_t Hf, int32_t Wf, int32_t shift, int32_t dtype, void *stream) {
+    if (Hf < H || Wf < W || shift < 0 || shift >= Hf || shift >= Wf) return -1;
+    return point_sample_forward(map, coords, out, B, H, W, C, S, 1, dtype, stream, Frame{Hf, Wf, shift});
+}
+extern "C" int gwd_point_sample_framed_backward(const float *gout, const float *coords, void *gmap, int32_t B, int32_t H, int32_t W, int32_t C,
+                                                int32_t S, int32_t Hf, int32_t Wf, int32_t shift, int32_t dtype, void *stream) {
+    if (Hf < H || Wf < W || shift < 0 || shift >= Hf || shift >= Wf) return -1;
+    return point_sample_backward_gather(gout, coords, gmap, B, H, W, C, S, 1, dtype, stream, Frame{Hf, Wf, shift});
 }
 
 extern "C" int gwd_point_sample_backward(const float *gout, const float *coords, void *gmap, int32_t B, int32_t H, int32_t W,

@@ -32,7 +32,7 @@ ENTRY_POINTS = [
     "gwd_plane_loss_forward", "gwd_plane_loss_backward", "gwd_collate",
     "gwd_anchor_depth_forward", "gwd_anchor_depth_backward", "gwd_mha_flash_forward", "gwd_mha_flash_backward",
     "gwd_ref_scores_forward", "gwd_ref_scores_backward", "gwd_ref_mix_forward", "gwd_ref_mix_backward", "gwd_unpad_add_batch", "gwd_stem_pack", "gwd_stem_forward", "gwd_pos_sine", "gwd_silog_finalize", "gwd_psp_pool_forward", "gwd_psp_pool_backward",
-    "gwd_match_cost", "gwd_set_losses_forward", "gwd_set_losses_backward", "gwd_resample_u8_pass", "gwd_gather2d", "gwd_point_sample_backward_gather", "gwd_stride_place", "gwd_color_adjust", "gwd_bmm",
+    "gwd_match_cost", "gwd_set_losses_forward", "gwd_set_losses_backward", "gwd_resample_u8_pass", "gwd_gather2d", "gwd_point_sample_backward_gather", "gwd_point_sample_framed_forward", "gwd_point_sample_framed_backward", "gwd_stride_place", "gwd_color_adjust", "gwd_bmm",
 ]
 
 
@@ -227,6 +227,8 @@ class HipLibrary:
         L.gwd_point_sample_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_point_sample_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_point_sample_backward_gather.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+        L.gwd_point_sample_framed_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+        L.gwd_point_sample_framed_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_weight_prep_batch.argtypes = [vp, i32, i32, vp, vp]
         L.gwd_window_map.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.gwd_window_map_multi.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -779,6 +781,18 @@ class HipLibrary:
             return False
         self._check(rc, "gwd_point_sample_backward_gather")
         return True
+
+    def point_sample_framed_forward(self, fmap, coords, out, B, H, W, C, S, frame):
+        """Nearest sampling in the padded / rolled (Hf, Wf, shift) frame of the map, without building it."""
+        Hf, Wf, shift = frame
+        self._check(self.lib.gwd_point_sample_framed_forward(_ptr(fmap), _ptr(coords), _ptr(out), B, H, W, C, S, Hf, Wf, shift, dtype_code(fmap),
+                                                             self._stream(fmap, out)), "gwd_point_sample_framed_forward")
+
+    def point_sample_framed_backward(self, gout, coords, gmap, B, H, W, C, S, frame):
+        """Every element of gmap written; S <= 256 (the caller checks before choosing the framed form)."""
+        Hf, Wf, shift = frame
+        self._check(self.lib.gwd_point_sample_framed_backward(_ptr(gout), _ptr(coords), _ptr(gmap), B, H, W, C, S, Hf, Wf, shift, dtype_code(gmap),
+                                                              self._stream(gout, gmap)), "gwd_point_sample_framed_backward")
 
     def point_sample_backward(self, gout, coords, gmap, B, H, W, C, S, mode):
         self._check(self.lib.gwd_point_sample_backward(_ptr(gout), _ptr(coords), _ptr(gmap), B, H, W, C, S, mode, dtype_code(gmap),

@@ -536,7 +536,6 @@ class SwinBlock(nn.Module):
         Hp, Wp = (H + WS - 1) // WS * WS, (W + WS - 1) // WS * WS
         mask = shift_regions(Hp, Wp, x.device) if shift else None
         if dtok is None:
-            sx, _, _ = pad_roll(xn, H, W, shift)
             if shift:                                                             # :678-686
                 rc = torch.stack([ref_coors[..., 0] - (shift / (Wp - 1)) * 2,
                                   ref_coors[..., 1] - (shift / (Hp - 1)) * 2], dim=-1)
@@ -544,7 +543,8 @@ class SwinBlock(nn.Module):
                 rpos = torch.roll(ref_pos, shifts=(-shift, -shift), dims=(1, 2))
             else:
                 rc, rpos = ref_coors, ref_pos
-            x_ref = (ops.point_sample(sx, rc, nearest=True) + ops.point_sample(rpos, rc, nearest=True)).to(x.dtype)   # (B, S, C)
+            # the padded / rolled map (sx of :662-676) is never built: the points are sampled in its frame
+            x_ref = (ops.point_sample(xn, rc, nearest=True, frame=(Hp, Wp, shift)) + ops.point_sample(rpos, rc, nearest=True)).to(x.dtype)   # (B, S, C)
             aw = self.attn(ops.window_gather(xn, shift), x_ref, mask)          # == window_partition(sx), one index-remapping copy
         else:
             tC = dtok.shape[-1]

@@ -1814,7 +1814,43 @@ class _PointSampleFn(torch.autograd.Function):
         return gmap, None, None
 
 
-def point_sample(fmap, coords, nearest=False):
+class _PointSampleFramedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fmap, coords, frame):
+        fmap = fmap.contiguous()
+        B, H, W, C = fmap.shape
+        coords = coords.detach().reshape(B, -1, 2).float().contiguous()
+        S = coords.shape[1]
+        out = torch.empty((B, S, C), dtype=torch.float32, device=fmap.device)
+        _lib().point_sample_framed_forward(fmap, coords, out, B, H, W, C, S, frame)
+        ctx.save_for_backward(coords)
+        ctx.cfg = (B, H, W, C, S, frame, fmap.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (coords,) = ctx.saved_tensors
+        B, H, W, C, S, frame, dtype = ctx.cfg
+        gmap = torch.empty((B, H, W, C), dtype=dtype, device=gout.device)
+        _lib().point_sample_framed_backward(gout.float().contiguous(), coords, gmap, B, H, W, C, S, frame)
+        return gmap, None, None
+
+
+def point_sample(fmap, coords, nearest=False, frame=None):
     """F.grid_sample(map, coords (B,S,1,2) or (B,S,2), align_corners=False, zeros padding) on a pixel-major map
-    (B,H,W,C) -> fp32 (B,S,C); gradient to the map only."""
+    (B,H,W,C) -> fp32 (B,S,C); gradient to the map only.  frame = (Hf, Wf, shift), nearest only: the map as
+    torch.roll(F.pad(map, to (Hf, Wf)), (-shift, -shift), (1, 2)) presents it (the shifted-window frame of the 1/32 stage), sampled in place."""
+    if frame is not None:
+        Hf, Wf, shift = (int(v) for v in frame)
+        B, H, W, _ = fmap.shape
+        if (Hf, Wf, shift) == (H, W, 0):
+            frame = None
+        elif not nearest:
+            raise ValueError("point_sample: a frame needs nearest sampling")
+        elif coords.numel() // (2 * B) <= 256:
+            return _PointSampleFramedFn.apply(fmap, coords, (Hf, Wf, shift))
+        else:                                               # more points than the gather backward stages: build the frame
+            fmap = torch.nn.functional.pad(fmap, (0, 0, 0, Wf - W, 0, Hf - H))
+            if shift:
+                fmap = torch.roll(fmap, shifts=(-shift, -shift), dims=(1, 2))
     return _PointSampleFn.apply(fmap, coords, 1 if nearest else 0)

@@ -313,6 +313,15 @@ int gwd_point_sample_backward(const float *gout, const float *coords, void *gmap
 int gwd_point_sample_backward_gather(const float *gout, const float *coords, void *gmap, int32_t B, int32_t H, int32_t W, int32_t C,
                                      int32_t S, int32_t mode, int32_t dtype, void *stream);
 
+/* Nearest sampling of the map as torch.roll(F.pad(map, to (Hf, Wf)), (-shift, -shift), (1, 2)) presents it - the shifted-window frame
+ * the 1/32 stage samples its reference points in (multiscale_transformerr.py:662-691) - without building that tensor: coords address
+ * the (Hf, Wf) frame, frame pixel (y, x) is map pixel ((y + shift) mod Hf, (x + shift) mod Wf), zero in the padding.  The backward
+ * writes every element of gmap (gather form); -4 when S > 256 (pad + roll, then the plain entry points).                          */
+int gwd_point_sample_framed_forward(const void *map, const float *coords, float *out, int32_t B, int32_t H, int32_t W, int32_t C,
+                                    int32_t S, int32_t Hf, int32_t Wf, int32_t shift, int32_t dtype, void *stream);
+int gwd_point_sample_framed_backward(const float *gout, const float *coords, void *gmap, int32_t B, int32_t H, int32_t W, int32_t C,
+                                     int32_t S, int32_t Hf, int32_t Wf, int32_t shift, int32_t dtype, void *stream);
+
 /* gwd_weight_prep for many weights in one launch (bf16 outputs).  `jobs` is a DEVICE array; job i owns the blocks
  * [block0_i, block0_{i+1}) of the launch, one 32(n) x 32(c) tile of one tap each: blocks_i = taps*ceil(N/32)*ceil(C/32),
  * block0_0 = 0, total_blocks = sum of blocks_i.

@@ -727,6 +727,24 @@ class FakeDevice:
                           mode="nearest" if mode == 1 else "bilinear", align_corners=False)
         out.copy_(r.reshape(B, C, S).permute(0, 2, 1).reshape(out.shape))
 
+    @staticmethod
+    def _framed(fmap, frame):
+        """The padded / rolled frame itself, as the reference builds it (multiscale_transformerr.py:662-676)."""
+        Hf, Wf, shift = frame
+        t = F.pad(fmap, (0, 0, 0, Wf - fmap.shape[2], 0, Hf - fmap.shape[1]))
+        return torch.roll(t, shifts=(-shift, -shift), dims=(1, 2)) if shift else t
+
+    def point_sample_framed_forward(self, fmap, coords, out, B, H, W, C, S, frame):
+        self.point_sample_forward(self._framed(fmap.reshape(B, H, W, C), frame), coords, out, B, frame[0], frame[1], C, S, 1)
+
+    def point_sample_framed_backward(self, gout, coords, gmap, B, H, W, C, S, frame):
+        Hf, Wf, shift = frame
+        gf = torch.zeros(B, Hf, Wf, C)
+        self.point_sample_backward(gout, coords, gf, B, Hf, Wf, C, S, 1)
+        if shift:
+            gf = torch.roll(gf, shifts=(shift, shift), dims=(1, 2))
+        gmap.copy_(gf[:, :H, :W].to(gmap.dtype))
+
     def point_sample_backward_gather(self, gout, coords, gmap, B, H, W, C, S, mode):
         gmap.zero_()
         self.point_sample_backward(gout, coords, gmap, B, H, W, C, S, mode)

@@ -399,6 +399,34 @@ def test_token_attention(dev, e, nwin, dtype):
     assert rel(o, o_r) < TOL[dtype] and rel(gq, gq_r) < TOL[dtype] and rel(gkv, gkv_r) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("H,W,shift,S", [(15, 20, 3, 100), (15, 20, 0, 100), (21, 21, 3, 64), (7, 9, 6, 256), (15, 20, 3, 300)])
+def test_point_sample_in_the_padded_rolled_frame(dev, H, W, shift, S, dtype):
+    """ops.point_sample(frame=...) == nearest sampling of torch.roll(F.pad(map), -shift): forward and map gradient (S > 256 builds the frame)."""
+    from gw_depth_amd import ops
+    B, C, WS = 2, 64, 7
+    Hf, Wf = (H + WS - 1) // WS * WS, (W + WS - 1) // WS * WS
+    fmap = rnd(B, H, W, C, dtype=dtype, seed=1)
+    g = torch.Generator().manual_seed(2)
+    coords = torch.rand(B, S, 2, generator=g) * 2.4 - 1.2                      # some points outside the frame
+    # exact pixel centres and points on the frame's far rows / columns (padding) as well
+    coords[:, :8, 0] = (2 * torch.arange(8).float() % Wf + 1) / Wf - 1
+    coords[:, :8, 1] = (2 * (Hf - 1 - torch.arange(8).float() % Hf) + 1) / Hf - 1
+    gout = torch.randn(B, S, C, generator=g)
+    fake = FakeDevice()
+    ref = torch.empty(B, S, C)
+    fake.point_sample_framed_forward(fmap, coords, ref, B, H, W, C, S, (Hf, Wf, shift))
+    gref = torch.empty(B, H, W, C, dtype=dtype)
+    fake.point_sample_framed_backward(gout, coords, gref, B, H, W, C, S, (Hf, Wf, shift))
+    x = fmap.cuda().requires_grad_(True)
+    out = ops.point_sample(x, coords.cuda(), nearest=True, frame=(Hf, Wf, shift))
+    (gx,) = torch.autograd.grad(out, [x], gout.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref)
+    assert rel(gx, gref) < TOL[dtype]
+    assert (ref.abs().sum(-1) == 0).any() and (ref.abs().sum(-1) > 0).any()         # both padding / outside hits and real samples occurred
+
+
 @pytest.mark.parametrize("Cout,Cin", [(64, 64), (32, 64), (160, 96), (1, 3)])
 def test_upsample_taps_collapse_and_fold(dev, Cout, Cin):
     """gwd_upsample_taps_collapse / _fold against the element-wise formulas (3x3 over a 2x nearest-upsampled map == 4x4 / stride 2 taps)."""
