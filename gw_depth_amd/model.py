@@ -537,10 +537,16 @@ class SwinBlock(nn.Module):
         mask = shift_regions(Hp, Wp, x.device) if shift else None
         if dtok is None:
             if shift:                                                             # :678-686
-                rc = torch.stack([ref_coors[..., 0] - (shift / (Wp - 1)) * 2,
-                                  ref_coors[..., 1] - (shift / (Hp - 1)) * 2], dim=-1)
-                rc = torch.where(rc < -1, -2 - rc, rc)
-                rpos = torch.roll(ref_pos, shifts=(-shift, -shift), dims=(1, 2))
+                # the shifted blocks of a layer get the same points: shifted coordinates / rolled position map made once per forward
+                memo = getattr(ref_coors, "_gwd_shifted", None)
+                if memo is None or memo[0] != (shift, Hp, Wp) or memo[1] is not ref_pos:
+                    rc = torch.stack([ref_coors[..., 0] - (shift / (Wp - 1)) * 2,
+                                      ref_coors[..., 1] - (shift / (Hp - 1)) * 2], dim=-1)
+                    rc = torch.where(rc < -1, -2 - rc, rc)
+                    rpos = torch.roll(ref_pos, shifts=(-shift, -shift), dims=(1, 2))
+                    ref_coors._gwd_shifted = ((shift, Hp, Wp), ref_pos, rc, rpos)
+                else:
+                    rc, rpos = memo[2], memo[3]
             else:
                 rc, rpos = ref_coors, ref_pos
             # the padded / rolled map (sx of :662-676) is never built: the points are sampled in its frame
